@@ -1,0 +1,128 @@
+/* libknpemi_hip.so -- C ABI of the MI355X-native DG assemble-and-solve path of knpemidg.Solver.
+ *
+ * This is the drop-in seam that replaces, inside adajel/KNP-EMI-DG's `Solver`,
+ *   - UFL form assembly      dolfin.assemble(a_emi|L_emi|B_emi|A_knp|L_knp)   src/knpemidg/solver.py:452-453,477-479,710,730-731
+ *   - the PETSc matrix build  as_backend_type(...).mat()                      src/knpemidg/solver.py:458-460,482-484,711-712,734-735
+ *   - the PETSc KSP solves    ksp.solve (cg / gmres + hypre)                  src/knpemidg/solver.py:509,755,771
+ *   - the step-III projections pcws_constant_project / project               src/knpemidg/solver.py:808-845, utils.py:100-124
+ * with matrix-free HIP kernels.  All functions are extern "C", take plain pointers and sizes,
+ * return 0 on success and a negative status on failure (message: knp_last_error).  The caller
+ * owns every host buffer; the context owns every device buffer.  One host thread per context,
+ * one HIP stream per context; calls are synchronous with respect to the host unless noted.
+ *
+ * DoF layout (build-defined): scalar DG-p field  dof(c, j) = c*nd + j ;
+ * species-major for the KNP unknown [k][c][j] ; facet fields one value per facet.
+ * Cells hold ASCENDING vertex ids; local facet i is opposite local vertex i.
+ */
+#ifndef KNPEMI_HIP_H
+#define KNPEMI_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct knp_ctx knp_ctx;
+
+/* device-resident fields addressable through knp_upload / knp_download / knp_*_apply */
+enum knp_field {
+    KNP_F_PHI = 0,       /* potential phi                    [nc*nd]          Solver.phi          solver.py:165 */
+    KNP_F_C = 1,         /* solved concentrations c          [n_sys][nc*nd]   Solver.c / c_prev_k solver.py:172-176 */
+    KNP_F_C_PREV = 2,    /* c at previous time level         [n_sys][nc*nd]   Solver.c_prev_n     solver.py:174 */
+    KNP_F_C_ELIM = 3,    /* eliminated ion                   [nc*nd]          ion_list[-1]['c']   solver.py:191 */
+    KNP_F_PHI_M = 4,     /* membrane potential on facets     [nf]             phi_M_prev_PDE      solver.py:214 */
+    KNP_F_I_CH = 5,      /* channel currents per ion         [n_ions][nf]     mem_models[..]['I_ch_k'] solver.py:251-259 */
+    KNP_F_E = 6,         /* Nernst potentials per ion        [n_ions][nf]     ion['E']            solver.py:299-300 */
+    KNP_F_KAPPA = 7,     /* kappa (derived)                  [nc*nd]          solver.py:306 */
+    KNP_F_DNPHI = 8,     /* grad(phi).n per local facet      [nc*nd]          (derived, feeds solver.py:583,593) */
+    KNP_F_B_EMI = 9,     /* assembled L_emi                  [nc*nd]          bb_emi              solver.py:478 */
+    KNP_F_B_KNP = 10,    /* assembled L_knp                  [n_sys][nc*nd]   bb_knp              solver.py:731 */
+    KNP_F_X = 11,        /* scratch vector                   [n_sys][nc*nd] */
+    KNP_F_Y = 12,        /* scratch vector                   [n_sys][nc*nd] */
+    KNP_F_FACET_TMP = 13,/* scratch facet field              [nf] */
+    KNP_F_COUNT = 14
+};
+
+/* ---- context -------------------------------------------------------------------------------
+ * Uploads the mesh and derives the per-(cell, local facet) neighbour / flag tables and the
+ * membrane facet table.  Replaces Solver.setup_domain + interface_normal + subdomain_marking_foo
+ * (solver.py:85-121, utils.py:44-85).
+ *  cells        i32[nc][dim+1] ascending vertex ids; cells [0,nc_owned) are owned, the rest are ghosts
+ *  cell_tags    u32[nc]         subdomain tags (0 = ECS)
+ *  facet_cells  i32[nf][2]      cells sharing each facet, -1 = none
+ *  facet_local  i8 [nf][2]      local facet index within those cells
+ *  facet_tags   u32[nf]         0 = ordinary interior facet (solver.py:60), membrane tags listed in membrane_tags
+ */
+int knp_ctx_create(knp_ctx** out, int device, int dim, int degree, int n_ions,
+                   int64_t nv, int64_t nc, int64_t nc_owned, int64_t nf,
+                   const double* coords, const int32_t* cells, const uint32_t* cell_tags,
+                   const int32_t* facet_cells, const int8_t* facet_local, const uint32_t* facet_tags,
+                   int n_membrane_tags, const uint32_t* membrane_tags);
+void knp_ctx_destroy(knp_ctx* ctx);
+const char* knp_last_error(knp_ctx* ctx);
+
+/* Physical parameters (Solver.setup_parameters, solver.py:124-154; tau: solver.py:109-111).
+ *  z[n_ions], D[n_ions][nc] (make_global, solver.py:1244-1258), rho[nc], fsrc[n_sys][nc] or NULL
+ *  (ion['f_source'] on dx(0), solver.py:599), splitting: solver.py:332-337, 614-622. */
+int knp_set_params(knp_ctx* ctx, double C_M, double dt, double F, double R, double T, double C_phi,
+                   double tau_emi, double tau_knp, const double* z, const double* D, const double* rho,
+                   const double* fsrc, int splitting);
+
+int64_t knp_field_size(knp_ctx* ctx, int field);
+int knp_upload(knp_ctx* ctx, int field, const double* src, int64_t offset, int64_t count);
+int knp_download(knp_ctx* ctx, int field, double* dst, int64_t offset, int64_t count);
+int knp_copy_field(knp_ctx* ctx, int dst_field, int src_field);
+
+/* ---- per-step coefficient updates ----------------------------------------------------------- */
+int knp_update_kappa(knp_ctx* ctx);        /* KAPPA <- C, C_ELIM                (solver.py:303-306) */
+int knp_update_dnphi(knp_ctx* ctx);        /* DNPHI <- PHI                      (feeds solver.py:583,593) */
+
+/* ---- operator applies (matrix-free MatMult) --------------------------------------------------
+ * fy = A_emi(KAPPA) fx  on scalar fields;   fy = A_knp(DNPHI) fx  on [n_sys] species-major fields. */
+int knp_emi_apply(knp_ctx* ctx, int fx, int fy);
+int knp_knp_apply(knp_ctx* ctx, int fx, int fy);
+
+/* ---- right-hand sides ------------------------------------------------------------------------ */
+int knp_emi_rhs(knp_ctx* ctx);             /* B_EMI <- L_emi(C, C_ELIM, PHI_M, I_CH)          solver.py:478 */
+int knp_knp_rhs(knp_ctx* ctx);             /* B_KNP <- L_knp(C, C_PREV, C_ELIM, PHI, PHI_M, I_CH) solver.py:731 */
+
+/* ---- solves (KSP.solve) ----------------------------------------------------------------------
+ * EMI: PCG, cell-block-Jacobi; converged when ||M^-1 r|| <= max(rtol ||M^-1 b||, atol) (PETSc's default
+ *      preconditioned-norm test, solver.py:425-444); initial guess = PHI (ksp_initial_guess_nonzero).
+ * KNP: per-species BiCGStab, cell-block-Jacobi, true residual ||r|| <= max(rtol ||b||, atol), at least
+ *      min_it iterations (ksp_min_it, solver.py:686); initial guess = C.
+ * niter: iterations (EMI: 1 int, KNP: n_sys ints); res: per system {res0, res, bnorm}.
+ * Returns -3 if not converged within maxit (ksp_error_if_not_converged, solver.py:428). */
+int knp_emi_solve(knp_ctx* ctx, double rtol, double atol, int maxit, int check_every, int* niter, double* res);
+int knp_knp_solve(knp_ctx* ctx, double rtol, double atol, int maxit, int min_it, int check_every, int* niter, double* res);
+
+/* ---- step III (solver.py:808-845) -------------------------------------------------------------
+ * C_PREV <- C ; PHI_M <- facet-avg(phi_i - phi_e) ; C_ELIM <- -(sum z_k c_k + rho)/z_N ; E <- Nernst. */
+int knp_step_updates(knp_ctx* ctx);
+int knp_nernst(knp_ctx* ctx);              /* E only, from the current C / C_ELIM (solver.py:299-300) */
+/* FACET_TMP <- facet average of the plus (side 0, ECS-like) or minus (side 1) trace of a nodal field;
+ * species indexes into [n_sys] fields (update_ode hook, examples/idealized-geometries/run_3D.py:39-51). */
+int knp_facet_trace(knp_ctx* ctx, int field, int species, int side);
+
+/* ---- timing / sync ------------------------------------------------------------------------------ */
+int knp_sync(knp_ctx* ctx);
+int knp_timer_begin(knp_ctx* ctx);         /* records a HIP event on the context's stream */
+int knp_timer_end(knp_ctx* ctx, float* ms);/* records, synchronises, returns elapsed ms */
+/* Launches `reps` back-to-back applies (which: 0 = EMI, 1 = KNP) on X -> Y and returns the average
+ * kernel duration measured with HIP events on the stream the kernel runs on. */
+int knp_bench_apply(knp_ctx* ctx, int which, int reps, float* avg_ms);
+
+/* ---- multi-GPU (one process per GPU, RCCL over xGMI) ------------------------------------------------
+ * Replaces DOLFIN ghosting + PETSc VecGhost/MatMult scatters + KSP reductions (solver.py:16,529,789). */
+int knp_comm_unique_id(char* out128);
+int knp_comm_init(knp_ctx* ctx, int rank, int nranks, const char* id128);
+/* send_cells: owned cell ids whose DoFs peer p needs, grouped by peer; ghosts of peer p occupy
+ * cells [recv_offsets[p], recv_offsets[p]+recv_counts[p]). */
+int knp_halo_tables(knp_ctx* ctx, int npeers, const int32_t* peers, const int64_t* send_counts,
+                    const int32_t* send_cells, const int64_t* recv_offsets, const int64_t* recv_counts);
+int knp_halo_exchange(knp_ctx* ctx, int field);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,388 @@
+// C ABI of libknpemi_hip.so (see include/knpemi_hip.h for the contract and the reference
+// interfaces each entry point replaces).
+#include "../../include/knpemi_hip.h"
+#include "knpemi_internal.hpp"
+#include "krylov.hpp"
+#include <cstring>
+#include <algorithm>
+
+namespace {
+
+struct Fields {
+    double* f[KNP_F_COUNT] = {nullptr};
+    int64_t n[KNP_F_COUNT] = {0};
+    // solver workspace
+    double *binv_emi = nullptr, *binv_knp = nullptr;
+    double *r = nullptr, *z = nullptr, *p = nullptr, *w = nullptr, *rhat = nullptr, *v = nullptr, *y = nullptr;
+};
+
+std::map<knp_ctx*, Fields*> g_fields;
+thread_local std::string g_err;
+
+Fields* F(knp_ctx* c) { return g_fields[c]; }
+
+template <typename T> int dev_alloc_copy(knp_ctx* c, T** dst, const T* src, size_t n) {
+    HIPCHK(c, hipMalloc((void**)dst, std::max<size_t>(n, 1) * sizeof(T)));
+    if (src && n) HIPCHK(c, hipMemcpy(*dst, src, n * sizeof(T), hipMemcpyHostToDevice));
+    return 0;
+}
+
+int dev_zeros(knp_ctx* c, double** dst, size_t n) {
+    HIPCHK(c, hipMalloc((void**)dst, std::max<size_t>(n, 1) * sizeof(double)));
+    HIPCHK(c, hipMemset(*dst, 0, std::max<size_t>(n, 1) * sizeof(double)));
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* knp_last_error(knp_ctx* ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
+
+int knp_ctx_create(knp_ctx** out, int device, int dim, int degree, int n_ions, int64_t nv, int64_t nc, int64_t nc_owned,
+                   int64_t nf, const double* coords, const int32_t* cells, const uint32_t* cell_tags,
+                   const int32_t* facet_cells, const int8_t* facet_local, const uint32_t* facet_tags, int n_membrane_tags,
+                   const uint32_t* membrane_tags) {
+    if (!out) return -1;
+    *out = nullptr;
+    if (dim != 2 && dim != 3) { g_err = "dim must be 2 or 3"; return -1; }
+    if (degree != 1) { g_err = "only degree 1 is implemented on the device path"; return -1; }
+    if (n_ions < 2 || n_ions > KNP_MAX_IONS) { g_err = "n_ions out of range"; return -1; }
+    if (nc_owned < 0 || nc_owned > nc) { g_err = "nc_owned out of range"; return -1; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { g_err = "no HIP device visible"; return -5; }
+    if (device < 0 || device >= ndev) { g_err = "device index out of range"; return -5; }
+    knp_ctx* c = new knp_ctx();
+    c->device = device;
+    c->degree = degree;
+    const int NV = dim + 1;
+    c->nd = NV;
+    c->p.n_ions = n_ions;
+    c->p.n_sys = n_ions - 1;
+    if (hipSetDevice(device) != hipSuccess) { g_err = "hipSetDevice failed"; delete c; return -5; }
+    if (hipStreamCreate(&c->stream) != hipSuccess) { g_err = "hipStreamCreate failed"; delete c; return -5; }
+    hipEventCreate(&c->ev0);
+    hipEventCreate(&c->ev1);
+
+    // ---- host-side validation + derived tables ------------------------------------------------
+    for (int64_t i = 0; i < nc * NV; ++i)
+        if (cells[i] < 0 || cells[i] >= nv) { g_err = "cell vertex index out of range"; delete c; return -1; }
+    for (int64_t k = 0; k < nc; ++k)
+        for (int a = 1; a < NV; ++a)
+            if (cells[k * NV + a] <= cells[k * NV + a - 1]) { g_err = "cells must hold ascending vertex ids"; delete c; return -1; }
+    std::vector<int32_t> nbr(nc * NV, -1), cfacet(nc * NV, -1);
+    std::vector<uint32_t> fflag(nc, 0);
+    std::vector<uint8_t> fb(nc * NV, (uint8_t)(FK_EXTERIOR << 2));
+    std::vector<int32_t> mf;
+    auto is_mem = [&](uint32_t t) {
+        for (int i = 0; i < n_membrane_tags; ++i) if (membrane_tags[i] == t) return true;
+        return false;
+    };
+    for (int64_t f = 0; f < nf; ++f) {
+        const int64_t c0 = facet_cells[2 * f], c1 = facet_cells[2 * f + 1];
+        const int l0 = facet_local[2 * f], l1 = facet_local[2 * f + 1];
+        if (c0 < 0 || c0 >= nc || l0 < 0 || l0 >= NV || c1 >= nc || (c1 >= 0 && (l1 < 0 || l1 >= NV))) {
+            g_err = "facet table entry out of range"; delete c; return -1;
+        }
+        cfacet[c0 * NV + l0] = (int32_t)f;
+        if (c1 < 0) continue;
+        cfacet[c1 * NV + l1] = (int32_t)f;
+        const uint32_t t = facet_tags[f];
+        const uint32_t kind = (t == 0) ? FK_SIPG : (is_mem(t) ? FK_MEMBRANE : FK_INACTIVE);
+        // plus (normal-leaving, lower tag) side; on equal tags the reference takes n('-'), i.e. side 1
+        const int e_side = (cell_tags[c0] >= cell_tags[c1]) ? 1 : 0;
+        nbr[c0 * NV + l0] = (int32_t)c1;
+        nbr[c1 * NV + l1] = (int32_t)c0;
+        fb[c0 * NV + l0] = (uint8_t)((l1 & 3) | (kind << 2) | ((e_side == 0 ? 1u : 0u) << 4));
+        fb[c1 * NV + l1] = (uint8_t)((l0 & 3) | (kind << 2) | ((e_side == 1 ? 1u : 0u) << 4));
+        if (kind == FK_MEMBRANE) {
+            const int64_t ce = e_side == 0 ? c0 : c1, ci = e_side == 0 ? c1 : c0;
+            const int le = e_side == 0 ? l0 : l1, li = e_side == 0 ? l1 : l0;
+            const int active = (ce < nc_owned || ci < nc_owned) ? 1 : 0;
+            mf.insert(mf.end(), {(int32_t)ce, (int32_t)ci, le, li, (int32_t)f, active});
+        }
+    }
+    for (int64_t k = 0; k < nc; ++k) {
+        uint32_t w = 0;
+        for (int a = 0; a < NV; ++a) w |= (uint32_t)fb[k * NV + a] << (8 * a);
+        fflag[k] = w;
+    }
+    // owned cells must have every neighbour present (one ghost layer)
+    for (int64_t k = 0; k < nc_owned; ++k)
+        for (int a = 0; a < NV; ++a)
+            if (cfacet[k * NV + a] < 0) { g_err = "owned cell with a facet missing from the facet table"; delete c; return -1; }
+
+    MeshDev& m = c->m;
+    m.dim = dim; m.nv = nv; m.nc = nc; m.nc_owned = nc_owned; m.nf = nf; m.nmf = (int64_t)mf.size() / 6;
+    std::vector<double> cpad;
+    const double* csrc = coords;
+    size_t cstride = dim;
+    if (dim == 3) {
+        cpad.resize(nv * 4, 0.0);
+        for (int64_t v = 0; v < nv; ++v) for (int k = 0; k < 3; ++k) cpad[4 * v + k] = coords[3 * v + k];
+        csrc = cpad.data();
+        cstride = 4;
+    }
+    int rc = 0;
+    rc |= dev_alloc_copy(c, &m.coords, csrc, (size_t)nv * cstride);
+    rc |= dev_alloc_copy(c, &m.cells, cells, (size_t)nc * NV);
+    rc |= dev_alloc_copy(c, &m.nbr, nbr.data(), nbr.size());
+    rc |= dev_alloc_copy(c, &m.fflag, fflag.data(), fflag.size());
+    rc |= dev_alloc_copy(c, &m.cfacet, cfacet.data(), cfacet.size());
+    rc |= dev_alloc_copy(c, &m.mf, mf.data(), mf.size());
+    if (rc) { g_err = c->err; delete c; return -2; }
+
+    Fields* fl = new Fields();
+    const int64_t ndof = nc * NV, ns = c->p.n_sys;
+    const int64_t sizes[KNP_F_COUNT] = {ndof, ns * ndof, ns * ndof, ndof, nf, n_ions * nf, n_ions * nf, ndof, ndof,
+                                        ndof, ns * ndof, ns * ndof, ns * ndof, nf};
+    for (int i = 0; i < KNP_F_COUNT; ++i) {
+        fl->n[i] = sizes[i];
+        rc |= dev_zeros(c, &fl->f[i], sizes[i]);
+    }
+    rc |= dev_zeros(c, &fl->binv_emi, ndof * NV);
+    rc |= dev_zeros(c, &fl->binv_knp, ns * ndof * NV);
+    double** wk[] = {&fl->r, &fl->z, &fl->p, &fl->w, &fl->rhat, &fl->v, &fl->y};
+    for (auto pp : wk) rc |= dev_zeros(c, pp, ns * ndof);
+    rc |= dev_zeros(c, &c->D, (size_t)n_ions * nc);
+    rc |= dev_zeros(c, &c->rho, nc);
+    c->partial_blocks = grid_for(nc_owned) + 8;
+    rc |= dev_zeros(c, &c->partial, (size_t)c->partial_blocks * KNP_MAX_SYS * KNP_MAX_RED);
+    rc |= dev_zeros(c, &c->scal, KNP_MAX_SYS * KS_N + KNP_MAX_SYS * KNP_MAX_RED);
+    if (!rc && hipMalloc((void**)&c->status, sizeof(int) * 2 * KNP_MAX_SYS) != hipSuccess) rc = -2;
+    if (!rc) hipMemset(c->status, 0, sizeof(int) * 2 * KNP_MAX_SYS);
+    if (!rc && hipHostMalloc(&c->pinned, 4096) != hipSuccess) rc = -2;
+    if (rc) { g_err = "device allocation failed: " + c->err; delete fl; delete c; return -2; }
+    g_fields[c] = fl;
+    *out = c;
+    return 0;
+}
+
+void knp_ctx_destroy(knp_ctx* c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    hipDeviceSynchronize();
+    Fields* fl = g_fields[c];
+    if (fl) {
+        for (int i = 0; i < KNP_F_COUNT; ++i) hipFree(fl->f[i]);
+        double* wk[] = {fl->binv_emi, fl->binv_knp, fl->r, fl->z, fl->p, fl->w, fl->rhat, fl->v, fl->y};
+        for (auto p : wk) hipFree(p);
+        delete fl;
+        g_fields.erase(c);
+    }
+    hipFree(c->m.coords); hipFree(c->m.cells); hipFree(c->m.nbr); hipFree(c->m.fflag); hipFree(c->m.cfacet); hipFree(c->m.mf);
+    hipFree(c->D); hipFree(c->rho); hipFree(c->fsrc); hipFree(c->partial); hipFree(c->scal); hipFree(c->status);
+    hipFree(c->halo_send_idx); hipFree(c->halo_sendbuf);
+    if (c->pinned) hipHostFree(c->pinned);
+    if (c->ev0) hipEventDestroy(c->ev0);
+    if (c->ev1) hipEventDestroy(c->ev1);
+
+    comm_destroy(c);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int knp_set_params(knp_ctx* c, double C_M, double dt, double Fc, double R, double T, double C_phi, double tau_emi,
+                   double tau_knp, const double* z, const double* D, const double* rho, const double* fsrc, int splitting) {
+    if (!c || !z || !D) return -1;
+    Params& p = c->p;
+    p.C_M = C_M; p.dt = dt; p.F = Fc; p.R = R; p.T = T; p.C_phi = C_phi; p.psi = Fc / (R * T);
+    p.tau_emi = tau_emi; p.tau_knp = tau_knp; p.splitting = splitting;
+    for (int i = 0; i < p.n_ions; ++i) {
+        p.z[i] = z[i];
+        if (z[i] == 0.0) { c->err = "ion valence z must be non-zero"; return -1; }
+    }
+    if (!(dt > 0.0)) { c->err = "dt must be positive"; return -1; }
+    HIPCHK(c, hipMemcpy(c->D, D, sizeof(double) * p.n_ions * c->m.nc, hipMemcpyHostToDevice));
+    if (rho) HIPCHK(c, hipMemcpy(c->rho, rho, sizeof(double) * c->m.nc, hipMemcpyHostToDevice));
+    else HIPCHK(c, hipMemset(c->rho, 0, sizeof(double) * c->m.nc));
+    if (fsrc) {
+        if (!c->fsrc) HIPCHK(c, hipMalloc((void**)&c->fsrc, sizeof(double) * p.n_sys * c->m.nc));
+        HIPCHK(c, hipMemcpy(c->fsrc, fsrc, sizeof(double) * p.n_sys * c->m.nc, hipMemcpyHostToDevice));
+    } else if (c->fsrc) {
+        hipFree(c->fsrc);
+        c->fsrc = nullptr;
+    }
+    return 0;
+}
+
+static int chk_field(knp_ctx* c, int field) {
+    if (!c) return -1;
+    if (field < 0 || field >= KNP_F_COUNT) { c->err = "unknown field id"; return -1; }
+    return 0;
+}
+
+int64_t knp_field_size(knp_ctx* c, int field) { return chk_field(c, field) ? -1 : F(c)->n[field]; }
+
+int knp_upload(knp_ctx* c, int field, const double* src, int64_t offset, int64_t count) {
+    if (chk_field(c, field)) return -1;
+    if (offset < 0 || count < 0 || offset + count > F(c)->n[field]) { c->err = "upload range out of bounds"; return -1; }
+    HIPCHK(c, hipMemcpyAsync(F(c)->f[field] + offset, src, sizeof(double) * count, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int knp_download(knp_ctx* c, int field, double* dst, int64_t offset, int64_t count) {
+    if (chk_field(c, field)) return -1;
+    if (offset < 0 || count < 0 || offset + count > F(c)->n[field]) { c->err = "download range out of bounds"; return -1; }
+    HIPCHK(c, hipMemcpyAsync(dst, F(c)->f[field] + offset, sizeof(double) * count, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int knp_copy_field(knp_ctx* c, int dst, int src) {
+    if (chk_field(c, dst) || chk_field(c, src)) return -1;
+    if (F(c)->n[dst] != F(c)->n[src]) { c->err = "copy_field: size mismatch"; return -1; }
+    HIPCHK(c, hipMemcpyAsync(F(c)->f[dst], F(c)->f[src], sizeof(double) * F(c)->n[src], hipMemcpyDeviceToDevice, c->stream));
+    return 0;
+}
+
+int knp_update_kappa(knp_ctx* c) {
+    if (!c) return -1;
+    Fields* f = F(c);
+    return launch_kappa(c, f->f[KNP_F_C], f->f[KNP_F_C_ELIM], f->f[KNP_F_KAPPA]);
+}
+
+int knp_update_dnphi(knp_ctx* c) {
+    if (!c) return -1;
+    Fields* f = F(c);
+    return launch_dnphi(c, f->f[KNP_F_PHI], f->f[KNP_F_DNPHI]);
+}
+
+static int chk_vec(knp_ctx* c, int fx, int fy, int64_t need) {
+    if (chk_field(c, fx) || chk_field(c, fy)) return -1;
+    if (fx == fy) { c->err = "apply: input and output fields must differ"; return -1; }
+    if (F(c)->n[fx] < need || F(c)->n[fy] < need) { c->err = "apply: field too small for this operator"; return -1; }
+    return 0;
+}
+
+int knp_emi_apply(knp_ctx* c, int fx, int fy) {
+    if (!c) return -1;
+    if (chk_vec(c, fx, fy, c->m.nc * c->nd)) return -1;
+    Fields* f = F(c);
+    if (c->nranks > 1) { int rc = halo_exchange(c, f->f[fx], 1); if (rc) return rc; }
+    return launch_emi_apply(c, f->f[fx], f->f[KNP_F_KAPPA], f->f[fy]);
+}
+
+int knp_knp_apply(knp_ctx* c, int fx, int fy) {
+    if (!c) return -1;
+    if (chk_vec(c, fx, fy, (int64_t)c->p.n_sys * c->m.nc * c->nd)) return -1;
+    Fields* f = F(c);
+    if (c->nranks > 1) { int rc = halo_exchange(c, f->f[fx], c->p.n_sys); if (rc) return rc; }
+    return launch_knp_apply(c, f->f[fx], f->f[KNP_F_DNPHI], f->f[fy]);
+}
+
+int knp_emi_rhs(knp_ctx* c) {
+    if (!c) return -1;
+    Fields* f = F(c);
+    return launch_emi_rhs(c, f->f[KNP_F_C], f->f[KNP_F_C_ELIM], f->f[KNP_F_PHI_M], f->f[KNP_F_I_CH], f->f[KNP_F_B_EMI]);
+}
+
+int knp_knp_rhs(knp_ctx* c) {
+    if (!c) return -1;
+    Fields* f = F(c);
+    return launch_knp_rhs(c, f->f[KNP_F_C], f->f[KNP_F_C_PREV], f->f[KNP_F_C_ELIM], f->f[KNP_F_PHI], f->f[KNP_F_PHI_M],
+                          f->f[KNP_F_I_CH], f->f[KNP_F_B_KNP]);
+}
+
+int knp_emi_solve(knp_ctx* c, double rtol, double atol, int maxit, int check_every, int* niter, double* res) {
+    if (!c || !niter || !res) return -1;
+    Fields* f = F(c);
+    int rc = launch_emi_blockjacobi(c, f->f[KNP_F_KAPPA], f->binv_emi);
+    if (rc) return rc;
+    KrylovVecs kv{};
+    kv.x = f->f[KNP_F_PHI]; kv.b = f->f[KNP_F_B_EMI]; kv.coef = f->f[KNP_F_KAPPA]; kv.binv = f->binv_emi;
+    kv.r = f->r; kv.z = f->z; kv.p = f->p; kv.w = f->w;
+    rc = pcg_solve(c, kv, rtol, atol, maxit, check_every, niter, res);
+    if (rc) return rc;
+    if (c->nranks > 1) return halo_exchange(c, kv.x, 1);     // ghostUpdate (solver.py:529)
+    return 0;
+}
+
+int knp_knp_solve(knp_ctx* c, double rtol, double atol, int maxit, int min_it, int check_every, int* niter, double* res) {
+    if (!c || !niter || !res) return -1;
+    Fields* f = F(c);
+    int rc = launch_knp_blockjacobi(c, f->f[KNP_F_DNPHI], f->binv_knp);
+    if (rc) return rc;
+    KrylovVecs kv{};
+    kv.x = f->f[KNP_F_C]; kv.b = f->f[KNP_F_B_KNP]; kv.coef = f->f[KNP_F_DNPHI]; kv.binv = f->binv_knp;
+    kv.r = f->r; kv.z = f->z; kv.p = f->p; kv.w = f->w; kv.rhat = f->rhat; kv.v = f->v; kv.y = f->y;
+    rc = bicgstab_solve(c, kv, rtol, atol, maxit, min_it, check_every, niter, res);
+    if (rc) return rc;
+    if (c->nranks > 1) return halo_exchange(c, kv.x, c->p.n_sys);   // ghostUpdate (solver.py:789)
+    return 0;
+}
+
+int knp_step_updates(knp_ctx* c) {
+    if (!c) return -1;
+    Fields* f = F(c);
+    HIPCHK(c, hipMemcpyAsync(f->f[KNP_F_C_PREV], f->f[KNP_F_C], sizeof(double) * f->n[KNP_F_C], hipMemcpyDeviceToDevice, c->stream));
+    return launch_step_updates(c, f->f[KNP_F_C], f->f[KNP_F_C_ELIM], f->f[KNP_F_PHI], f->f[KNP_F_PHI_M], f->f[KNP_F_E]);
+}
+
+
+
+int knp_nernst(knp_ctx* c) {
+    if (!c) return -1;
+    Fields* f = F(c);
+    return launch_nernst_only(c, f->f[KNP_F_C], f->f[KNP_F_C_ELIM], f->f[KNP_F_E]);
+}
+
+int knp_facet_trace(knp_ctx* c, int field, int species, int side) {
+    if (chk_field(c, field)) return -1;
+    if (side != 0 && side != 1) { c->err = "side must be 0 (plus) or 1 (minus)"; return -1; }
+    const int64_t ndof = c->m.nc * c->nd;
+    if (species < 0 || (int64_t)(species + 1) * ndof > F(c)->n[field]) { c->err = "facet_trace: species out of range"; return -1; }
+    return launch_facet_trace(c, F(c)->f[field] + (int64_t)species * ndof, side, F(c)->f[KNP_F_FACET_TMP]);
+}
+
+int knp_sync(knp_ctx* c) {
+    if (!c) return -1;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int knp_timer_begin(knp_ctx* c) {
+    if (!c) return -1;
+    HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+    return 0;
+}
+
+int knp_timer_end(knp_ctx* c, float* ms) {
+    if (!c || !ms) return -1;
+    HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+    HIPCHK(c, hipEventSynchronize(c->ev1));
+    HIPCHK(c, hipEventElapsedTime(ms, c->ev0, c->ev1));
+    return 0;
+}
+
+int knp_bench_apply(knp_ctx* c, int which, int reps, float* avg_ms) {
+    if (!c || !avg_ms || reps < 1) return -1;
+    Fields* f = F(c);
+    int rc = 0;
+    // one untimed launch (code object load, cache warm)
+    rc = which == 0 ? launch_emi_apply(c, f->f[KNP_F_X], f->f[KNP_F_KAPPA], f->f[KNP_F_Y])
+                    : launch_knp_apply(c, f->f[KNP_F_X], f->f[KNP_F_DNPHI], f->f[KNP_F_Y]);
+    if (rc) return rc;
+    HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+    for (int i = 0; i < reps && !rc; ++i)
+        rc = which == 0 ? launch_emi_apply(c, f->f[KNP_F_X], f->f[KNP_F_KAPPA], f->f[KNP_F_Y])
+                        : launch_knp_apply(c, f->f[KNP_F_X], f->f[KNP_F_DNPHI], f->f[KNP_F_Y]);
+    if (rc) return rc;
+    HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+    HIPCHK(c, hipEventSynchronize(c->ev1));
+    float ms = 0.f;
+    HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    *avg_ms = ms / (float)reps;
+    return 0;
+}
+
+int knp_halo_exchange(knp_ctx* c, int field) {
+    if (chk_field(c, field)) return -1;
+    const int64_t ndof = c->m.nc * c->nd;
+    if (F(c)->n[field] % ndof) { c->err = "halo_exchange: not a nodal field"; return -1; }
+    if (c->nranks <= 1) return 0;
+    return halo_exchange(c, F(c)->f[field], (int)(F(c)->n[field] / ndof));
+}
+
+}  // extern "C"

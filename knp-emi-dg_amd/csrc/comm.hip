@@ -1,0 +1,134 @@
+// Multi-GPU plumbing: one process per GPU, RCCL over xGMI.
+//  * halo exchange of facet-neighbour (ghost) cell DoFs: packed per peer, grouped ncclSend/ncclRecv
+//    (messages are ~80 KB per field for slab partitions -> latency bound; one group per exchange,
+//    every peer is one xGMI hop);
+//  * Krylov inner products: one ncclAllReduce of the packed partial sums per reduction point.
+// Replaces DOLFIN ghost updates + PETSc VecGhost / MatMult scatters + KSP reductions
+// (reference: src/knpemidg/solver.py:16, 529, 789).
+#include "../../include/knpemi_hip.h"
+#include "knpemi_internal.hpp"
+#include <rccl/rccl.h>
+#include <cstring>
+
+#define NCCLCHK(ctx, call)                                                         \
+    do {                                                                           \
+        ncclResult_t r_ = (call);                                                  \
+        if (r_ != ncclSuccess) {                                                   \
+            (ctx)->err = std::string(#call) + ": " + ncclGetErrorString(r_);       \
+            return -6;                                                             \
+        }                                                                          \
+    } while (0)
+
+static_assert(sizeof(ncclUniqueId) <= 128, "unique id must fit the ABI buffer");
+
+void comm_destroy(knp_ctx* c) {
+    if (c->comm) {
+        ncclCommDestroy((ncclComm_t)c->comm);
+        c->comm = nullptr;
+    }
+}
+
+int allreduce_red(knp_ctx* c, double* red, int count) {
+    if (!c->comm) { c->err = "allreduce without communicator"; return -6; }
+    NCCLCHK(c, ncclAllReduce(red, red, count, ncclDouble, ncclSum, (ncclComm_t)c->comm, c->stream));
+    return 0;
+}
+
+// out layout for one peer: [field][cell][nv]
+__global__ void k_halo_pack(const double* __restrict__ v, const int32_t* __restrict__ idx, int64_t cnt, int nfields,
+                            int64_t field_stride, int nv, double* __restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= cnt * nv) return;
+    const int64_t i = t / nv;
+    const int a = (int)(t % nv);
+    const int64_t cell = idx[i];
+    for (int f = 0; f < nfields; ++f) out[((int64_t)f * cnt + i) * nv + a] = v[(int64_t)f * field_stride + cell * nv + a];
+}
+
+int halo_exchange(knp_ctx* c, double* v, int nfields) {
+    if (c->nranks <= 1 || c->halo_peer.empty()) return 0;
+    if (!c->comm) { c->err = "halo exchange without communicator"; return -6; }
+    if (nfields > KNP_MAX_SYS) { c->err = "halo exchange: too many fields"; return -1; }
+    const int NV = c->nd;
+    const int64_t stride = c->m.nc * NV;
+    const int np = (int)c->halo_peer.size();
+    for (int p = 0; p < np; ++p) {
+        const int64_t cnt = c->halo_send_cnt[p];
+        if (!cnt) continue;
+        const int64_t n = cnt * NV;
+        hipLaunchKernelGGL(k_halo_pack, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, (const double*)v,
+                           (const int32_t*)(c->halo_send_idx + c->halo_send_off[p]), cnt, nfields, stride, NV,
+                           c->halo_sendbuf + c->halo_send_off[p] * KNP_MAX_SYS * NV);
+    }
+    HIPCHK(c, hipGetLastError());
+    ncclComm_t comm = (ncclComm_t)c->comm;
+    NCCLCHK(c, ncclGroupStart());
+    for (int p = 0; p < np; ++p) {
+        const int peer = c->halo_peer[p];
+        if (c->halo_send_cnt[p])
+            NCCLCHK(c, ncclSend(c->halo_sendbuf + c->halo_send_off[p] * KNP_MAX_SYS * NV,
+                                (size_t)(c->halo_send_cnt[p] * nfields * NV), ncclDouble, peer, comm, c->stream));
+        for (int f = 0; f < nfields && c->halo_recv_cnt[p]; ++f)
+            NCCLCHK(c, ncclRecv(v + (int64_t)f * stride + c->halo_recv_off[p] * NV, (size_t)(c->halo_recv_cnt[p] * NV), ncclDouble,
+                                peer, comm, c->stream));
+    }
+    NCCLCHK(c, ncclGroupEnd());
+    return 0;
+}
+
+extern "C" {
+
+int knp_comm_unique_id(char* out128) {
+    if (!out128) return -1;
+    ncclUniqueId id;
+    if (ncclGetUniqueId(&id) != ncclSuccess) return -6;
+    memset(out128, 0, 128);
+    memcpy(out128, &id, sizeof(id));
+    return 0;
+}
+
+int knp_comm_init(knp_ctx* c, int rank, int nranks, const char* id128) {
+    if (!c || !id128 || nranks < 1 || rank < 0 || rank >= nranks) return -1;
+    c->rank = rank;
+    c->nranks = nranks;
+    if (nranks == 1) return 0;
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof(id));
+    HIPCHK(c, hipSetDevice(c->device));
+    ncclComm_t comm;
+    NCCLCHK(c, ncclCommInitRank(&comm, nranks, id, rank));
+    c->comm = comm;
+    return 0;
+}
+
+int knp_halo_tables(knp_ctx* c, int npeers, const int32_t* peers, const int64_t* send_counts, const int32_t* send_cells,
+                    const int64_t* recv_offsets, const int64_t* recv_counts) {
+    if (!c || npeers < 0) return -1;
+    c->halo_peer.clear(); c->halo_send_off.clear(); c->halo_send_cnt.clear(); c->halo_recv_off.clear(); c->halo_recv_cnt.clear();
+    int64_t total = 0;
+    for (int p = 0; p < npeers; ++p) {
+        if (peers[p] < 0 || peers[p] >= c->nranks || peers[p] == c->rank) { c->err = "halo_tables: bad peer rank"; return -1; }
+        if (recv_offsets[p] < c->m.nc_owned || recv_offsets[p] + recv_counts[p] > c->m.nc) {
+            c->err = "halo_tables: ghost range outside [nc_owned, nc)"; return -1;
+        }
+        c->halo_peer.push_back(peers[p]);
+        c->halo_send_off.push_back(total);
+        c->halo_send_cnt.push_back(send_counts[p]);
+        c->halo_recv_off.push_back(recv_offsets[p]);
+        c->halo_recv_cnt.push_back(recv_counts[p]);
+        total += send_counts[p];
+    }
+    for (int64_t i = 0; i < total; ++i)
+        if (send_cells[i] < 0 || send_cells[i] >= c->m.nc_owned) { c->err = "halo_tables: send cell is not owned"; return -1; }
+    c->halo_send_total = total;
+    hipFree(c->halo_send_idx); c->halo_send_idx = nullptr;
+    hipFree(c->halo_sendbuf); c->halo_sendbuf = nullptr;
+    if (total) {
+        HIPCHK(c, hipMalloc((void**)&c->halo_send_idx, sizeof(int32_t) * total));
+        HIPCHK(c, hipMemcpy(c->halo_send_idx, send_cells, sizeof(int32_t) * total, hipMemcpyHostToDevice));
+        HIPCHK(c, hipMalloc((void**)&c->halo_sendbuf, sizeof(double) * total * KNP_MAX_SYS * c->nd));
+    }
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,106 @@
+// Internal declarations of libknpemi_hip.so (gfx950 only).  The public C ABI is
+// include/knpemi_hip.h; nothing here is visible to callers.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <string>
+#include <vector>
+#include <map>
+
+#define KNP_MAX_IONS 8          // total species incl. the eliminated one
+#define KNP_MAX_SYS 7           // solved species (batched KNP systems)
+#define KNP_BLOCK 256
+#define KNP_MAX_RED 8           // partial sums per block per system in one reduction pass
+
+// facet kinds stored in bits 2..3 of the per-(cell, local facet) flag byte
+enum : uint32_t { FK_SIPG = 0u, FK_MEMBRANE = 1u, FK_EXTERIOR = 2u, FK_INACTIVE = 3u };
+// bits 0..1: local facet index of this facet in the neighbour cell
+// bit 4    : this cell is the `plus` (ECS-like, lower tag) side of the oriented normal n_g
+
+struct MeshDev {
+    int dim = 0;
+    int64_t nv = 0, nc = 0, nc_owned = 0, nf = 0, nmf = 0;
+    double* coords = nullptr;      // [nv][4] in 3D (padded), [nv][2] in 2D
+    int32_t* cells = nullptr;      // [nc][dim+1]
+    int32_t* nbr = nullptr;        // [nc][dim+1]
+    uint32_t* fflag = nullptr;     // [nc] packed 4 x u8 flag bytes
+    int32_t* cfacet = nullptr;     // [nc][dim+1] global facet ids
+    int32_t* mf = nullptr;         // [nmf][6]: cell_e, cell_i, lf_e, lf_i, facet, owner flag
+};
+
+struct Params {
+    int n_ions = 0;                // total species, last one eliminated
+    int n_sys = 0;                 // n_ions - 1
+    double C_M = 0, dt = 0, F = 0, R = 0, T = 0, C_phi = 0, psi = 0;
+    double tau_emi = 0, tau_knp = 0;
+    double z[KNP_MAX_IONS] = {0};
+    double f_source[KNP_MAX_IONS] = {0};
+    int splitting = 1;
+};
+
+struct KernelArgsIons {            // small by-value structs for kernels
+    int n;
+    double z[KNP_MAX_IONS];
+};
+
+struct knp_ctx {
+    int device = 0;
+    int degree = 1;
+    int nd = 0;                    // dofs per cell
+    hipStream_t stream = nullptr;
+    MeshDev m;
+    Params p;
+    double* D = nullptr;           // [n_ions][nc]
+    double* rho = nullptr;         // [nc]
+    double* fsrc = nullptr;        // [n_sys][nc] DG0 source on ECS cells, or null
+    std::map<int, double*> vecs;   // handle -> device pointer
+    std::map<int, int64_t> vlen;
+    int next_handle = 1;
+    // Krylov workspace
+    double* partial = nullptr;     // [grid][KNP_MAX_SYS][KNP_MAX_RED]
+    int64_t partial_blocks = 0;
+    double* scal = nullptr;        // device scalars
+    int* status = nullptr;         // device: [0]=converged flag, [1]=iterations
+    void* pinned = nullptr;        // host pinned mirror for status/scalars
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // distributed
+    void* comm = nullptr;          // ncclComm_t
+    int rank = 0, nranks = 1;
+    std::vector<int> halo_peer;
+    std::vector<int64_t> halo_send_off, halo_send_cnt, halo_recv_off, halo_recv_cnt;
+    int32_t* halo_send_idx = nullptr;   // device: owned cell ids to pack, grouped by peer
+    double* halo_sendbuf = nullptr;
+    int64_t halo_send_total = 0;
+    std::string err;
+};
+
+#define HIPCHK(ctx, call)                                                        \
+    do {                                                                         \
+        hipError_t e_ = (call);                                                  \
+        if (e_ != hipSuccess) {                                                  \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);      \
+            return -2;                                                           \
+        }                                                                        \
+    } while (0)
+
+// ---- launchers implemented in the .hip files --------------------------------------------
+int launch_emi_apply(knp_ctx* c, const double* x, const double* kappa, double* y);
+int launch_knp_apply(knp_ctx* c, const double* x, const double* dnphi, double* y);
+int launch_emi_blockjacobi(knp_ctx* c, const double* kappa, double* binv);
+int launch_knp_blockjacobi(knp_ctx* c, const double* dnphi, double* binv);
+int launch_dnphi(knp_ctx* c, const double* phi, double* dnphi);
+int launch_kappa(knp_ctx* c, const double* cc, const double* celim, double* kappa);
+int launch_emi_rhs(knp_ctx* c, const double* cc, const double* celim, const double* phiM,
+                   const double* Ich, double* b);
+int launch_knp_rhs(knp_ctx* c, const double* cc, const double* cprev, const double* celim,
+                   const double* phi, const double* phiM, const double* Ich, double* b);
+int launch_step_updates(knp_ctx* c, const double* cc, double* celim, const double* phi,
+                        double* phiM, double* E);
+int launch_facet_trace(knp_ctx* c, const double* nodal, int side, double* out);
+
+int halo_exchange(knp_ctx* c, double* v, int nfields);
+
+int64_t grid_for(int64_t n);
+int launch_nernst_only(knp_ctx* c, const double* cc, const double* celim, double* E);
+void comm_destroy(knp_ctx* c);
+int allreduce_red(knp_ctx* c, double* red, int count);

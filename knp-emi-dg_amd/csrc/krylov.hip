@@ -1,0 +1,480 @@
+// Device-resident Krylov solvers: PCG for the (singular, consistent) EMI system and a batched
+// per-species BiCGStab for the KNP systems, both with a cell-block-Jacobi preconditioner.
+// All Krylov scalars live in device memory; the host only launches kernels and polls a status
+// word every `check_every` iterations, so there is no per-iteration host round trip.
+// Inner products: 64-lane wavefront shuffle -> per-block LDS -> per-block partial in HBM ->
+// fixed-order second stage (bitwise reproducible), all-reduced over RCCL when nranks > 1.
+//
+// Replaces PETSc KSP cg / gmres + hypre (reference: src/knpemidg/solver.py:425-444,509,684-701,771).
+#include "cell_geom.hpp"
+#include "krylov.hpp"
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// block-level sum of NR values per thread; result valid in thread 0
+template <int NR> __device__ __forceinline__ void block_sum(double* v, double* out) {
+    __shared__ double lds[KNP_BLOCK / 64][NR];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const double s = wave_sum(v[r]);
+        if (lane == 0) lds[wv][r] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            double s = lds[0][r];
+#pragma unroll
+            for (int w = 1; w < KNP_BLOCK / 64; ++w) s += lds[w][r];
+            out[r] = s;
+        }
+    }
+}
+
+template <int NR> __device__ __forceinline__ void write_partials(double* partial, int nsys, double* v) {
+    double out[NR];
+    block_sum<NR>(v, out);
+    if (threadIdx.x == 0) {
+        double* p = partial + ((int64_t)blockIdx.x * nsys + blockIdx.y) * KNP_MAX_RED;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) p[r] = out[r];
+    }
+}
+
+template <int NV> __device__ __forceinline__ void ldv(const double* p, int64_t c, double* v) { load_nodal<NV - 1>(p, c, v); }
+template <int NV> __device__ __forceinline__ void stv(double* p, int64_t c, const double* v) { store_nodal<NV - 1>(p, c, v); }
+
+template <int NV> __device__ __forceinline__ void block_matvec(const double* __restrict__ binv, int64_t c, const double* r, double* z) {
+    const double* B = binv + c * NV * NV;
+#pragma unroll
+    for (int a = 0; a < NV; ++a) {
+        double s = 0.0;
+#pragma unroll
+        for (int b = 0; b < NV; ++b) s += B[a * NV + b] * r[b];
+        z[a] = s;
+    }
+}
+
+struct VecDims {
+    int64_t nc_owned, nc;   // vectors are [nsys][nc*NV]; only owned cells are updated / reduced
+    int nsys;
+};
+
+#define SYS_PTR(p, s) ((p) + (int64_t)(s) * d.nc * NV)
+
+// ---- second-stage reduction + scalar recurrences ------------------------------------------
+// op codes
+enum { OP_CG_INIT = 1, OP_CG_ALPHA, OP_CG_BETA, OP_BI_INIT, OP_BI_ALPHA, OP_BI_OMEGA, OP_BI_RHO, OP_SUM_ONLY };
+
+__global__ void k_reduce(const double* __restrict__ partial, int64_t nblocks, int nsys, int nred, double* __restrict__ red) {
+    // one block per system; deterministic order
+    const int s = blockIdx.x;
+    __shared__ double lds[KNP_BLOCK / 64][KNP_MAX_RED];
+    double acc[KNP_MAX_RED];
+#pragma unroll
+    for (int r = 0; r < KNP_MAX_RED; ++r) acc[r] = 0.0;
+    for (int64_t b = threadIdx.x; b < nblocks; b += blockDim.x) {
+        const double* p = partial + (b * nsys + s) * KNP_MAX_RED;
+        for (int r = 0; r < nred; ++r) acc[r] += p[r];
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int r = 0; r < nred; ++r) {
+        const double v = wave_sum(acc[r]);
+        if (lane == 0) lds[wv][r] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int r = 0; r < nred; ++r) {
+            double v = lds[0][r];
+            for (int w = 1; w < KNP_BLOCK / 64; ++w) v += lds[w][r];
+            red[s * KNP_MAX_RED + r] = v;
+        }
+    }
+}
+
+__global__ void k_scalar_op(int op, int nsys, const double* __restrict__ red, double* __restrict__ scal, int* __restrict__ status,
+                            double rtol, double atol, int min_it) {
+    const int s = threadIdx.x;
+    if (s >= nsys) return;
+    double* S = scal + s * KS_N;
+    const double* R = red + s * KNP_MAX_RED;
+    int* flag = status + 2 * s;
+    int* iter = status + 2 * s + 1;
+    if (op != OP_CG_INIT && op != OP_BI_INIT && *flag) return;
+    switch (op) {
+        case OP_CG_INIT: {              // R: rz, zz, (Minv b).(Minv b)
+            S[KS_RHO] = R[0];
+            S[KS_RES0] = sqrt(R[1]);
+            S[KS_RES] = S[KS_RES0];
+            S[KS_BNORM] = sqrt(R[2]);
+            S[KS_TOL] = fmax(rtol * S[KS_BNORM], atol);
+            *iter = 0;
+            *flag = (S[KS_RES] <= S[KS_TOL]) ? 1 : 0;
+        } break;
+        case OP_CG_ALPHA: {             // R: p.w
+            S[KS_ALPHA] = (R[0] != 0.0) ? S[KS_RHO] / R[0] : 0.0;
+            if (R[0] == 0.0) *flag = 2;
+        } break;
+        case OP_CG_BETA: {              // R: rz_new, zz
+            S[KS_BETA] = (S[KS_RHO] != 0.0) ? R[0] / S[KS_RHO] : 0.0;
+            S[KS_RHO] = R[0];
+            S[KS_RES] = sqrt(R[1]);
+            *iter += 1;
+            if (S[KS_RES] <= S[KS_TOL] && *iter >= min_it) *flag = 1;
+            if (!(S[KS_RES] == S[KS_RES])) *flag = 3;                      // NaN
+        } break;
+        case OP_BI_INIT: {              // R: r.r, b.b
+            S[KS_RES0] = sqrt(R[0]);
+            S[KS_RES] = S[KS_RES0];
+            S[KS_BNORM] = sqrt(R[1]);
+            S[KS_TOL] = fmax(rtol * S[KS_BNORM], atol);
+            S[KS_RHO] = R[0];           // rhat = r0  ->  rho_1 = r0.r0
+            S[KS_RHO_OLD] = 1.0;
+            S[KS_ALPHA] = 1.0;
+            S[KS_OMEGA] = 1.0;
+            S[KS_BETA] = 0.0;
+            *iter = 0;
+            *flag = (R[0] == 0.0) ? 1 : 0;   // exact zero residual: nothing to do (rest state)
+        } break;
+        case OP_BI_ALPHA: {             // R: rhat.v
+            if (R[0] == 0.0) { *flag = 2; S[KS_ALPHA] = 0.0; }
+            else S[KS_ALPHA] = S[KS_RHO] / R[0];
+        } break;
+        case OP_BI_OMEGA: {             // R: t.s, t.t
+            S[KS_OMEGA] = (R[1] != 0.0) ? R[0] / R[1] : 0.0;
+        } break;
+        case OP_BI_RHO: {               // R: rhat.r, r.r
+            S[KS_RES] = sqrt(R[1]);
+            *iter += 1;
+            if (S[KS_RES] <= S[KS_TOL] && *iter >= min_it) { *flag = 1; break; }
+            if (!(S[KS_RES] == S[KS_RES])) { *flag = 3; break; }
+            if (R[0] == 0.0 || S[KS_OMEGA] == 0.0) { *flag = (S[KS_RES] <= S[KS_TOL]) ? 1 : 2; break; }
+            S[KS_BETA] = (R[0] / S[KS_RHO]) * (S[KS_ALPHA] / S[KS_OMEGA]);
+            S[KS_RHO] = R[0];
+        } break;
+        default: break;
+    }
+}
+
+// ---- PCG kernels ----------------------------------------------------------------------------
+// r = b - w(=A x);  z = Binv r;  p = z;  partials: r.z, z.z, (Binv b).(Binv b)
+template <int NV>
+__global__ __launch_bounds__(KNP_BLOCK) void k_cg_init(VecDims d, const double* __restrict__ b, const double* __restrict__ w,
+                                                       const double* __restrict__ binv, double* __restrict__ r,
+                                                       double* __restrict__ z, double* __restrict__ p, double* __restrict__ partial) {
+    const int64_t c = (int64_t)blockIdx.x * KNP_BLOCK + threadIdx.x;
+    double acc[3] = {0.0, 0.0, 0.0};
+    if (c < d.nc_owned) {
+        double bv[NV], wv[NV], rv[NV], zv[NV], zb[NV];
+        ldv<NV>(b, c, bv);
+        ldv<NV>(w, c, wv);
+#pragma unroll
+        for (int a = 0; a < NV; ++a) rv[a] = bv[a] - wv[a];
+        block_matvec<NV>(binv, c, rv, zv);
+        block_matvec<NV>(binv, c, bv, zb);
+        stv<NV>(r, c, rv);
+        stv<NV>(z, c, zv);
+        stv<NV>(p, c, zv);
+#pragma unroll
+        for (int a = 0; a < NV; ++a) {
+            acc[0] += rv[a] * zv[a];
+            acc[1] += zv[a] * zv[a];
+            acc[2] += zb[a] * zb[a];
+        }
+    }
+    write_partials<3>(partial, 1, acc);
+}
+
+template <int NV>
+__global__ __launch_bounds__(KNP_BLOCK) void k_dot2(VecDims d, const double* __restrict__ u, const double* __restrict__ v,
+                                                    const double* __restrict__ u2, const double* __restrict__ v2,
+                                                    double* __restrict__ partial, const int* __restrict__ status) {
+    const int s = blockIdx.y;
+    if (status[2 * s]) return;
+    const int64_t c = (int64_t)blockIdx.x * KNP_BLOCK + threadIdx.x;
+    double acc[2] = {0.0, 0.0};
+    if (c < d.nc_owned) {
+        double a[NV], b[NV];
+        ldv<NV>(SYS_PTR(u, s), c, a);
+        ldv<NV>(SYS_PTR(v, s), c, b);
+#pragma unroll
+        for (int k = 0; k < NV; ++k) acc[0] += a[k] * b[k];
+        if (u2) {
+            ldv<NV>(SYS_PTR(u2, s), c, a);
+            ldv<NV>(SYS_PTR(v2, s), c, b);
+#pragma unroll
+            for (int k = 0; k < NV; ++k) acc[1] += a[k] * b[k];
+        }
+    }
+    write_partials<2>(partial, d.nsys, acc);
+}
+
+// x += alpha p ; r -= alpha w ; z = Binv r ; partials r.z, z.z
+template <int NV>
+__global__ __launch_bounds__(KNP_BLOCK) void k_cg_update(VecDims d, const double* __restrict__ scal, const int* __restrict__ status,
+                                                         const double* __restrict__ p, const double* __restrict__ w,
+                                                         const double* __restrict__ binv, double* __restrict__ x,
+                                                         double* __restrict__ r, double* __restrict__ z, double* __restrict__ partial) {
+    if (status[0]) return;
+    const double alpha = scal[KS_ALPHA];
+    const int64_t c = (int64_t)blockIdx.x * KNP_BLOCK + threadIdx.x;
+    double acc[2] = {0.0, 0.0};
+    if (c < d.nc_owned) {
+        double pv[NV], wv[NV], xv[NV], rv[NV], zv[NV];
+        ldv<NV>(p, c, pv);
+        ldv<NV>(w, c, wv);
+        ldv<NV>(x, c, xv);
+        ldv<NV>(r, c, rv);
+#pragma unroll
+        for (int a = 0; a < NV; ++a) { xv[a] += alpha * pv[a]; rv[a] -= alpha * wv[a]; }
+        block_matvec<NV>(binv, c, rv, zv);
+        stv<NV>(x, c, xv);
+        stv<NV>(r, c, rv);
+        stv<NV>(z, c, zv);
+#pragma unroll
+        for (int a = 0; a < NV; ++a) { acc[0] += rv[a] * zv[a]; acc[1] += zv[a] * zv[a]; }
+    }
+    write_partials<2>(partial, 1, acc);
+}
+
+// p = z + beta p
+template <int NV>
+__global__ __launch_bounds__(KNP_BLOCK) void k_cg_p(VecDims d, const double* __restrict__ scal, const int* __restrict__ status,
+                                                    const double* __restrict__ z, double* __restrict__ p) {
+    if (status[0]) return;
+    const double beta = scal[KS_BETA];
+    const int64_t c = (int64_t)blockIdx.x * KNP_BLOCK + threadIdx.x;
+    if (c >= d.nc_owned) return;
+    double zv[NV], pv[NV];
+    ldv<NV>(z, c, zv);
+    ldv<NV>(p, c, pv);
+#pragma unroll
+    for (int a = 0; a < NV; ++a) pv[a] = zv[a] + beta * pv[a];
+    stv<NV>(p, c, pv);
+}
+
+// ---- BiCGStab kernels (system = blockIdx.y) ------------------------------------------------------
+// r = b - w ; rhat = r ; p = v = 0 ; partials r.r, b.b
+template <int NV>
+__global__ __launch_bounds__(KNP_BLOCK) void k_bi_init(VecDims d, const double* __restrict__ b, const double* __restrict__ w,
+                                                       double* __restrict__ r, double* __restrict__ rhat, double* __restrict__ p,
+                                                       double* __restrict__ v, double* __restrict__ partial) {
+    const int s = blockIdx.y;
+    const int64_t c = (int64_t)blockIdx.x * KNP_BLOCK + threadIdx.x;
+    double acc[2] = {0.0, 0.0};
+    if (c < d.nc_owned) {
+        double bv[NV], wv[NV], rv[NV], zero[NV];
+        ldv<NV>(SYS_PTR(b, s), c, bv);
+        ldv<NV>(SYS_PTR(w, s), c, wv);
+#pragma unroll
+        for (int a = 0; a < NV; ++a) { rv[a] = bv[a] - wv[a]; zero[a] = 0.0; acc[0] += rv[a] * rv[a]; acc[1] += bv[a] * bv[a]; }
+        stv<NV>(SYS_PTR(r, s), c, rv);
+        stv<NV>(SYS_PTR(rhat, s), c, rv);
+        stv<NV>(SYS_PTR(p, s), c, zero);
+        stv<NV>(SYS_PTR(v, s), c, zero);
+    }
+    write_partials<2>(partial, d.nsys, acc);
+}
+
+// p = r + beta (p - omega v) ; y = Binv p
+template <int NV>
+__global__ __launch_bounds__(KNP_BLOCK) void k_bi_p(VecDims d, const double* __restrict__ scal, const int* __restrict__ status,
+                                                    const double* __restrict__ r, const double* __restrict__ v,
+                                                    const double* __restrict__ binv, double* __restrict__ p, double* __restrict__ y) {
+    const int s = blockIdx.y;
+    if (status[2 * s]) return;
+    const double beta = scal[s * KS_N + KS_BETA], omega = scal[s * KS_N + KS_OMEGA];
+    const int64_t c = (int64_t)blockIdx.x * KNP_BLOCK + threadIdx.x;
+    if (c >= d.nc_owned) return;
+    double rv[NV], vv[NV], pv[NV], yv[NV];
+    ldv<NV>(SYS_PTR(r, s), c, rv);
+    ldv<NV>(SYS_PTR(v, s), c, vv);
+    ldv<NV>(SYS_PTR(p, s), c, pv);
+#pragma unroll
+    for (int a = 0; a < NV; ++a) pv[a] = rv[a] + beta * (pv[a] - omega * vv[a]);
+    block_matvec<NV>(binv + (int64_t)s * d.nc * NV * NV, c, pv, yv);
+    stv<NV>(SYS_PTR(p, s), c, pv);
+    stv<NV>(SYS_PTR(y, s), c, yv);
+}
+
+// s = r - alpha v (in place in r) ; z = Binv s
+template <int NV>
+__global__ __launch_bounds__(KNP_BLOCK) void k_bi_s(VecDims d, const double* __restrict__ scal, const int* __restrict__ status,
+                                                    const double* __restrict__ v, const double* __restrict__ binv,
+                                                    double* __restrict__ r, double* __restrict__ z) {
+    const int s = blockIdx.y;
+    if (status[2 * s]) return;
+    const double alpha = scal[s * KS_N + KS_ALPHA];
+    const int64_t c = (int64_t)blockIdx.x * KNP_BLOCK + threadIdx.x;
+    if (c >= d.nc_owned) return;
+    double rv[NV], vv[NV], zv[NV];
+    ldv<NV>(SYS_PTR(r, s), c, rv);
+    ldv<NV>(SYS_PTR(v, s), c, vv);
+#pragma unroll
+    for (int a = 0; a < NV; ++a) rv[a] -= alpha * vv[a];
+    block_matvec<NV>(binv + (int64_t)s * d.nc * NV * NV, c, rv, zv);
+    stv<NV>(SYS_PTR(r, s), c, rv);
+    stv<NV>(SYS_PTR(z, s), c, zv);
+}
+
+// x += alpha y + omega z ; r = s - omega t ; partials rhat.r, r.r
+template <int NV>
+__global__ __launch_bounds__(KNP_BLOCK) void k_bi_x(VecDims d, const double* __restrict__ scal, const int* __restrict__ status,
+                                                    const double* __restrict__ y, const double* __restrict__ z,
+                                                    const double* __restrict__ t, const double* __restrict__ rhat,
+                                                    double* __restrict__ x, double* __restrict__ r, double* __restrict__ partial) {
+    const int s = blockIdx.y;
+    if (status[2 * s]) return;
+    const double alpha = scal[s * KS_N + KS_ALPHA], omega = scal[s * KS_N + KS_OMEGA];
+    const int64_t c = (int64_t)blockIdx.x * KNP_BLOCK + threadIdx.x;
+    double acc[2] = {0.0, 0.0};
+    if (c < d.nc_owned) {
+        double yv[NV], zv[NV], tv[NV], hv[NV], xv[NV], rv[NV];
+        ldv<NV>(SYS_PTR(y, s), c, yv);
+        ldv<NV>(SYS_PTR(z, s), c, zv);
+        ldv<NV>(SYS_PTR(t, s), c, tv);
+        ldv<NV>(SYS_PTR(rhat, s), c, hv);
+        ldv<NV>(SYS_PTR(x, s), c, xv);
+        ldv<NV>(SYS_PTR(r, s), c, rv);
+#pragma unroll
+        for (int a = 0; a < NV; ++a) {
+            xv[a] += alpha * yv[a] + omega * zv[a];
+            rv[a] -= omega * tv[a];
+            acc[0] += hv[a] * rv[a];
+            acc[1] += rv[a] * rv[a];
+        }
+        stv<NV>(SYS_PTR(x, s), c, xv);
+        stv<NV>(SYS_PTR(r, s), c, rv);
+    }
+    write_partials<2>(partial, d.nsys, acc);
+}
+
+// ---- host drivers ---------------------------------------------------------------------------------
+
+
+static int finalize(knp_ctx* c, int op, int nsys, int nred, double rtol, double atol, int min_it) {
+    const int64_t nb = grid_for(c->m.nc_owned);
+    double* red = c->scal + KNP_MAX_SYS * KS_N;
+    hipLaunchKernelGGL(k_reduce, dim3(nsys), dim3(KNP_BLOCK), 0, c->stream, c->partial, nb, nsys, nred, red);
+    if (c->nranks > 1) {
+        int rc = allreduce_red(c, red, nsys * KNP_MAX_RED);
+        if (rc) return rc;
+    }
+    hipLaunchKernelGGL(k_scalar_op, dim3(1), dim3(64), 0, c->stream, op, nsys, red, c->scal, c->status, rtol, atol, min_it);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
+static int poll_status(knp_ctx* c, int nsys, int* host_status) {
+    HIPCHK(c, hipMemcpyAsync(c->pinned, c->status, sizeof(int) * 2 * nsys, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int i = 0; i < 2 * nsys; ++i) host_status[i] = ((int*)c->pinned)[i];
+    return 0;
+}
+
+template <int NV>
+static int pcg_impl(knp_ctx* c, KrylovVecs& kv, double rtol, double atol, int maxit, int check_every, int* niter, double* res) {
+    VecDims d{c->m.nc_owned, c->m.nc, 1};
+    const dim3 g((unsigned)grid_for(c->m.nc_owned)), b(KNP_BLOCK);
+    int rc;
+    if (c->nranks > 1 && (rc = halo_exchange(c, kv.x, 1))) return rc;
+    if ((rc = launch_emi_apply(c, kv.x, kv.coef, kv.w))) return rc;
+    hipLaunchKernelGGL(k_cg_init<NV>, g, b, 0, c->stream, d, kv.b, kv.w, kv.binv, kv.r, kv.z, kv.p, c->partial);
+    if ((rc = finalize(c, OP_CG_INIT, 1, 3, rtol, atol, 0))) return rc;
+    int hs[2] = {0, 0};
+    int it = 0;
+    if ((rc = poll_status(c, 1, hs))) return rc;
+    while (!hs[0] && it < maxit) {
+        const int chunk = (maxit - it < check_every) ? (maxit - it) : check_every;
+        for (int k = 0; k < chunk; ++k) {
+            if (c->nranks > 1 && (rc = halo_exchange(c, kv.p, 1))) return rc;
+            if ((rc = launch_emi_apply(c, kv.p, kv.coef, kv.w))) return rc;
+            hipLaunchKernelGGL(k_dot2<NV>, dim3(g.x, 1), b, 0, c->stream, d, kv.p, kv.w, (const double*)nullptr,
+                               (const double*)nullptr, c->partial, c->status);
+            if ((rc = finalize(c, OP_CG_ALPHA, 1, 1, rtol, atol, 0))) return rc;
+            hipLaunchKernelGGL(k_cg_update<NV>, g, b, 0, c->stream, d, c->scal, c->status, kv.p, kv.w, kv.binv, kv.x, kv.r, kv.z,
+                               c->partial);
+            if ((rc = finalize(c, OP_CG_BETA, 1, 2, rtol, atol, 0))) return rc;
+            hipLaunchKernelGGL(k_cg_p<NV>, g, b, 0, c->stream, d, c->scal, c->status, kv.z, kv.p);
+        }
+        it += chunk;
+        if ((rc = poll_status(c, 1, hs))) return rc;
+    }
+    double hscal[KS_N];
+    HIPCHK(c, hipMemcpy(hscal, c->scal, sizeof(double) * KS_N, hipMemcpyDeviceToHost));
+    *niter = hs[1];
+    res[0] = hscal[KS_RES0];
+    res[1] = hscal[KS_RES];
+    res[2] = hscal[KS_BNORM];
+    if (hs[0] == 3) { c->err = "EMI PCG: NaN residual"; return -4; }
+    if (hs[0] != 1) { c->err = "EMI PCG did not converge"; return -3; }
+    return 0;
+}
+
+int pcg_solve(knp_ctx* c, KrylovVecs& kv, double rtol, double atol, int maxit, int check_every, int* niter, double* res) {
+    if (check_every < 1) check_every = 1;
+    return c->m.dim == 3 ? pcg_impl<4>(c, kv, rtol, atol, maxit, check_every, niter, res)
+                         : pcg_impl<3>(c, kv, rtol, atol, maxit, check_every, niter, res);
+}
+
+template <int NV>
+static int bicgstab_impl(knp_ctx* c, KrylovVecs& kv, double rtol, double atol, int maxit, int min_it, int check_every,
+                         int* niter, double* res) {
+    const int ns = c->p.n_sys;
+    VecDims d{c->m.nc_owned, c->m.nc, ns};
+    const dim3 g((unsigned)grid_for(c->m.nc_owned), (unsigned)ns), b(KNP_BLOCK);
+    int rc;
+    if (c->nranks > 1 && (rc = halo_exchange(c, kv.x, ns))) return rc;
+    if ((rc = launch_knp_apply(c, kv.x, kv.coef, kv.w))) return rc;
+    hipLaunchKernelGGL(k_bi_init<NV>, g, b, 0, c->stream, d, kv.b, kv.w, kv.r, kv.rhat, kv.p, kv.v, c->partial);
+    if ((rc = finalize(c, OP_BI_INIT, ns, 2, rtol, atol, min_it))) return rc;
+    int hs[2 * KNP_MAX_SYS];
+    auto all_done = [&]() { for (int s = 0; s < ns; ++s) if (!hs[2 * s]) return false; return true; };
+    if ((rc = poll_status(c, ns, hs))) return rc;
+    int it = 0;
+    while (!all_done() && it < maxit) {
+        const int chunk = (maxit - it < check_every) ? (maxit - it) : check_every;
+        for (int k = 0; k < chunk; ++k) {
+            hipLaunchKernelGGL(k_bi_p<NV>, g, b, 0, c->stream, d, c->scal, c->status, kv.r, kv.v, kv.binv, kv.p, kv.y);
+            if (c->nranks > 1 && (rc = halo_exchange(c, kv.y, ns))) return rc;
+            if ((rc = launch_knp_apply(c, kv.y, kv.coef, kv.v))) return rc;
+            hipLaunchKernelGGL(k_dot2<NV>, g, b, 0, c->stream, d, kv.rhat, kv.v, (const double*)nullptr, (const double*)nullptr,
+                               c->partial, c->status);
+            if ((rc = finalize(c, OP_BI_ALPHA, ns, 1, rtol, atol, min_it))) return rc;
+            hipLaunchKernelGGL(k_bi_s<NV>, g, b, 0, c->stream, d, c->scal, c->status, kv.v, kv.binv, kv.r, kv.z);
+            if (c->nranks > 1 && (rc = halo_exchange(c, kv.z, ns))) return rc;
+            if ((rc = launch_knp_apply(c, kv.z, kv.coef, kv.w))) return rc;
+            hipLaunchKernelGGL(k_dot2<NV>, g, b, 0, c->stream, d, kv.w, kv.r, kv.w, kv.w, c->partial, c->status);
+            if ((rc = finalize(c, OP_BI_OMEGA, ns, 2, rtol, atol, min_it))) return rc;
+            hipLaunchKernelGGL(k_bi_x<NV>, g, b, 0, c->stream, d, c->scal, c->status, kv.y, kv.z, kv.w, kv.rhat, kv.x, kv.r,
+                               c->partial);
+            if ((rc = finalize(c, OP_BI_RHO, ns, 2, rtol, atol, min_it))) return rc;
+        }
+        it += chunk;
+        if ((rc = poll_status(c, ns, hs))) return rc;
+    }
+    double hscal[KNP_MAX_SYS * KS_N];
+    HIPCHK(c, hipMemcpy(hscal, c->scal, sizeof(double) * KS_N * ns, hipMemcpyDeviceToHost));
+    int bad = 0;
+    for (int s = 0; s < ns; ++s) {
+        niter[s] = hs[2 * s + 1];
+        res[3 * s + 0] = hscal[s * KS_N + KS_RES0];
+        res[3 * s + 1] = hscal[s * KS_N + KS_RES];
+        res[3 * s + 2] = hscal[s * KS_N + KS_BNORM];
+        if (hs[2 * s] != 1) bad = hs[2 * s] ? hs[2 * s] : -1;
+    }
+    if (bad) { c->err = "KNP BiCGStab did not converge (status " + std::to_string(bad) + ")"; return -3; }
+    return 0;
+}
+
+int bicgstab_solve(knp_ctx* c, KrylovVecs& kv, double rtol, double atol, int maxit, int min_it, int check_every, int* niter,
+                   double* res) {
+    if (check_every < 1) check_every = 1;
+    return c->m.dim == 3 ? bicgstab_impl<4>(c, kv, rtol, atol, maxit, min_it, check_every, niter, res)
+                         : bicgstab_impl<3>(c, kv, rtol, atol, maxit, min_it, check_every, niter, res);
+}

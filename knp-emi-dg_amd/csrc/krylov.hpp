@@ -1,0 +1,15 @@
+// Krylov scalars (device resident, one row of KS_N doubles per system) and work-vector bundle.
+#pragma once
+#include "knpemi_internal.hpp"
+
+enum { KS_RHO = 0, KS_RHO_OLD, KS_ALPHA, KS_BETA, KS_OMEGA, KS_RES, KS_RES0, KS_BNORM, KS_TOL, KS_N = 12 };
+
+struct KrylovVecs {
+    double *x, *b, *coef, *binv;           // unknown, rhs, operator coefficient (kappa | dnphi), block-Jacobi inverses
+    double *r, *z, *p, *w;                 // PCG
+    double *rhat, *v, *y;                  // BiCGStab extras (t aliases w)
+};
+
+int pcg_solve(knp_ctx* c, KrylovVecs& kv, double rtol, double atol, int maxit, int check_every, int* niter, double* res);
+int bicgstab_solve(knp_ctx* c, KrylovVecs& kv, double rtol, double atol, int maxit, int min_it, int check_every, int* niter,
+                   double* res);

@@ -1,0 +1,235 @@
+"""ctypes binding of libknpemi_hip.so (the C ABI declared in include/knpemi_hip.h).
+
+The product path has NO CPU fallback: if the shared library is missing, or no
+MI355X is visible when a context is created, this module raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libknpemi_hip.so")
+
+# enum knp_field (include/knpemi_hip.h)
+F_PHI, F_C, F_C_PREV, F_C_ELIM, F_PHI_M, F_I_CH, F_E, F_KAPPA, F_DNPHI, F_B_EMI, F_B_KNP, F_X, F_Y, \
+    F_FACET_TMP = range(14)
+
+_f64p = C.POINTER(C.c_double)
+_i32p = C.POINTER(C.c_int32)
+_i64p = C.POINTER(C.c_int64)
+_u32p = C.POINTER(C.c_uint32)
+_i8p = C.POINTER(C.c_int8)
+_ctxp = C.c_void_p
+
+# every exported symbol of include/knpemi_hip.h with its signature
+SIGNATURES = {
+    "knp_ctx_create": (C.c_int, [C.POINTER(_ctxp), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64,
+                                 C.c_int64, C.c_int64, _f64p, _i32p, _u32p, _i32p, _i8p, _u32p, C.c_int, _u32p]),
+    "knp_ctx_destroy": (None, [_ctxp]),
+    "knp_last_error": (C.c_char_p, [_ctxp]),
+    "knp_set_params": (C.c_int, [_ctxp] + [C.c_double] * 8 + [_f64p, _f64p, _f64p, _f64p, C.c_int]),
+    "knp_field_size": (C.c_int64, [_ctxp, C.c_int]),
+    "knp_upload": (C.c_int, [_ctxp, C.c_int, _f64p, C.c_int64, C.c_int64]),
+    "knp_download": (C.c_int, [_ctxp, C.c_int, _f64p, C.c_int64, C.c_int64]),
+    "knp_copy_field": (C.c_int, [_ctxp, C.c_int, C.c_int]),
+    "knp_update_kappa": (C.c_int, [_ctxp]),
+    "knp_update_dnphi": (C.c_int, [_ctxp]),
+    "knp_emi_apply": (C.c_int, [_ctxp, C.c_int, C.c_int]),
+    "knp_knp_apply": (C.c_int, [_ctxp, C.c_int, C.c_int]),
+    "knp_emi_rhs": (C.c_int, [_ctxp]),
+    "knp_knp_rhs": (C.c_int, [_ctxp]),
+    "knp_emi_solve": (C.c_int, [_ctxp, C.c_double, C.c_double, C.c_int, C.c_int, C.POINTER(C.c_int), _f64p]),
+    "knp_knp_solve": (C.c_int, [_ctxp, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), _f64p]),
+    "knp_step_updates": (C.c_int, [_ctxp]),
+    "knp_nernst": (C.c_int, [_ctxp]),
+    "knp_facet_trace": (C.c_int, [_ctxp, C.c_int, C.c_int, C.c_int]),
+    "knp_sync": (C.c_int, [_ctxp]),
+    "knp_timer_begin": (C.c_int, [_ctxp]),
+    "knp_timer_end": (C.c_int, [_ctxp, C.POINTER(C.c_float)]),
+    "knp_bench_apply": (C.c_int, [_ctxp, C.c_int, C.c_int, C.POINTER(C.c_float)]),
+    "knp_comm_unique_id": (C.c_int, [C.c_char_p]),
+    "knp_comm_init": (C.c_int, [_ctxp, C.c_int, C.c_int, C.c_char_p]),
+    "knp_halo_tables": (C.c_int, [_ctxp, C.c_int, _i32p, _i64p, _i32p, _i64p, _i64p]),
+    "knp_halo_exchange": (C.c_int, [_ctxp, C.c_int]),
+}
+
+_lib = None
+
+
+class KnpError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library (no GPU needed for loading)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise KnpError("libknpemi_hip.so is not built (%s); run `python __graft_entry__.py` or "
+                           "knp-emi-dg_amd/build.py -- there is no CPU fallback" % LIB_PATH)
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def _p(a, typ):
+    return a.ctypes.data_as(typ) if a is not None else None
+
+
+class Device:
+    """One context = one GPU = one partition of the mesh."""
+
+    def __init__(self, mesh, cell_tags, facet_tags, membrane_tags, n_ions, degree=1, device=0, nc_owned=None):
+        self.lib = load()
+        self.ctx = _ctxp()
+        coords = np.ascontiguousarray(mesh.coords, dtype=np.float64)
+        cells = np.ascontiguousarray(mesh.cells, dtype=np.int32)
+        ctags = np.ascontiguousarray(np.asarray(cell_tags), dtype=np.uint32)
+        ftags = np.ascontiguousarray(np.asarray(facet_tags), dtype=np.uint32)
+        fcells = np.ascontiguousarray(mesh.facet_cells, dtype=np.int32)
+        flocal = np.ascontiguousarray(mesh.facet_local, dtype=np.int8)
+        mt = np.ascontiguousarray(np.asarray(list(membrane_tags)), dtype=np.uint32)
+        nc = cells.shape[0]
+        assert ctags.shape == (nc,) and ftags.shape == (fcells.shape[0],)
+        self.dim = mesh.gdim
+        self.nd = self.dim + 1 if degree == 1 else (self.dim + 1) * (self.dim + 2) // 2
+        self.nc = nc
+        self.nc_owned = nc if nc_owned is None else int(nc_owned)
+        self.nf = fcells.shape[0]
+        self.n_ions = int(n_ions)
+        self.n_sys = self.n_ions - 1
+        rc = self.lib.knp_ctx_create(C.byref(self.ctx), device, self.dim, degree, self.n_ions, coords.shape[0], nc,
+                                     self.nc_owned, self.nf, _p(coords, _f64p), _p(cells, _i32p), _p(ctags, _u32p),
+                                     _p(fcells, _i32p), _p(flocal, _i8p), _p(ftags, _u32p), len(mt), _p(mt, _u32p))
+        if rc != 0:
+            msg = self.lib.knp_last_error(None)
+            self.ctx = None
+            raise KnpError("knp_ctx_create failed (%d): %s" % (rc, msg.decode() if msg else "?"))
+
+    # -- helpers -------------------------------------------------------------------
+    def _chk(self, rc, what):
+        if rc != 0:
+            msg = self.lib.knp_last_error(self.ctx)
+            raise KnpError("%s failed (%d): %s" % (what, rc, msg.decode() if msg else "?"))
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.knp_ctx_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_params(self, C_M, dt, F, R, T, C_phi, tau_emi, tau_knp, z, D, rho=None, fsrc=None, splitting=True):
+        z = np.ascontiguousarray(z, dtype=np.float64)
+        D = np.ascontiguousarray(D, dtype=np.float64)
+        assert z.shape == (self.n_ions,) and D.shape == (self.n_ions, self.nc)
+        rho = None if rho is None else np.ascontiguousarray(rho, dtype=np.float64)
+        fsrc = None if fsrc is None else np.ascontiguousarray(fsrc, dtype=np.float64)
+        self._chk(self.lib.knp_set_params(self.ctx, C_M, dt, F, R, T, C_phi, tau_emi, tau_knp, _p(z, _f64p), _p(D, _f64p),
+                                          _p(rho, _f64p), _p(fsrc, _f64p), int(bool(splitting))), "knp_set_params")
+
+    def size(self, field):
+        return int(self.lib.knp_field_size(self.ctx, field))
+
+    def upload(self, field, a, offset=0):
+        a = np.ascontiguousarray(a, dtype=np.float64).ravel()
+        self._chk(self.lib.knp_upload(self.ctx, field, _p(a, _f64p), offset, a.size), "knp_upload")
+
+    def download(self, field, offset=0, count=None):
+        n = self.size(field) - offset if count is None else count
+        out = np.empty(n, dtype=np.float64)
+        self._chk(self.lib.knp_download(self.ctx, field, _p(out, _f64p), offset, n), "knp_download")
+        return out
+
+    def copy_field(self, dst, src):
+        self._chk(self.lib.knp_copy_field(self.ctx, dst, src), "knp_copy_field")
+
+    def update_kappa(self):
+        self._chk(self.lib.knp_update_kappa(self.ctx), "knp_update_kappa")
+
+    def update_dnphi(self):
+        self._chk(self.lib.knp_update_dnphi(self.ctx), "knp_update_dnphi")
+
+    def emi_apply(self, fx=F_X, fy=F_Y):
+        self._chk(self.lib.knp_emi_apply(self.ctx, fx, fy), "knp_emi_apply")
+
+    def knp_apply(self, fx=F_X, fy=F_Y):
+        self._chk(self.lib.knp_knp_apply(self.ctx, fx, fy), "knp_knp_apply")
+
+    def emi_rhs(self):
+        self._chk(self.lib.knp_emi_rhs(self.ctx), "knp_emi_rhs")
+
+    def knp_rhs(self):
+        self._chk(self.lib.knp_knp_rhs(self.ctx), "knp_knp_rhs")
+
+    def emi_solve(self, rtol, atol=1e-40, maxit=1000, check_every=25):
+        it = C.c_int(0)
+        res = np.zeros(3)
+        rc = self.lib.knp_emi_solve(self.ctx, rtol, atol, maxit, check_every, C.byref(it), _p(res, _f64p))
+        self._chk(rc, "knp_emi_solve")
+        return it.value, res
+
+    def knp_solve(self, rtol, atol=1e-40, maxit=1000, min_it=5, check_every=10):
+        it = (C.c_int * max(self.n_sys, 1))()
+        res = np.zeros(3 * self.n_sys)
+        rc = self.lib.knp_knp_solve(self.ctx, rtol, atol, maxit, min_it, check_every, it, _p(res, _f64p))
+        self._chk(rc, "knp_knp_solve")
+        return list(it)[:self.n_sys], res.reshape(self.n_sys, 3)
+
+    def step_updates(self):
+        self._chk(self.lib.knp_step_updates(self.ctx), "knp_step_updates")
+
+    def nernst(self):
+        self._chk(self.lib.knp_nernst(self.ctx), "knp_nernst")
+
+    def facet_trace(self, field, species, side):
+        self._chk(self.lib.knp_facet_trace(self.ctx, field, species, side), "knp_facet_trace")
+        return self.download(F_FACET_TMP)
+
+    def sync(self):
+        self._chk(self.lib.knp_sync(self.ctx), "knp_sync")
+
+    def timer_begin(self):
+        self._chk(self.lib.knp_timer_begin(self.ctx), "knp_timer_begin")
+
+    def timer_end(self):
+        ms = C.c_float(0)
+        self._chk(self.lib.knp_timer_end(self.ctx, C.byref(ms)), "knp_timer_end")
+        return ms.value
+
+    def bench_apply(self, which, reps):
+        ms = C.c_float(0)
+        self._chk(self.lib.knp_bench_apply(self.ctx, which, reps, C.byref(ms)), "knp_bench_apply")
+        return ms.value
+
+    # -- multi-GPU ---------------------------------------------------------------------
+    def comm_init(self, rank, nranks, uid):
+        self._chk(self.lib.knp_comm_init(self.ctx, rank, nranks, uid), "knp_comm_init")
+
+    def halo_tables(self, peers, send_lists, recv_offsets, recv_counts):
+        peers = np.ascontiguousarray(peers, dtype=np.int32)
+        sc = np.ascontiguousarray([len(s) for s in send_lists], dtype=np.int64)
+        cells = np.ascontiguousarray(np.concatenate(send_lists) if len(send_lists) else np.zeros(0), dtype=np.int32)
+        ro = np.ascontiguousarray(recv_offsets, dtype=np.int64)
+        rcnt = np.ascontiguousarray(recv_counts, dtype=np.int64)
+        self._chk(self.lib.knp_halo_tables(self.ctx, len(peers), _p(peers, _i32p), _p(sc, _i64p), _p(cells, _i32p),
+                                           _p(ro, _i64p), _p(rcnt, _i64p)), "knp_halo_tables")
+
+    def halo_exchange(self, field):
+        self._chk(self.lib.knp_halo_exchange(self.ctx, field), "knp_halo_exchange")
+
+
+def comm_unique_id():
+    buf = C.create_string_buffer(128)
+    if load().knp_comm_unique_id(buf) != 0:
+        raise KnpError("knp_comm_unique_id failed")
+    return buf.raw

@@ -1,0 +1,50 @@
+"""Shared helpers for parity tests: seeded synthetic inputs of BASELINE config 2."""
+import numpy as np
+
+import knpemi_oracle as ko
+
+
+def synthetic_state(pb, seed=0):
+    """x ~ U(-1,1) seed 0; c_k = tag-wise ICs * (1 + 0.01 U(-1,1)) seed 1; phi ~ 0.07 U(-1,1) seed 2
+    (BASELINE.md section 4, config 2).  Also perturbs phi_M and channel currents."""
+    nc, nd = pb.mesh.num_cells(), pb.nd
+    x = np.random.default_rng(seed).uniform(-1, 1, size=(pb.N_ions, nc, nd))
+    r1 = np.random.default_rng(seed + 1)
+    pb.c = pb.c * (1 + 0.01 * r1.uniform(-1, 1, size=pb.c.shape))
+    pb.c_elim = pb.c_elim * (1 + 0.01 * r1.uniform(-1, 1, size=pb.c_elim.shape))
+    pb.c_prev_n = pb.c * (1 + 0.001 * r1.uniform(-1, 1, size=pb.c.shape))
+    pb.phi = 0.07 * np.random.default_rng(seed + 2).uniform(-1, 1, size=(nc, nd))
+    r3 = np.random.default_rng(seed + 3)
+    nf = pb.mesh.num_facets()
+    pb.phi_M = np.zeros(nf)
+    pb.phi_M[pb.mem] = -0.07 + 0.01 * r3.uniform(-1, 1, size=len(pb.mem))
+    for name in pb.I_ch:
+        pb.I_ch[name] = np.zeros(nf)
+        pb.I_ch[name][pb.mem] = 1e-3 * r3.uniform(-1, 1, size=len(pb.mem))
+    return x
+
+
+def device_for(pb, **kw):
+    from knpemidg import _abi
+    dev = _abi.Device(pb.mesh, pb.cell_tags, pb.facet_tags, pb.membrane_tags, len(pb.ions), degree=pb.p, **kw)
+    z = [ion["z"] for ion in pb.ions]
+    D = np.stack([ion["D"] for ion in pb.ions])
+    dev.set_params(pb.C_M, pb.dt, pb.F, pb.R, pb.T, pb.C_phi, pb.tau, pb.tau, z, D, rho=pb.rho,
+                   splitting=pb.splitting)
+    return dev
+
+
+def push_state(dev, pb):
+    from knpemidg import _abi as A
+    dev.upload(A.F_C, pb.c)
+    dev.upload(A.F_C_PREV, pb.c_prev_n)
+    dev.upload(A.F_C_ELIM, pb.c_elim)
+    dev.upload(A.F_PHI, pb.phi)
+    dev.upload(A.F_PHI_M, pb.phi_M)
+    dev.upload(A.F_I_CH, np.stack([pb.I_ch[ion["name"]] for ion in pb.ions]))
+
+
+def relerr(a, b):
+    a = np.asarray(a).ravel()
+    b = np.asarray(b).ravel()
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-300))

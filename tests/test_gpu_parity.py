@@ -1,0 +1,109 @@
+"""GPU parity: HIP path (through the C ABI) vs the CPU oracle on identical seeded inputs.
+Tolerances: operator applies / right-hand sides / projections are pure re-orderings of the same
+floating-point sums -> 1e-11 relative to the vector's max norm (<= 1e-12 typical)."""
+import numpy as np
+import pytest
+
+import knpemi_oracle as ko
+from common import synthetic_state, device_for, push_state, relerr
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-11
+
+
+def _problems():
+    from knpemidg.mesh import make_mesh_2D, make_mesh_3D, make_mesh_MMS, BoxMesh, MeshFunction
+    out = {}
+    m, s, f = make_mesh_2D(0)
+    out["2D_neuron_r0"] = ko.build_idealized(m, s.array(), f.array(), membrane_tags=(1,))
+    m, s, f = make_mesh_3D(0)
+    out["3D_4axon_r0"] = ko.build_idealized(m, s.array(), f.array())
+    m, s, f = make_mesh_3D(0, n_axons=1)
+    out["3D_1axon_r0"] = ko.build_idealized(m, s.array(), f.array())
+    return out
+
+
+@pytest.fixture(scope="module", params=["2D_neuron_r0", "3D_1axon_r0", "3D_4axon_r0"])
+def case(request, hip_lib):
+    from knpemidg import _abi as A
+    pb = _problems()[request.param]
+    x = synthetic_state(pb)
+    dev = device_for(pb)
+    push_state(dev, pb)
+    yield pb, dev, x, A
+    dev.close()
+
+
+def test_kappa(case):
+    pb, dev, x, A = case
+    dev.update_kappa()
+    assert relerr(dev.download(A.F_KAPPA), pb.kappa()) < 1e-14
+
+
+def test_emi_apply(case):
+    pb, dev, x, A = case
+    Aemi, b, _ = ko.assemble_emi(pb, want_B=False)
+    dev.update_kappa()
+    dev.upload(A.F_X, x[0])
+    dev.emi_apply(A.F_X, A.F_Y)
+    y = dev.download(A.F_Y, 0, pb.ndof)
+    assert relerr(y, Aemi @ x[0].ravel()) < TOL
+    # A is symmetric and annihilates constants
+    dev.upload(A.F_X, np.ones(pb.ndof))
+    dev.emi_apply(A.F_X, A.F_Y)
+    y1 = dev.download(A.F_Y, 0, pb.ndof)
+    assert np.abs(y1).max() < 1e-9 * np.abs(y).max()
+
+
+def test_emi_rhs(case):
+    pb, dev, x, A = case
+    for splitting in (True, False):
+        pb.splitting = splitting
+        z = [ion["z"] for ion in pb.ions]
+        D = np.stack([ion["D"] for ion in pb.ions])
+        dev.set_params(pb.C_M, pb.dt, pb.F, pb.R, pb.T, pb.C_phi, pb.tau, pb.tau, z, D, rho=pb.rho, splitting=splitting)
+        dev.emi_rhs()
+        assert relerr(dev.download(A.F_B_EMI), ko.emi_rhs(pb)) < TOL
+    pb.splitting = True
+    dev.set_params(pb.C_M, pb.dt, pb.F, pb.R, pb.T, pb.C_phi, pb.tau, pb.tau, z, D, rho=pb.rho, splitting=True)
+
+
+def test_knp_apply(case):
+    pb, dev, x, A = case
+    dev.update_dnphi()
+    dev.upload(A.F_X, x)
+    dev.knp_apply(A.F_X, A.F_Y)
+    y = dev.download(A.F_Y).reshape(pb.N_ions, -1)
+    for k in range(pb.N_ions):
+        Ak = ko.assemble_knp(pb, k)
+        assert relerr(y[k], Ak @ x[k].ravel()) < TOL
+
+
+def test_knp_rhs(case):
+    pb, dev, x, A = case
+    dev.knp_rhs()
+    b = dev.download(A.F_B_KNP).reshape(pb.N_ions, -1)
+    for k in range(pb.N_ions):
+        assert relerr(b[k], ko.knp_rhs(pb, k)) < TOL
+
+
+def test_step_updates(case):
+    pb, dev, x, A = case
+    import copy
+    dev.step_updates()
+    phiM = dev.download(A.F_PHI_M)
+    ref = ko.update_phi_M(pb).copy()
+    assert relerr(phiM[pb.mem], ref) < 1e-13
+    celim = dev.download(A.F_C_ELIM)
+    assert relerr(celim, ko.update_c_elim(pb)) < 1e-14
+    E = dev.download(A.F_E).reshape(len(pb.ions), -1)
+    for k in range(len(pb.ions)):
+        assert relerr(E[k][pb.mem], ko.nernst(pb, k)) < 1e-12
+    assert relerr(dev.download(A.F_C_PREV), pb.c) < 1e-16
+    # traces used by the update_ode hook (run_3D.py:44-49)
+    K_e = dev.facet_trace(A.F_C, 0, 0)
+    ref = ko.facet_average(pb, pb.mem, lambda plus, minus: plus(pb.c[0]), 1)
+    assert relerr(K_e[pb.mem], ref) < 1e-14
+    Na_i = dev.facet_trace(A.F_C_ELIM, 0, 1)
+    ref = ko.facet_average(pb, pb.mem, lambda plus, minus: minus(pb.c_elim), 1)
+    assert relerr(Na_i[pb.mem], ref) < 1e-14
