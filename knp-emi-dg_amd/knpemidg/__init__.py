@@ -6,5 +6,11 @@ the dolfin-typed arguments are replaced by the array-backed stand-ins of `knpemi
 from knpemidg.mesh import Mesh, MeshFunction, Constant, RectangleMesh, BoxMesh
 from knpemidg.mesh import make_mesh_2D, make_mesh_3D, make_mesh_MMS
 
-__all__ = ["Mesh", "MeshFunction", "Constant", "RectangleMesh", "BoxMesh",
+from knpemidg.membrane import MembraneModel, get_indices, is_dlt_scalar, get_values, set_values
+from knpemidg.utils import (subdomain_marking_foo, interface_normal, plus, minus, pcws_constant_project,
+                            CellCenterDistance)
+from knpemidg.solver import Solver
+
+__all__ = ["Solver", "MembraneModel", "subdomain_marking_foo", "interface_normal", "plus", "minus",
+           "pcws_constant_project", "CellCenterDistance", "Mesh", "MeshFunction", "Constant", "RectangleMesh", "BoxMesh",
            "make_mesh_2D", "make_mesh_3D", "make_mesh_MMS"]

@@ -1,0 +1,190 @@
+"""`MembraneModel`: one ODE system per membrane facet (reference: src/knpemidg/membrane.py:7-186).
+
+Same constructor and method names as the reference.  Differences forced by the environment
+(SURVEY.md section 8b/8f-1): the ODE module supplies a vectorised `rhs(t, states, parameters)`
+(numpy, all nodes at once) instead of a numba cfunc address, and `step_lsoda` integrates the
+whole batch with an adaptive Dormand-Prince 5(4) pair under the reference's tolerance
+(rtol 1e-8, membrane.py:112) instead of one numbalsoda call per facet.  The channel currents
+`I_ch_k` are evaluated at the END state (the reference leaves whatever LSODA's last internal RHS
+call wrote, mm_hh.py:154-159), so ODE outputs agree at tolerance level, never bitwise.
+"""
+import numpy as np
+
+from knpemidg.functions import FacetFunction
+
+
+def is_dlt_scalar(V):
+    return hasattr(V, "tabulate_dof_coordinates")
+
+
+def get_indices(V, facet_f, tags):
+    """Facets (= DLT0 dofs) carrying one of `tags` (reference: dlt_dof_extraction.py:18-48)."""
+    marked = np.sort(np.unique(np.concatenate([np.nonzero(facet_f.array() == t)[0] for t in tags])))
+    return marked, marked.reshape(-1, 1)
+
+
+def get_values(u, indices):
+    return u.array()[np.asarray(indices).ravel()]
+
+
+def set_values(u, indices, values):
+    a = u.array().copy()
+    a[np.asarray(indices).ravel()] = values
+    u.vector().set_local(a)
+
+
+# Dormand-Prince 5(4) tableau
+_C = np.array([0, 1 / 5, 3 / 10, 4 / 5, 8 / 9, 1, 1])
+_A = [
+    [],
+    [1 / 5],
+    [3 / 40, 9 / 40],
+    [44 / 45, -56 / 15, 32 / 9],
+    [19372 / 6561, -25360 / 2187, 64448 / 6561, -212 / 729],
+    [9017 / 3168, -355 / 33, 46732 / 5247, 49 / 176, -5103 / 18656],
+    [35 / 384, 0, 500 / 1113, 125 / 192, -2187 / 6784, 11 / 84],
+]
+_B5 = np.array([35 / 384, 0, 500 / 1113, 125 / 192, -2187 / 6784, 11 / 84, 0])
+_B4 = np.array([5179 / 57600, 0, 7571 / 16695, 393 / 640, -92097 / 339200, 187 / 2100, 1 / 40])
+
+
+def integrate_batch(rhs, t0, t1, y, params, rtol=1.0e-8, atol=1.0e-12, h0=None, max_steps=100000):
+    """Advance all rows of `y` from t0 to t1 (shared adaptive step, error controlled row-wise)."""
+    t = t0
+    h = (t1 - t0) / 16 if h0 is None else h0
+    y = y.copy()
+    k = [None] * 7
+    k[0] = rhs(t, y, params)
+    steps = 0
+    while t < t1 and steps < max_steps:
+        h = min(h, t1 - t)
+        for s in range(1, 7):
+            ys = y + h * sum(a * k[j] for j, a in enumerate(_A[s]) if a != 0)
+            k[s] = rhs(t + _C[s] * h, ys, params)
+        y5 = y + h * sum(b * kk for b, kk in zip(_B5, k) if b != 0)
+        err = h * sum((b5 - b4) * kk for b5, b4, kk in zip(_B5, _B4, k))
+        scale = atol + rtol * np.maximum(np.abs(y), np.abs(y5))
+        e = float(np.max(np.abs(err) / scale)) if y.size else 0.0
+        steps += 1
+        if e <= 1.0 or h < 1e-14 * max(abs(t1), 1e-30):
+            t += h
+            y = y5
+            k[0] = k[6]                                   # FSAL
+            if t >= t1 - 1e-15 * abs(t1):
+                break
+        fac = 0.9 * (1.0 / max(e, 1e-10)) ** 0.2
+        h *= min(5.0, max(0.2, fac))
+    if steps >= max_steps:
+        raise AssertionError("ODE integrator did not reach the end time")   # `assert success`, membrane.py:113
+    rhs(t1, y, params)                                    # leave I_ch_k evaluated at the end state
+    return y, h
+
+
+class MembraneModel:
+    """ODE on the membrane facets where facet_f == tag (reference: membrane.py:7-41)."""
+
+    def __init__(self, ode, facet_f, tag, V):
+        mesh = facet_f.mesh()
+        assert mesh.gdim - 1 == facet_f.dim()
+        assert isinstance(tag, int)
+        assert is_dlt_scalar(V)
+        self.V = V
+        self.facets, indices = get_indices(V, facet_f, (tag,))
+        self.indices = indices.flatten()
+        self.dof_locations = V.tabulate_dof_coordinates()[self.indices]
+        nodes = len(self.indices)
+        self.nodes = nodes
+        self.states = np.array([ode.init_state_values() for _ in range(nodes)], dtype=np.float64)
+        self.parameters = np.array([ode.init_parameter_values() for _ in range(nodes)], dtype=np.float64)
+        self.tag = tag
+        self.ode = ode
+        self.prefix = getattr(ode, "__name__", "ode")
+        self.time = 0
+        self._h = None
+
+    # --- ODE <- PDE
+    def set_state(self, which, u, locator=None):
+        return self.__set_ODE('state', which, u, locator=locator)
+
+    def set_parameter(self, which, u, locator=None):
+        return self.__set_ODE('parameter', which, u, locator=locator)
+
+    # --- PDE <- ODE
+    def get_state(self, which, u, locator=None):
+        return self.__get_PDE('state', which, u, locator=locator)
+
+    def get_parameter(self, which, u, locator=None):
+        return self.__get_PDE('parameter', which, u, locator=locator)
+
+    def set_state_values(self, value_dict, locator=None):
+        return self.__set_ODE_values('state', value_dict, locator=locator)
+
+    def set_parameter_values(self, value_dict, locator=None):
+        return self.__set_ODE_values('parameter', value_dict, locator=locator)
+
+    def set_membrane_potential(self, u, locator=None):
+        return self.set_state('V', u, locator=locator)
+
+    def get_membrane_potential(self, u, locator=None):
+        return self.get_state('V', u, locator=locator)
+
+    @property
+    def V_index(self):
+        return self.ode.state_indices('V')
+
+    # ---- ODE integration (membrane.py:84-119)
+    def step_lsoda(self, dt, stimulus, stimulus_locator=None):
+        if stimulus is None:
+            stimulus = {}
+        if stimulus_locator is None:
+            stimulus_locator = lambda x: True
+        mask = np.fromiter(map(stimulus_locator, self.dof_locations), dtype=bool, count=self.nodes)
+        for key, value in stimulus.items():
+            self.parameters[mask, self.ode.parameter_indices(key)] = value
+        if self.nodes:
+            self.states, self._h = integrate_batch(self.ode.rhs, self.time, self.time + dt, self.states,
+                                                   self.parameters, rtol=1.0e-8, h0=self._h)
+        self.time = self.time + dt
+        return self.states
+
+    # --- work horses (membrane.py:122-186)
+    def _lidx(self, locator):
+        lidx = np.arange(self.nodes)
+        if locator is not None:
+            lidx = lidx[np.fromiter(map(locator, self.dof_locations), dtype=bool, count=self.nodes)]
+        return lidx
+
+    def __set_ODE(self, what, which, u, locator=None):
+        get_index, destination = {'state': (self.ode.state_indices, self.states),
+                                  'parameter': (self.ode.parameter_indices, self.parameters)}[what]
+        the_index = get_index(which)
+        lidx = self._lidx(locator)
+        source = u.array() if hasattr(u, "array") else np.asarray(u)
+        if len(lidx) > 0:
+            destination[lidx, the_index] = source[self.indices[lidx]]
+        return self.states
+
+    def __get_PDE(self, what, which, u, locator=None):
+        get_index, source = {'state': (self.ode.state_indices, self.states),
+                             'parameter': (self.ode.parameter_indices, self.parameters)}[what]
+        the_index = get_index(which)
+        lidx = self._lidx(locator)
+        destination = np.array(u.array(), dtype=np.float64, copy=True)
+        if len(lidx) > 0:
+            destination[self.indices[lidx]] = source[lidx, the_index]
+        u.vector().set_local(destination)
+        return u
+
+    def __set_ODE_values(self, what, value_dict, locator=None):
+        destination, get_col = {'state': (self.states, self.ode.state_indices),
+                                'parameter': (self.parameters, self.ode.parameter_indices)}[what]
+        lidx = self._lidx(locator)
+        if len(lidx) == 0:
+            return destination
+        coords = self.dof_locations[lidx]
+        for param in value_dict:
+            col = get_col(param)
+            get_value = value_dict[param]
+            for row, x in zip(lidx, coords):
+                destination[row, col] = get_value(x)
+        return destination

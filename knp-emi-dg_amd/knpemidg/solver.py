@@ -1,0 +1,487 @@
+"""`Solver`: the KNP-EMI splitting solver of adajel/KNP-EMI-DG with its DG assemble-and-solve
+hot path running as hand-written HIP kernels on MI355X.
+
+Same class, method names, call order, parameter field names and error behaviour as the
+reference (reference: src/knpemidg/solver.py:62-1258); what changed is what sits underneath:
+
+    reference                                     this build
+    ---------                                     ----------
+    UFL forms + dolfin.assemble (solver.py:477)   matrix-free operator applies  (csrc/apply_p1.hip)
+    PETSc Mat build (solver.py:458-460)           nothing -- no matrix exists
+    PETSc KSP cg/gmres + hypre (solver.py:509)    device PCG / BiCGStab         (csrc/krylov.hip)
+    pcws_constant_project / project (808-845)     facet kernels                 (csrc/rhs_p1.hip)
+
+dolfin objects are replaced by the array stand-ins of `knpemidg.mesh` / `knpemidg.functions`.
+There is no CPU fallback: without libknpemi_hip.so and a visible GPU, setup raises.
+"""
+import os
+import sys
+import time
+
+import numpy as np
+
+from knpemidg import _abi
+from knpemidg.functions import FacetSpace, FacetFunction, DeviceFacetFunction, DeviceFunction
+from knpemidg.membrane import MembraneModel
+from knpemidg.mesh import Constant
+from knpemidg.utils import interface_normal, plus, minus, pcws_constant_project
+
+JUMP = lambda f, n: ("JUMP", f, n)   # symbolic marker; the device evaluates minus - plus
+
+
+class bcolors:
+    OKGREEN = '\033[92m'
+    WARNING = '\033[93m'
+    ENDC = '\033[0m'
+
+
+def _f(v):
+    return float(v)
+
+
+class Solver:
+    def __init__(self, params, ion_list, degree_emi=1, degree_knp=1, mms=None, sf=1):
+        self.ion_list = ion_list
+        self.N_ions = len(ion_list[:-1])
+        self.degree_emi = degree_emi
+        self.degree_knp = degree_knp
+        self.mms = mms
+        self.params = params
+        self.sf = sf
+        # timers (solver.py:76-81)
+        self.ode_solve_timer = 0
+        self.emi_solve_timer = 0
+        self.knp_solve_timer = 0
+        self.emi_ass_timer = 0
+        self.knp_ass_timer = 0
+        self.verbose = True
+        self.dev = None
+        self.device_index = int(os.environ.get("LOCAL_RANK", "0"))
+        self.mem_models = []
+        self.stimulus = None
+        self.stimulus_locator = None
+        self.emi_niter = []
+        self.knp_niter = []
+        # Krylov caps: the reference sets ksp_max_it 1000 behind BoomerAMG (solver.py:429,687);
+        # the block-Jacobi preconditioner here needs more, so the cap is a solver_params option.
+        self.max_it_emi = 50000
+        self.max_it_knp = 5000
+
+    # ------------------------------------------------------------------ setup_domain (solver.py:85-121)
+    def setup_domain(self, mesh, subdomains, surfaces):
+        self.mesh = mesh
+        self.subdomains = subdomains
+        self.surfaces = surfaces
+        self.n_g = interface_normal(subdomains, mesh)
+        self.gdim = mesh.geometry().dim()
+        self.tau_emi = Constant(20 * self.gdim * self.degree_emi)
+        self.tau_knp = Constant(20 * self.gdim * self.degree_knp)
+        if self.mms is not None:
+            self.lm_tags = [1, 2, 3, 4]
+        if self.degree_emi != self.degree_knp:
+            raise NotImplementedError("degree_emi must equal degree_knp on the device path")
+        return
+
+    # ------------------------------------------------------------------ setup_parameters (solver.py:124-154)
+    def setup_parameters(self):
+        params = self.params
+        self.C_phi = Constant(_f(params.C_phi))
+        self.C_M = Constant(_f(params.C_M))
+        self.dt = Constant(_f(params.dt))
+        self.F = Constant(_f(params.F))
+        self.R = Constant(_f(params.R))
+        self.temperature = Constant(_f(params.temperature))
+        self.psi = _f(self.F) / (_f(self.R) * _f(self.temperature))
+        self.phi_M_init_type = params.phi_M_init_type
+        for idx, ion in enumerate(self.ion_list):
+            ion['D'] = self.make_global(ion['D_sub'])
+            self.rho = self.make_global(params.rho_sub)
+            if self.mms is not None:
+                ion['C'] = self.make_global(ion['C_sub'])
+        return
+
+    def make_global(self, f):
+        """DG0 array from a {cell tag: value} dict (solver.py:1244-1258); tags absent from the
+        dict keep 0 exactly as the reference's zero-initialised Function does."""
+        tags = self.subdomains.array()
+        q = np.zeros(len(tags), dtype=np.float64)
+        for key, value in f.items():
+            q[tags == int(key)] = float(value)
+        return q
+
+    # ------------------------------------------------------------------ setup_FEM_spaces (solver.py:157-225)
+    def setup_FEM_spaces(self):
+        d = self.gdim
+        p = self.degree_knp
+        self.nd = d + 1 if p == 1 else (d + 1) * (d + 2) // 2
+        nc = self.mesh.num_cells()
+        self._init_c = np.zeros((self.N_ions, nc, self.nd))
+        self._init_c_elim = np.zeros((nc, self.nd))
+        for idx, ion in enumerate(self.ion_list):
+            t = ion['c_init_sub_type']
+            if t == 'constant':
+                vals = self.make_global(ion['c_init_sub'])[:, None] * np.ones((nc, self.nd))
+            elif t == 'expression':
+                vals = self.make_global_expression(ion['c_init_sub'])
+            elif t == 'function':
+                src = ion['c_init_sub']
+                vals = np.asarray(src.array() if hasattr(src, "array") else src, dtype=np.float64).reshape(nc, self.nd)
+            else:
+                print(f"""Type of initial condition \"{t}\" not
+                    recognized - please spesify whether initial condition is
+                    \"constant\", \"expression\" or \"function\" """)
+                sys.exit(0)
+            if idx == len(self.ion_list) - 1:
+                self._init_c_elim = vals
+            else:
+                self._init_c[idx] = vals
+        self.Q = FacetSpace(self.mesh)
+        self._init_phi_M = np.zeros(self.mesh.num_facets())
+        if self.phi_M_init_type == 'function':
+            src = self.params.phi_M_init
+            self._init_phi_M = np.asarray(src.array() if hasattr(src, "array") else src, dtype=np.float64).copy()
+        elif self.phi_M_init_type in ('constant', 'expression'):
+            pm = getattr(self.params, "phi_M_init", None)
+            if pm is not None and self.phi_M_init_type == 'constant':
+                # the reference leaves phi_M_prev_PDE = 0 here and takes the value from the ODE file at
+                # k == 0 (solver.py:214, 1086-1090); identical once the first ODE step has run.
+                pass
+        else:
+            print(f"""Type of initial condition \"{self.phi_M_init_type}\" not
+                recognized - please spesify whether initial condition is
+                \"constant\", \"expression\" or \"function\" """)
+            sys.exit(0)
+        return
+
+    def make_global_expression(self, f):
+        """Nodal interpolation of per-subdomain callables f[tag](x) (solver.py:1260-1298)."""
+        tags = self.subdomains.array()
+        X = self._node_coordinates()
+        out = np.zeros(X.shape[:2])
+        matched = np.zeros(len(tags), dtype=bool)
+        for tag, fun in f.items():
+            sel = tags == int(tag)
+            matched |= sel
+            if sel.any():
+                out[sel] = np.asarray(fun(X[sel]), dtype=np.float64)
+        assert matched.all(), "Dictionaries for DG data must match cell tags in mesh"
+        return out
+
+    def _node_coordinates(self):
+        x = self.mesh.coords[self.mesh.cells]
+        if self.degree_knp == 1:
+            return x
+        nv = x.shape[1]
+        mids = [0.5 * (x[:, a] + x[:, b]) for a in range(nv) for b in range(a + 1, nv)]
+        return np.concatenate([x, np.stack(mids, axis=1)], axis=1)
+
+    # ------------------------------------------------------------------ setup_membrane_model (solver.py:228-267)
+    def setup_membrane_model(self, stim_params, odes):
+        self.stimulus = stim_params.stimulus
+        self.stimulus_locator = stim_params.stimulus_locator
+        self.mem_models = []
+        self._ensure_device(membrane_tags=[int(t) for t in odes.keys()])
+        for tag, ode in odes.items():
+            ode_model = MembraneModel(ode, facet_f=self.surfaces, tag=int(tag), V=self.Q)
+            ode_model.set_parameter_values({'Cm': lambda x: self.params.C_M})
+            I_ch_k = {}
+            for i, ion in enumerate(self.ion_list):
+                I_ch_k_ = FacetFunction(self.Q)
+                ode_model.get_parameter("I_ch_" + ion['name'], I_ch_k_)
+                I_ch_k[ion['name']] = I_ch_k_
+            self.mem_models.append({'ode': ode_model, 'I_ch_k': I_ch_k})
+        return
+
+    # ------------------------------------------------------------------ device context
+    def _ensure_device(self, membrane_tags=None):
+        if self.dev is not None:
+            return
+        if self.mms is not None:
+            raise NotImplementedError("MMS source terms are not on the device path yet (SURVEY.md section 8f-4)")
+        if membrane_tags is None:
+            membrane_tags = [m['ode'].tag for m in self.mem_models]
+        self.membrane_tags = list(membrane_tags)
+        nc = self.mesh.num_cells()
+        self.dev = _abi.Device(self.mesh, self.subdomains.array(), self.surfaces.array(), self.membrane_tags,
+                               len(self.ion_list), degree=self.degree_knp, device=self.device_index)
+        A = _abi
+        dev = self.dev
+        self.phi = DeviceFunction(dev, A.F_PHI, nc, self.nd)
+        self.c = DeviceFunction(dev, A.F_C, nc, self.nd, n_comp=self.N_ions)
+        self.c_prev_k = self.c                                       # identical between Picard levels (solver.py:809)
+        self.c_prev_n = DeviceFunction(dev, A.F_C_PREV, nc, self.nd, n_comp=self.N_ions)
+        self.ion_list[-1]['c'] = DeviceFunction(dev, A.F_C_ELIM, nc, self.nd)
+        self.phi_M_prev_PDE = DeviceFacetFunction(self.Q, dev, A.F_PHI_M)
+        for k, ion in enumerate(self.ion_list):
+            ion['E'] = DeviceFacetFunction(self.Q, dev, A.F_E, row=k)
+        dev.upload(A.F_C, self._init_c)
+        dev.upload(A.F_C_PREV, self._init_c)
+        dev.upload(A.F_C_ELIM, self._init_c_elim)
+        dev.upload(A.F_PHI_M, self._init_phi_M)
+        self._push_params(splitting=True)
+        dev.nernst()                                                 # initial E_k (solver.py:299-300)
+
+    def _push_params(self, splitting):
+        z = [float(ion['z']) for ion in self.ion_list]
+        D = np.stack([ion['D'] for ion in self.ion_list])
+        fsrc = None
+        fs = [float(ion.get('f_source', 0.0)) for ion in self.ion_list[:-1]]
+        if any(v != 0.0 for v in fs):
+            ecs = (self.subdomains.array() == 0).astype(np.float64)
+            fsrc = np.stack([v * ecs for v in fs])
+        self.dev.set_params(_f(self.C_M), _f(self.dt), _f(self.F), _f(self.R), _f(self.temperature), _f(self.C_phi),
+                            _f(self.tau_emi), _f(self.tau_knp), z, D, rho=self.rho, fsrc=fsrc, splitting=splitting)
+
+    # ------------------------------------------------------------------ forms / solvers (solver.py:270-468, 534-721)
+    def setup_varform_emi(self):
+        """The bilinear / linear forms are fixed kernels; only the splitting flag is data."""
+        self._ensure_device()
+        self._push_params(self.splitting_scheme)
+        self.I_ch = [None] * len(self.mem_models)
+        return
+
+    def setup_varform_knp(self):
+        return
+
+    def setup_solver_emi(self):
+        self._read_solver_params()
+        return
+
+    def setup_solver_knp(self):
+        return
+
+    def _read_solver_params(self):
+        sp = getattr(self, "solver_params", None)
+        self.max_it_emi = int(getattr(sp, "max_it_emi", self.max_it_emi))
+        self.max_it_knp = int(getattr(sp, "max_it_knp", self.max_it_knp))
+        # direct solvers (MUMPS, solver.py:412-422, 671-681) have no device counterpart: emulate with a tight
+        # iterative tolerance
+        self._rtol_emi = 1e-12 if self.direct_emi else float(self.rtol_emi)
+        self._atol_emi = 1e-40 if self.direct_emi else float(self.atol_emi)
+        self._rtol_knp = 1e-12 if self.direct_knp else float(self.rtol_knp)
+        self._atol_knp = 1e-40 if self.direct_knp else float(self.atol_knp)
+
+    def _sync_membrane_to_device(self):
+        """phi_M and I_ch_k facet fields produced by the ODE step -> device."""
+        if not self.mem_models:
+            return
+        A = _abi
+        nf = self.mesh.num_facets()
+        Ich = np.zeros((len(self.ion_list), nf))
+        for mm in self.mem_models:
+            idx = mm['ode'].indices
+            for k, ion in enumerate(self.ion_list):
+                Ich[k, idx] = mm['I_ch_k'][ion['name']].array()[idx]
+        self.dev.upload(A.F_I_CH, Ich)
+
+    # ------------------------------------------------------------------ solve_emi (solver.py:470-531)
+    def solve_emi(self):
+        dev = self.dev
+        ts = time.perf_counter()
+        dev.update_kappa()
+        dev.emi_rhs()
+        dev.sync()
+        te = time.perf_counter()
+        res = te - ts
+        if self.verbose:
+            print(f"{bcolors.OKGREEN} GPU Execution time PDE assemble emi: {res:.4f} seconds {bcolors.ENDC}")
+        self.emi_ass_timer += res
+        if self.save_solver_stats:
+            self.file_emi_assem.write("ass_time: %.4f \n" % (res))
+        ts = time.perf_counter()
+        niter, r = dev.emi_solve(self._rtol_emi, self._atol_emi, maxit=self.max_it_emi)
+        te = time.perf_counter()
+        res = te - ts
+        if self.verbose:
+            print(f"{bcolors.OKGREEN} GPU Execution time PDE solve emi: {res:.4f} seconds ({niter} its) {bcolors.ENDC}")
+        self.emi_solve_timer += res
+        self.emi_niter.append(niter)
+        if self.save_solver_stats:
+            if not self.direct_emi:
+                self.file_emi_niter.write("niter: %d \n" % niter)
+            self.file_emi_solve.write("solve_time: %.4f \n" % (res))
+        return
+
+    # ------------------------------------------------------------------ solve_knp (solver.py:723-791)
+    def solve_knp(self):
+        dev = self.dev
+        ts = time.perf_counter()
+        dev.update_dnphi()
+        dev.knp_rhs()
+        dev.sync()
+        te = time.perf_counter()
+        res = te - ts
+        if self.verbose:
+            print(f"{bcolors.OKGREEN} GPU Execution time PDE assemble knp: {res:.4f} seconds {bcolors.ENDC}")
+        self.knp_ass_timer += res
+        if self.save_solver_stats:
+            self.file_knp_assem.write("ass_time: %.4f \n" % (res))
+        ts = time.perf_counter()
+        niters, r = dev.knp_solve(self._rtol_knp, self._atol_knp, maxit=self.max_it_knp, min_it=5)
+        te = time.perf_counter()
+        res = te - ts
+        if self.verbose:
+            print(f"{bcolors.OKGREEN} GPU Execution time PDE solve knp: {res:.4f} seconds ({niters} its) {bcolors.ENDC}")
+        self.knp_solve_timer += res
+        self.knp_niter.append(niters)
+        if self.save_solver_stats:
+            self.file_knp_solve.write("solve_time: %.4f \n" % (res))
+            if not self.direct_knp:
+                self.file_knp_niter.write("niter: %d \n" % max(niters))
+        return
+
+    # ------------------------------------------------------------------ solve_for_time_step (solver.py:794-847)
+    def solve_for_time_step(self, k, t):
+        if self.verbose:
+            print("------------------------------------------------")
+            print(f"{bcolors.WARNING} t = {float(t)} {bcolors.ENDC}")
+            print(f"{bcolors.WARNING} k = {k} {bcolors.ENDC}")
+            print("------------------------------------------------")
+        self.solve_emi()                    # step I
+        self.solve_knp()                    # step II
+        self.dev.step_updates()             # step III: c_prev <- c, phi_M, E_k, c_elim
+        t.assign(float(t + self.dt))
+        return
+
+    def _unpack_solver_params(self, solver_params):
+        self.solver_params = solver_params
+        self.direct_emi = solver_params.direct_emi
+        if not self.direct_emi:
+            self.rtol_emi = solver_params.rtol_emi
+            self.atol_emi = solver_params.atol_emi
+            self.threshold_emi = solver_params.threshold_emi      # accepted and ignored (no hypre)
+        self.direct_knp = solver_params.direct_knp
+        if not self.direct_knp:
+            self.rtol_knp = solver_params.rtol_knp
+            self.atol_knp = solver_params.atol_knp
+            self.threshold_knp = solver_params.threshold_knp
+
+    def _check_output_args(self, filename):
+        if filename is None and (self.save_solver_stats or self.save_fields):
+            print("Please specify filename when initiating Solver.solve_system_*() method")
+            sys.exit(0)
+        if self.save_fields:
+            self.init_h5_savefile(filename + 'results')
+        if self.save_solver_stats:
+            self.init_solver_stats(filename + 'solver/')
+
+    # ------------------------------------------------------------------ solve_system_passive (solver.py:930-1011)
+    def solve_system_passive(self, Tstop, t, solver_params, membrane_params, filename=None, save_fields=False,
+                             save_solver_stats=False):
+        self.filename = filename
+        self.save_fields = save_fields
+        self.save_solver_stats = save_solver_stats
+        self._unpack_solver_params(solver_params)
+        self.splitting_scheme = False
+        self.setup_varform_emi()
+        self.setup_varform_knp()
+        self.setup_solver_emi()
+        self.setup_solver_knp()
+        self._check_output_args(filename)
+        for k in range(int(round(Tstop / float(self.dt)))):
+            self.solve_for_time_step(k, t)
+            if (k % self.sf) == 0 and self.save_fields:
+                self.save_h5()
+        if self.save_fields:
+            self.close_h5()
+        if self.save_solver_stats:
+            self.close_solver_stats()
+        uh = self.c.split() + (self.phi,)
+        return uh, self.ion_list[-1]['c']
+
+    # ------------------------------------------------------------------ solve_system_active (solver.py:1014-1135)
+    def solve_system_active(self, Tstop, t, solver_params, filename=None, save_fields=False, save_solver_stats=False):
+        self.filename = filename
+        self.save_fields = save_fields
+        self.save_solver_stats = save_solver_stats
+        self._unpack_solver_params(solver_params)
+        self.splitting_scheme = True
+        self.setup_varform_emi()
+        self.setup_varform_knp()
+        self.setup_solver_emi()
+        self.setup_solver_knp()
+        self._check_output_args(filename)
+        for k in range(int(round(Tstop / float(self.dt)))):
+            self.step_membrane_models(k)
+            self.solve_for_time_step(k, t)
+            if (k % self.sf) == 0 and self.save_fields:
+                self.save_h5()
+        if self.save_fields:
+            self.close_h5()
+        if self.save_solver_stats:
+            self.close_solver_stats()
+        return
+
+    def step_membrane_models(self, k):
+        """ODE step of every membrane model + PDE<->ODE copies (solver.py:1076-1118)."""
+        ts = time.perf_counter()
+        dt_ode = float(self.dt)
+        for mem_model in self.mem_models:
+            ode_model = mem_model['ode']
+            if (self.phi_M_init_type == 'constant') and (k == 0):
+                pass
+            else:
+                ode_model.set_membrane_potential(self.phi_M_prev_PDE)
+            for i, ion in enumerate(self.ion_list):
+                ode_model.set_parameter(f"E_{ion['name']}", ion['E'])
+            self.update_ode(ode_model)
+            ode_model.step_lsoda(dt=dt_ode, stimulus=self.stimulus, stimulus_locator=self.stimulus_locator)
+            ode_model.get_membrane_potential(self.phi_M_prev_PDE)
+            for ion, I_ch_k in mem_model['I_ch_k'].items():
+                ode_model.get_parameter("I_ch_" + ion, I_ch_k)
+        self._sync_membrane_to_device()
+        res = time.perf_counter() - ts
+        self.ode_solve_timer += res
+        if self.verbose:
+            print(f"{bcolors.OKGREEN} CPU Execution time ODE solve: {res:.4f} seconds {bcolors.ENDC}")
+
+    def update_ode(self, ode_model):
+        raise NotImplementedError("Subclasses must implement the 'update_ode' function.")
+
+    # ------------------------------------------------------------------ solver statistics (solver.py:1146-1211)
+    def init_solver_stats(self, path_timings):
+        os.makedirs(path_timings, exist_ok=True)
+        reso = getattr(self.solver_params, "resolution", 0)
+        num_cells = self.mesh.num_cells()
+        dofs_emi = num_cells * self.nd
+        dofs_knp = dofs_emi * self.N_ions
+        sfx_e = "_dir" if self.direct_emi else ""
+        sfx_k = "_dir" if self.direct_knp else ""
+        self.file_emi_solve = open(path_timings + "emi_solve%s_%d.txt" % (sfx_e, reso), "w")
+        self.file_emi_assem = open(path_timings + "emi_assem%s_%d.txt" % (sfx_e, reso), "w")
+        self.file_emi_niter = None if self.direct_emi else open(path_timings + "emi_niter_%d.txt" % reso, "w")
+        self.file_knp_solve = open(path_timings + "knp_solve%s_%d.txt" % (sfx_k, reso), "w")
+        self.file_knp_assem = open(path_timings + "knp_assem%s_%d.txt" % (sfx_k, reso), "w")
+        self.file_knp_niter = None if self.direct_knp else open(path_timings + "knp_niter_%d.txt" % reso, "w")
+        for f, dofs in ((self.file_emi_solve, dofs_emi), (self.file_emi_assem, dofs_emi), (self.file_emi_niter, dofs_emi),
+                        (self.file_knp_solve, dofs_knp), (self.file_knp_assem, dofs_knp), (self.file_knp_niter, dofs_knp)):
+            if f is not None:
+                f.write("num cells: %d \n" % num_cells)
+                f.write("dofs: %d \n" % dofs)
+
+    def close_solver_stats(self):
+        for f in (self.file_emi_niter, self.file_knp_niter, self.file_emi_solve, self.file_knp_solve,
+                  self.file_emi_assem, self.file_knp_assem):
+            if f is not None:
+                f.close()
+
+    # ------------------------------------------------------------------ field output (solver.py:1214-1242)
+    # The reference writes a DOLFIN HDF5 time series; without h5py the same datasets go to .npz snapshots.
+    def init_h5_savefile(self, filename):
+        self.h5_idx = 0
+        self._h5_prefix = filename
+        os.makedirs(os.path.dirname(filename) or ".", exist_ok=True)
+        np.savez(filename + "_mesh.npz", coords=self.mesh.coords, cells=self.mesh.cells,
+                 subdomains=self.subdomains.array(), surfaces=self.surfaces.array(), facets=self.mesh.facets)
+        self._write_snapshot()
+
+    def _write_snapshot(self):
+        np.savez(self._h5_prefix + "_%05d.npz" % self.h5_idx, concentrations=self.c.array(),
+                 elim_concentration=self.ion_list[-1]['c'].array(), potential=self.phi.array())
+
+    def save_h5(self):
+        self.h5_idx += 1
+        self._write_snapshot()
+
+    def close_h5(self):
+        return

@@ -48,3 +48,23 @@ def relerr(a, b):
     a = np.asarray(a).ravel()
     b = np.asarray(b).ravel()
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-300))
+
+
+def small_3d(n=(8, 4, 4)):
+    """Tiny 3D box with one ICS block: fast enough for the oracle's direct solves."""
+    from knpemidg.mesh import BoxMesh, MeshFunction, _tag_box
+    nx, ny, nz = n
+    mesh = BoxMesh((0, 0, 0), (nx * 1.0, ny * 0.1, nz * 0.1), nx, ny, nz)
+    sub = MeshFunction(mesh, 3, 0)
+    surf = MeshFunction(mesh, 2, 0)
+    _tag_box(mesh, sub, surf, (2, 0.1, 0.1), (nx - 2, (ny - 1) * 0.1, (nz - 1) * 0.1), 1)
+    surf.array()[mesh.exterior_facets()] = 5
+    mesh.coords *= 1e-6
+    return mesh, sub, surf
+
+
+def mean_free(phi, vol):
+    """Subtract the volume-weighted mean (phi is defined modulo a constant, solver.py:464-490)."""
+    phi = np.asarray(phi).reshape(len(vol), -1)
+    mean = (phi.mean(axis=1) * vol).sum() / vol.sum()
+    return phi - mean

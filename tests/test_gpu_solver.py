@@ -1,0 +1,101 @@
+"""GPU solves and the full splitting step vs the oracle (direct sparse solves on small meshes).
+Tolerances: converged c <= 1e-6 relative, mean-free phi <= 1e-4 relative at the
+reference's rtol (1e-5 / 1e-7); tighter here because both sides are solved tightly."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import knpemi_oracle as ko
+from common import synthetic_state, device_for, push_state, relerr, small_3d, mean_free
+
+pytestmark = pytest.mark.gpu
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "idealized_geometries"))
+
+
+def _small_problems():
+    from knpemidg.mesh import make_mesh_2D
+    out = {}
+    m, s, f = make_mesh_2D(0)
+    out["2D"] = ko.build_idealized(m, s.array(), f.array(), membrane_tags=(1,))
+    m, s, f = small_3d()
+    out["3D"] = ko.build_idealized(m, s.array(), f.array(), membrane_tags=(1,))
+    return out
+
+
+@pytest.fixture(scope="module", params=["2D", "3D"])
+def case(request, hip_lib):
+    from knpemidg import _abi as A
+    pb = _small_problems()[request.param]
+    synthetic_state(pb)
+    dev = device_for(pb)
+    push_state(dev, pb)
+    yield pb, dev, A
+    dev.close()
+
+
+def test_emi_solve(case):
+    pb, dev, A = case
+    dev.update_kappa()
+    dev.emi_rhs()
+    dev.upload(A.F_PHI, np.zeros(pb.ndof))
+    niter, res = dev.emi_solve(1e-11, maxit=20000)
+    phi = dev.download(A.F_PHI)
+    ref = ko.solve_emi(pb, direct=True).copy()
+    a, b = mean_free(phi, pb.geom.vol), mean_free(ref, pb.geom.vol)
+    assert relerr(a, b) < 1e-7, (niter, res)
+    assert niter > 0
+
+
+def test_knp_solve(case):
+    pb, dev, A = case
+    # phi from the oracle's EMI solve so that both sides use the same potential
+    ko.solve_emi(pb, direct=True)
+    dev.upload(A.F_PHI, pb.phi)
+    dev.update_dnphi()
+    dev.knp_rhs()
+    niter, res = dev.knp_solve(1e-13, maxit=5000)
+    c = dev.download(A.F_C).reshape(pb.c.shape)
+    c0 = pb.c.copy()
+    ref = ko.solve_knp(pb, direct=True)
+    pb.c = c0
+    assert relerr(c, ref) < 1e-9, (niter, res)
+    assert all(n >= 5 for n in niter)          # ksp_min_it 5 (solver.py:686)
+
+
+@pytest.mark.parametrize("dim", [2, 3])
+def test_active_time_loop(hip_lib, dim):
+    """Three splitting steps with HH membranes + stimulus: GPU Solver vs oracle stepping fed with the
+    same ODE outputs (the ODE step is adjacent to the hot path)."""
+    from common_examples import make_solver, solver_parameters, Constant
+    from knpemidg.mesh import make_mesh_2D
+    mt = make_mesh_2D(0) if dim == 2 else small_3d()
+    S = make_solver(dim=dim, resolution=0, n_axons=1, mesh_tuple=mt)
+    sp = solver_parameters(dim, 0, max_it_emi=50000)
+    sp = sp._replace(rtol_emi=1e-10, rtol_knp=1e-12)
+    S._unpack_solver_params(sp)
+    S.save_fields = S.save_solver_stats = False
+    S.splitting_scheme = True
+    S.setup_varform_emi(); S.setup_varform_knp(); S.setup_solver_emi(); S.setup_solver_knp()
+    pb = ko.build_idealized(mt[0], mt[1].array(), mt[2].array(), membrane_tags=(1,))
+    pb.phi_M[:] = 0.0
+    t = Constant(0.0)
+    for k in range(3):
+        S.step_membrane_models(k)
+        # feed the oracle with the ODE outputs
+        pb.phi_M = S.phi_M_prev_PDE.array().copy()
+        for ion in pb.ions:
+            pb.I_ch[ion["name"]] = S.mem_models[0]['I_ch_k'][ion["name"]].array().copy()
+        S.solve_for_time_step(k, t)
+        E = ko.solve_for_time_step(pb, direct=True)
+        vol = pb.geom.vol
+        assert relerr(mean_free(S.phi.array(), vol), mean_free(pb.phi, vol)) < 1e-6
+        assert relerr(S.c.array(), pb.c) < 1e-8
+        assert relerr(S.ion_list[-1]['c'].array(), pb.c_elim) < 1e-8
+        assert relerr(S.phi_M_prev_PDE.array()[pb.mem], pb.phi_M[pb.mem]) < 1e-6
+        for ki, ion in enumerate(S.ion_list):
+            assert relerr(ion['E'].array()[pb.mem], E[ion['name']]) < 1e-7
+    # the stimulus must have moved the membrane potential on the stimulated part
+    assert np.abs(S.phi_M_prev_PDE.array()[pb.mem] + 0.0743861).max() > 1e-5
+    assert abs(float(t) - 3e-4) < 1e-12
