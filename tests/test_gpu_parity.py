@@ -107,3 +107,41 @@ def test_step_updates(case):
     Na_i = dev.facet_trace(A.F_C_ELIM, 0, 1)
     ref = ko.facet_average(pb, pb.mem, lambda plus, minus: minus(pb.c_elim), 1)
     assert relerr(Na_i[pb.mem], ref) < 1e-14
+
+
+@pytest.mark.parametrize("name", ["idealized_2D_r0", "box_3D_8x4x4"])
+def test_gpu_matches_golden(hip_lib, name):
+    """HIP path vs the committed fixtures (tests/golden/*.npz): applies, right-hand sides and one converged
+    splitting step.  The 2D r=0 case has membrane-tagged facets between EQUAL-tag cells (the mesh is too
+    coarse for the ICS box): the reference's n('-') orientation rule (utils.py:80) is exercised."""
+    import os
+    from knpemidg import _abi as A
+    from knpemidg.mesh import Mesh
+    from common import mean_free
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".npz"))
+    mesh = Mesh(g["coords"], g["cells"])
+    pb = ko.build_idealized(mesh, g["cell_tags"], g["facet_tags"], membrane_tags=(1,))
+    pb.c, pb.c_prev_n, pb.c_elim, pb.phi, pb.phi_M = g["c"], g["c_prev"], g["c_elim"], g["phi"], g["phi_M"]
+    for k, ion in enumerate(pb.ions):
+        pb.I_ch[ion["name"]] = g["I_ch"][k]
+    dev = device_for(pb)
+    push_state(dev, pb)
+    dev.update_kappa(); dev.update_dnphi()
+    dev.upload(A.F_X, g["x"][0]); dev.emi_apply(A.F_X, A.F_Y)
+    assert relerr(dev.download(A.F_Y, 0, pb.ndof), g["emi_Ax"]) < TOL
+    dev.upload(A.F_X, g["x"]); dev.knp_apply(A.F_X, A.F_Y)
+    assert relerr(dev.download(A.F_Y), g["knp_Ax"]) < TOL
+    dev.emi_rhs(); dev.knp_rhs()
+    assert relerr(dev.download(A.F_B_EMI), g["emi_rhs"]) < TOL
+    assert relerr(dev.download(A.F_B_KNP), g["knp_rhs"]) < TOL
+    # one splitting step, tight tolerances
+    dev.emi_solve(1e-11, maxit=50000)
+    dev.update_dnphi(); dev.knp_rhs(); dev.knp_solve(1e-13, maxit=5000)
+    dev.step_updates()
+    vol = pb.geom.vol
+    assert relerr(mean_free(dev.download(A.F_PHI), vol), mean_free(g["step_phi"], vol)) < 1e-6
+    assert relerr(dev.download(A.F_C), g["step_c"]) < 1e-8
+    assert relerr(dev.download(A.F_C_ELIM), g["step_c_elim"]) < 1e-8
+    assert relerr(dev.download(A.F_PHI_M)[pb.mem], g["step_phi_M"][pb.mem]) < 1e-6
+    assert relerr(dev.download(A.F_E).reshape(3, -1)[:, pb.mem], g["step_E"]) < 1e-7
+    dev.close()
