@@ -49,34 +49,42 @@ _B4 = np.array([5179 / 57600, 0, 7571 / 16695, 393 / 640, -92097 / 339200, 187 /
 
 
 def integrate_batch(rhs, t0, t1, y, params, rtol=1.0e-8, atol=1.0e-12, h0=None, max_steps=100000):
-    """Advance all rows of `y` from t0 to t1 (shared adaptive step, error controlled row-wise)."""
-    t = t0
-    h = (t1 - t0) / 16 if h0 is None else h0
+    """Advance all rows of `y` from t0 to t1.  Every row carries its OWN time and adaptive step, so a
+    row's result does not depend on which other rows share the batch (ranks that both hold a membrane
+    facet on a partition boundary therefore compute bitwise identical ODE outputs)."""
+    n = y.shape[0]
     y = y.copy()
+    t = np.full(n, float(t0))
+    h = np.full(n, (t1 - t0) / 16) if h0 is None else np.array(h0, dtype=np.float64, copy=True)
+    if h.shape != (n,):
+        h = np.full(n, (t1 - t0) / 16)
     k = [None] * 7
     k[0] = rhs(t, y, params)
+    done = np.zeros(n, dtype=bool)
+    tiny = 1e-14 * max(abs(t1), 1e-30)
     steps = 0
-    while t < t1 and steps < max_steps:
-        h = min(h, t1 - t)
+    while not done.all() and steps < max_steps:
+        hh = np.where(done, 0.0, np.minimum(h, t1 - t))
+        hc = hh[:, None]
         for s in range(1, 7):
-            ys = y + h * sum(a * k[j] for j, a in enumerate(_A[s]) if a != 0)
-            k[s] = rhs(t + _C[s] * h, ys, params)
-        y5 = y + h * sum(b * kk for b, kk in zip(_B5, k) if b != 0)
-        err = h * sum((b5 - b4) * kk for b5, b4, kk in zip(_B5, _B4, k))
+            ys = y + hc * sum(a * k[j] for j, a in enumerate(_A[s]) if a != 0)
+            k[s] = rhs(t + _C[s] * hh, ys, params)
+        y5 = y + hc * sum(b * kk for b, kk in zip(_B5, k) if b != 0)
+        err = hc * sum((b5 - b4) * kk for b5, b4, kk in zip(_B5, _B4, k))
         scale = atol + rtol * np.maximum(np.abs(y), np.abs(y5))
-        e = float(np.max(np.abs(err) / scale)) if y.size else 0.0
+        e = np.max(np.abs(err) / scale, axis=1)
+        e = np.where(np.isfinite(e), e, 1e10)
         steps += 1
-        if e <= 1.0 or h < 1e-14 * max(abs(t1), 1e-30):
-            t += h
-            y = y5
-            k[0] = k[6]                                   # FSAL
-            if t >= t1 - 1e-15 * abs(t1):
-                break
-        fac = 0.9 * (1.0 / max(e, 1e-10)) ** 0.2
-        h *= min(5.0, max(0.2, fac))
+        acc = ((e <= 1.0) | (hh < tiny)) & ~done
+        t = np.where(acc, t + hh, t)
+        y = np.where(acc[:, None], y5, y)
+        k[0] = np.where(acc[:, None], k[6], k[0])          # FSAL for accepted rows
+        done |= acc & (t >= t1 - 1e-15 * abs(t1))
+        fac = np.clip(0.9 * (1.0 / np.maximum(e, 1e-10)) ** 0.2, 0.2, 5.0)
+        h = np.where(done, h, hh * fac)
     if steps >= max_steps:
         raise AssertionError("ODE integrator did not reach the end time")   # `assert success`, membrane.py:113
-    rhs(t1, y, params)                                    # leave I_ch_k evaluated at the end state
+    rhs(np.full(n, float(t1)), y, params)                 # leave I_ch_k evaluated at the end state
     return y, h
 
 

@@ -203,7 +203,8 @@ class Solver:
         self.membrane_tags = list(membrane_tags)
         nc = self.mesh.num_cells()
         self.dev = _abi.Device(self.mesh, self.subdomains.array(), self.surfaces.array(), self.membrane_tags,
-                               len(self.ion_list), degree=self.degree_knp, device=self.device_index)
+                               len(self.ion_list), degree=self.degree_knp, device=self.device_index,
+                               nc_owned=getattr(self, "nc_owned", None))
         A = _abi
         dev = self.dev
         self.phi = DeviceFunction(dev, A.F_PHI, nc, self.nd)

@@ -145,3 +145,54 @@ def test_gpu_matches_golden(hip_lib, name):
     assert relerr(dev.download(A.F_PHI_M)[pb.mem], g["step_phi_M"][pb.mem]) < 1e-6
     assert relerr(dev.download(A.F_E).reshape(3, -1)[:, pb.mem], g["step_E"]) < 1e-7
     dev.close()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_partitioned_kernels_on_one_gpu(hip_lib, world):
+    """Owned+ghost sub-meshes on the device: every rank's context (all living on this one GPU, ghosts filled
+    from the global arrays = what the RCCL halo exchange delivers) must reproduce the owned rows of the
+    global oracle results.  Exercises nc_owned < nc in every kernel; RCCL itself needs >= 2 GPUs."""
+    from knpemidg import _abi as A
+    from knpemidg.partition import Partition
+    from common import small_3d
+    m, s, f = small_3d((12, 4, 4))
+    pbg = ko.build_idealized(m, s.array(), f.array(), membrane_tags=(1,))
+    x = synthetic_state(pbg)
+    Ag, bg, _ = ko.assemble_emi(pbg, want_B=False)
+    yg = (Ag @ x[0].ravel()).reshape(-1, pbg.nd)
+    yk = np.stack([(ko.assemble_knp(pbg, k) @ x[k].ravel()).reshape(-1, pbg.nd) for k in range(pbg.N_ions)])
+    bk = np.stack([ko.knp_rhs(pbg, k).reshape(-1, pbg.nd) for k in range(pbg.N_ions)])
+    import copy
+    q = copy.deepcopy(pbg)
+    ko.update_phi_M(q); ko.update_c_elim(q)
+    Eg = np.stack([ko.nernst(q, k) for k in range(3)])
+    part = Partition(m, world)
+    for rank in range(world):
+        loc = part.local(rank)
+        sub_l, surf_l = loc.localize(s, f, (1,))
+        pbl = ko.build_idealized(loc.mesh, sub_l.array(), surf_l.array(), membrane_tags=(1,))
+        cg, no = loc.cells_global, loc.nc_owned
+        pbl.c, pbl.c_prev_n, pbl.c_elim, pbl.phi = pbg.c[:, cg], pbg.c_prev_n[:, cg], pbg.c_elim[cg], pbg.phi[cg]
+        pbl.phi_M = pbg.phi_M[loc.facets_global]
+        for name in pbg.I_ch:
+            pbl.I_ch[name] = pbg.I_ch[name][loc.facets_global]
+        dev = device_for(pbl, nc_owned=no)
+        push_state(dev, pbl)
+        dev.update_kappa(); dev.update_dnphi()
+        dev.upload(A.F_X, x[0][cg]); dev.emi_apply(A.F_X, A.F_Y)
+        y = dev.download(A.F_Y, 0, pbl.ndof).reshape(-1, pbl.nd)
+        assert relerr(y[:no], yg[cg[:no]]) < TOL
+        dev.upload(A.F_X, x[:, cg]); dev.knp_apply(A.F_X, A.F_Y)
+        y = dev.download(A.F_Y).reshape(pbg.N_ions, -1, pbl.nd)
+        assert relerr(y[:, :no], yk[:, cg[:no]]) < TOL
+        dev.emi_rhs(); dev.knp_rhs()
+        assert relerr(dev.download(A.F_B_EMI).reshape(-1, pbl.nd)[:no], bg.reshape(-1, pbg.nd)[cg[:no]]) < TOL
+        assert relerr(dev.download(A.F_B_KNP).reshape(pbg.N_ions, -1, pbl.nd)[:, :no], bk[:, cg[:no]]) < TOL
+        dev.step_updates()
+        lmem = pbl.mem                                       # local membrane facets touching an owned cell
+        gmem = loc.facets_global[lmem]
+        pos = np.searchsorted(pbg.mem, gmem)
+        assert relerr(dev.download(A.F_PHI_M)[lmem], q.phi_M[gmem]) < 1e-13
+        assert relerr(dev.download(A.F_E).reshape(3, -1)[:, lmem], Eg[:, pos]) < 1e-12
+        assert relerr(dev.download(A.F_C_ELIM).reshape(-1, pbl.nd), q.c_elim[cg]) < 1e-14
+        dev.close()
