@@ -5,6 +5,7 @@
 #include "krylov.hpp"
 #include <cstring>
 #include <algorithm>
+#include <cmath>
 
 namespace {
 
@@ -123,7 +124,22 @@ int knp_ctx_create(knp_ctx** out, int device, int dim, int degree, int n_ions, i
         csrc = cpad.data();
         cstride = 4;
     }
+    std::vector<double> hcell(nc, 0.0);
+    for (int64_t k = 0; k < nc; ++k) {
+        double h2 = 0.0;
+        for (int a = 0; a < NV; ++a)
+            for (int b = a + 1; b < NV; ++b) {
+                double d2 = 0.0;
+                for (int q = 0; q < dim; ++q) {
+                    const double d = coords[(int64_t)cells[k * NV + a] * dim + q] - coords[(int64_t)cells[k * NV + b] * dim + q];
+                    d2 += d * d;
+                }
+                h2 = std::max(h2, d2);
+            }
+        hcell[k] = std::sqrt(h2);
+    }
     int rc = 0;
+    rc |= dev_alloc_copy(c, &m.h, hcell.data(), hcell.size());
     rc |= dev_alloc_copy(c, &m.coords, csrc, (size_t)nv * cstride);
     rc |= dev_alloc_copy(c, &m.cells, cells, (size_t)nc * NV);
     rc |= dev_alloc_copy(c, &m.nbr, nbr.data(), nbr.size());
@@ -170,7 +186,7 @@ void knp_ctx_destroy(knp_ctx* c) {
         delete fl;
         g_fields.erase(c);
     }
-    hipFree(c->m.coords); hipFree(c->m.cells); hipFree(c->m.nbr); hipFree(c->m.fflag); hipFree(c->m.cfacet); hipFree(c->m.mf);
+    hipFree(c->m.coords); hipFree(c->m.h); hipFree(c->m.cells); hipFree(c->m.nbr); hipFree(c->m.fflag); hipFree(c->m.cfacet); hipFree(c->m.mf);
     hipFree(c->D); hipFree(c->rho); hipFree(c->fsrc); hipFree(c->partial); hipFree(c->scal); hipFree(c->status);
     hipFree(c->halo_send_idx); hipFree(c->halo_sendbuf);
     if (c->pinned) hipHostFree(c->pinned);

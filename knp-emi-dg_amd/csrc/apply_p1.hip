@@ -5,21 +5,37 @@
 //
 // Replaces: dolfin.assemble(a_emi) + PETSc MatMult        (reference: src/knpemidg/solver.py:325-328,346,477,509)
 //           dolfin.assemble(A_knp) + PETSc MatMult        (reference: src/knpemidg/solver.py:586-594,730,771)
-// P1 facet integrals are closed forms (mass / triple-product matrices of a (D-1)-simplex).
+// P1 facet integrals are closed forms (mass / triple-product matrices of a (D-1)-simplex); the
+// geometry enters only through the own cell's Gram matrix and the neighbour apex's barycentric
+// coordinates (cell_geom.hpp).
 #include "cell_geom.hpp"
 
 template <int D> struct FacetConst;
 template <> struct FacetConst<3> { static constexpr double mass = 1.0 / 12.0, trip = 1.0 / 60.0; };
 template <> struct FacetConst<2> { static constexpr double mass = 1.0 / 6.0, trip = 1.0 / 24.0; };
 
+// grad(w') . g_i for the neighbour's P1 function w' (values wn[], neighbour local facet j)
+template <int D, int I>
+__device__ __forceinline__ double nb_grad_dot(const CellGeom<D>& K, const double* L, double rLi, const double* wn, int j) {
+    const double gr = K.G[I][I] * rLi;
+    double s = pick_apex<D>(wn, j) * gr;
+#pragma unroll
+    for (int mm = 0; mm < D; ++mm) {
+        const int a = mm + (mm >= I);
+        s = fma(pick_facet<D>(wn, mm, j), fma(-L[a], gr, K.G[a][I]), s);
+    }
+    return s;
+}
+
 // ------------------------------------------------------------------------------------------
 // EMI:  y = A(kappa) x
 //   A(u,v) = int kappa grad u.grad v - int_dS0 avg(kappa grad u).n jump(v) - int_dS0 avg(kappa grad v).n jump(u)
 //          + int_dS0 tau/avg(h) avg(kappa) jump(u) jump(v) + C_phi int_dS(mem) jump(u) jump(v)
+// With s(w) = grad w . g_i:   area * (grad w . n_i) = -D vol s(w),   area = sqrt(G_ii) D vol.
 // ------------------------------------------------------------------------------------------
 template <int D, int I, bool DIAG>
 __device__ __forceinline__ void emi_facet(const MeshDev& m, const CellGeom<D>& K, const int* nb, uint32_t flags,
-                                          const double* xv, const double* kv,
+                                          const double* xv, const double* kv, double hK,
                                           const double* __restrict__ x, const double* __restrict__ kappa,
                                           double C_phi, double tau, double* y) {
     constexpr int NV = D + 1;
@@ -28,8 +44,6 @@ __device__ __forceinline__ void emi_facet(const MeshDev& m, const CellGeom<D>& K
     if (kind >= FK_EXTERIOR) return;
     const int j = (int)(fb & 3u);
     const int64_t Kp = nb[I];
-    FacetGeom<D> F;
-    facet_own<D, I>(K, F);
     double xn[NV];
     if (DIAG) {
 #pragma unroll
@@ -43,80 +57,78 @@ __device__ __forceinline__ void emi_facet(const MeshDev& m, const CellGeom<D>& K
         du[mm] = xv[mm + (mm >= I)] - pick_facet<D>(xn, mm, j);
         sdu += du[mm];
     }
+    const double DV = (double)D * K.vol;
     if (kind == FK_MEMBRANE) {
-        const double w = C_phi * F.area * FacetConst<D>::mass;
+        const double w = C_phi * fast_sqrt(K.G[I][I]) * DV * FacetConst<D>::mass;
 #pragma unroll
-        for (int mm = 0; mm < D; ++mm) y[mm + (mm >= I)] += w * (sdu + du[mm]);
+        for (int mm = 0; mm < D; ++mm) y[mm + (mm >= I)] = fma(w, sdu + du[mm], y[mm + (mm >= I)]);
         return;
     }
-    double kn[NV];
+    double kn[NV], Xo[D], L[NV];
     load_nodal<D>(kappa, Kp, kn);
-    double Xo[D];
+    const double hN = m.h[Kp];
     load_vertex<D>(m.coords, m.cells[Kp * NV + j], Xo);
-    facet_neighbour<D, I>(K, Xo, F);
-    double dnu_own = 0.0;
+    apex_bary<D>(K, Xo, L);
+    const double rLi = fast_rcp(L[I]);
+    // s = grad u . g_i on both sides
+    double s_own = 0.0;
 #pragma unroll
-    for (int a = 0; a < NV; ++a) dnu_own += xv[a] * F.dn[a];
-    double foot = 0.0, kf[D], knf[D], sk = 0.0, skn = 0.0;
+    for (int a = 0; a < NV; ++a) s_own = fma(xv[a], K.G[a][I], s_own);
+    const double s_nb = nb_grad_dot<D, I>(K, L, rLi, xn, j);
+    double kf[D], knf[D], sk = 0.0, skn = 0.0, q = 0.0;
 #pragma unroll
     for (int mm = 0; mm < D; ++mm) {
-        foot += F.beta[mm] * pick_facet<D>(xn, mm, j);
         kf[mm] = kv[mm + (mm >= I)];
         knf[mm] = pick_facet<D>(kn, mm, j);
         sk += kf[mm];
         skn += knf[mm];
+        q = fma(kf[mm], sdu + du[mm], q);
     }
-    const double dnu_nb = (pick_apex<D>(xn, j) - foot) / F.hp;
-    const double am = F.area * FacetConst<D>::mass;
-    // consistency term on own test functions (jump(v) = +v on this side)
-    double q = 0.0;
+    const double hm = 0.5 * DV * FacetConst<D>::mass;
+    // consistency: -1/2 int (k grad u.n + k' grad u'.n) v   ->  +hm (s_own (sk+kf_m) + s_nb (skn+knf_m))
+    // adjoint consistency: -1/2 (grad v_a.n) int k jump(u)  ->  +hm G_ai q
+    q *= hm;
 #pragma unroll
-    for (int mm = 0; mm < D; ++mm) {
-        y[mm + (mm >= I)] -= 0.5 * am * (dnu_own * (sk + kf[mm]) + dnu_nb * (skn + knf[mm]));
-        q += kf[mm] * (sdu + du[mm]);
-    }
-    // adjoint consistency: -1/2 (grad v.n) int kappa_K jump(u)
-    q *= 0.5 * am;
-#pragma unroll
-    for (int a = 0; a < NV; ++a) y[a] -= F.dn[a] * q;
-    // penalty
-    const double hbar = 0.5 * (sqrt(K.h2) + sqrt(F.hN2));
-    const double pw = tau / hbar * F.area * FacetConst<D>::trip;
+    for (int a = 0; a < NV; ++a) y[a] = fma(K.G[a][I], q, y[a]);
+    // penalty: tau/avg(h) int avg(k) jump(u) v
+    const double pw = tau * fast_rcp(0.5 * (hK + hN)) * fast_sqrt(K.G[I][I]) * DV * FacetConst<D>::trip;
     double kb[D], skb = 0.0, skd = 0.0;
 #pragma unroll
     for (int mm = 0; mm < D; ++mm) {
         kb[mm] = 0.5 * (kf[mm] + knf[mm]);
         skb += kb[mm];
-        skd += kb[mm] * du[mm];
+        skd = fma(kb[mm], du[mm], skd);
     }
+    const double base = fma(skb, sdu, skd);
 #pragma unroll
-    for (int mm = 0; mm < D; ++mm)
-        y[mm + (mm >= I)] += pw * (skb * sdu + kb[mm] * sdu + du[mm] * skb + skd + 2.0 * kb[mm] * du[mm]);
+    for (int mm = 0; mm < D; ++mm) {
+        const double t1 = hm * fma(s_own, sk + kf[mm], s_nb * (skn + knf[mm]));
+        const double t3 = pw * (base + fma(kb[mm], sdu, du[mm] * fma(2.0, kb[mm], skb)));
+        y[mm + (mm >= I)] += t1 + t3;
+    }
 }
 
 template <int D, bool DIAG>
 __device__ __forceinline__ void emi_cell(const MeshDev& m, const CellGeom<D>& K, const int* nb, uint32_t flags,
-                                         const double* xv, const double* kv,
+                                         const double* xv, const double* kv, double hK,
                                          const double* __restrict__ x, const double* __restrict__ kappa,
                                          double C_phi, double tau, double* y) {
     constexpr int NV = D + 1;
-    double gu[D];
-#pragma unroll
-    for (int k = 0; k < D; ++k) {
-        gu[k] = 0.0;
-#pragma unroll
-        for (int a = 0; a < NV; ++a) gu[k] += xv[a] * K.g[a][k];
-    }
     double kbar = 0.0;
 #pragma unroll
     for (int a = 0; a < NV; ++a) kbar += kv[a];
     kbar *= K.vol / (double)NV;
 #pragma unroll
-    for (int a = 0; a < NV; ++a) y[a] = kbar * dotD<D>(gu, K.g[a]);
-    emi_facet<D, 0, DIAG>(m, K, nb, flags, xv, kv, x, kappa, C_phi, tau, y);
-    emi_facet<D, 1, DIAG>(m, K, nb, flags, xv, kv, x, kappa, C_phi, tau, y);
-    emi_facet<D, 2, DIAG>(m, K, nb, flags, xv, kv, x, kappa, C_phi, tau, y);
-    if (D == 3) emi_facet<D, (D == 3 ? 3 : 0), DIAG>(m, K, nb, flags, xv, kv, x, kappa, C_phi, tau, y);
+    for (int a = 0; a < NV; ++a) {
+        double s = 0.0;
+#pragma unroll
+        for (int b = 0; b < NV; ++b) s = fma(K.G[a][b], xv[b], s);
+        y[a] = kbar * s;
+    }
+    emi_facet<D, 0, DIAG>(m, K, nb, flags, xv, kv, hK, x, kappa, C_phi, tau, y);
+    emi_facet<D, 1, DIAG>(m, K, nb, flags, xv, kv, hK, x, kappa, C_phi, tau, y);
+    emi_facet<D, 2, DIAG>(m, K, nb, flags, xv, kv, hK, x, kappa, C_phi, tau, y);
+    if (D == 3) emi_facet<D, (D == 3 ? 3 : 0), DIAG>(m, K, nb, flags, xv, kv, hK, x, kappa, C_phi, tau, y);
 }
 
 template <int D>
@@ -130,12 +142,13 @@ __global__ __launch_bounds__(KNP_BLOCK) void k_emi_apply(MeshDev m, const double
     load_cell_ints<D>(m.cells, c, verts);
     load_cell_ints<D>(m.nbr, c, nb);
     const uint32_t flags = m.fflag[c];
-    CellGeom<D> K;
-    load_cell_geometry<D>(m, verts, K);
     double xv[NV], kv[NV], yv[NV];
     load_nodal<D>(x, c, xv);
     load_nodal<D>(kappa, c, kv);
-    emi_cell<D, false>(m, K, nb, flags, xv, kv, x, kappa, C_phi, tau, yv);
+    const double hK = m.h[c];
+    CellGeom<D> K;
+    load_cell_geometry<D>(m, verts, K);
+    emi_cell<D, false>(m, K, nb, flags, xv, kv, hK, x, kappa, C_phi, tau, yv);
     store_nodal<D>(y, c, yv);
 }
 
@@ -175,13 +188,14 @@ __global__ __launch_bounds__(KNP_BLOCK) void k_emi_blockjacobi(MeshDev m, const 
     load_cell_geometry<D>(m, verts, K);
     double kv[NV];
     load_nodal<D>(kappa, c, kv);
+    const double hK = m.h[c];
     double A[NV][NV];
 #pragma unroll
     for (int b = 0; b < NV; ++b) {
         double e[NV], col[NV];
 #pragma unroll
         for (int a = 0; a < NV; ++a) e[a] = (a == b) ? 1.0 : 0.0;
-        emi_cell<D, true>(m, K, nb, flags, e, kv, nullptr, kappa, C_phi, tau, col);
+        emi_cell<D, true>(m, K, nb, flags, e, kv, hK, nullptr, kappa, C_phi, tau, col);
 #pragma unroll
         for (int a = 0; a < NV; ++a) A[a][b] = col[a];
     }
@@ -209,8 +223,8 @@ __global__ __launch_bounds__(KNP_BLOCK) void k_emi_blockjacobi(MeshDev m, const 
 //   A_k(u,v) = 1/dt int u v + int D grad u.grad v - int_dS0 avg(D grad u).n jump(v)
 //            - int_dS0 avg(D grad v).n jump(u) + int_dS0 tau/avg(h) jump(D u) jump(v)
 //            + z psi int D u grad(phi).grad v - z psi int_dS0 jump(v) jump(un u),
-//   un = max(D grad(phi).n_own, 0).   `dnphi[c][i]` = grad(phi)_c . n_i (outward) is precomputed
-//   once per KNP solve (phi is frozen during the solve).
+//   un = max(D grad(phi).n_own, 0).   `gphi[c][a]` = grad(phi)_c . grad(lambda_a) is precomputed
+//   once per KNP solve (phi is frozen during the solve):  area * grad(phi).n_i = -D vol gphi_i.
 // ------------------------------------------------------------------------------------------
 struct KnpArgs {
     int ns;
@@ -220,27 +234,26 @@ struct KnpArgs {
 
 template <int D, int NS, int I, bool DIAG>
 __device__ __forceinline__ void knp_facet(const MeshDev& m, const CellGeom<D>& K, const int* nb, uint32_t flags,
-                                          const double (*xv)[D + 1], const double* sv, const double* Dk,
-                                          const double* __restrict__ x, const double* __restrict__ dnphi,
-                                          const double* __restrict__ Dall, int64_t c, const KnpArgs& ka,
-                                          double (*y)[D + 1]) {
+                                          const double (*xv)[D + 1], const double* gp, const double* Dk, double hK,
+                                          const double* __restrict__ x, const double* __restrict__ gphi,
+                                          const double* __restrict__ Dall, const KnpArgs& ka, double (*y)[D + 1]) {
     constexpr int NV = D + 1;
     const uint32_t fb = (flags >> (8 * I)) & 0xffu;
     const uint32_t kind = (fb >> 2) & 3u;
     if (kind != FK_SIPG) return;
     const int j = (int)(fb & 3u);
     const int64_t Kp = nb[I];
-    FacetGeom<D> F;
-    facet_own<D, I>(K, F);
-    double Xo[D];
+    double Xo[D], L[NV];
     load_vertex<D>(m.coords, m.cells[Kp * NV + j], Xo);
-    facet_neighbour<D, I>(K, Xo, F);
-    const double s_nb = dnphi[Kp * NV + j];
-    const double sp_own = fmax(sv[I], 0.0), sp_nb = fmax(s_nb, 0.0);
-    const double hbar = 0.5 * (sqrt(K.h2) + sqrt(F.hN2));
-    const double pen = ka.tau / hbar;
-    const double am = F.area * FacetConst<D>::mass;
-    const double aD = F.area / (double)D;
+    const double hN = m.h[Kp];
+    const double gp_nb = gphi[Kp * NV + j];
+    apex_bary<D>(K, Xo, L);
+    const double rLi = fast_rcp(L[I]);
+    const double DV = (double)D * K.vol;
+    // upwind speeds times area: un*area = D_k max(-gphi_i, 0) D vol ; neighbour: vol' = -L_i vol
+    const double up_own = fmax(-gp[I], 0.0) * DV;
+    const double up_nb = fmax(-gp_nb, 0.0) * DV * (-L[I]);
+    const double penA = ka.tau * fast_rcp(0.5 * (hK + hN)) * fast_sqrt(K.G[I][I]) * DV;
 #pragma unroll
     for (int k = 0; k < NS; ++k) {
         const double Dn = Dall[(int64_t)k * m.nc + Kp];
@@ -251,71 +264,65 @@ __device__ __forceinline__ void knp_facet(const MeshDev& m, const CellGeom<D>& K
         } else {
             load_nodal<D>(x + (int64_t)k * m.nc * NV, Kp, xn);
         }
-        double dnu_own = 0.0;
+        double s_own = 0.0;
 #pragma unroll
-        for (int a = 0; a < NV; ++a) dnu_own += xv[k][a] * F.dn[a];
-        double foot = 0.0, sdu = 0.0, w[D], sw = 0.0, u[D], su = 0.0;
-        const double un = Dk[k] * sp_own, unn = Dn * sp_nb;
+        for (int a = 0; a < NV; ++a) s_own = fma(xv[k][a], K.G[a][I], s_own);
+        const double s_nb = nb_grad_dot<D, I>(K, L, rLi, xn, j);
+        const double zp = ka.z[k] * ka.psi;
+        // per facet-vertex weight of the mass-like terms:  pen (D u - D' u') - z psi (un u - un' u')
+        const double c_own = penA * Dk[k] - zp * Dk[k] * up_own;
+        const double c_nb = penA * Dn - zp * Dn * up_nb;
+        double sdu = 0.0, w[D], sw = 0.0;
 #pragma unroll
         for (int mm = 0; mm < D; ++mm) {
             const double xo = xv[k][mm + (mm >= I)];
             const double xnb = pick_facet<D>(xn, mm, j);
-            foot += F.beta[mm] * xnb;
             sdu += xo - xnb;
-            w[mm] = Dk[k] * xo - Dn * xnb;
+            w[mm] = fma(c_own, xo, -c_nb * xnb);
             sw += w[mm];
-            u[mm] = un * xo - unn * xnb;
-            su += u[mm];
         }
-        const double dnu_nb = (pick_apex<D>(xn, j) - foot) / F.hp;
-        const double t1 = 0.5 * (Dk[k] * dnu_own + Dn * dnu_nb) * aD;
-        const double t2 = 0.5 * Dk[k] * aD * sdu;
-        const double zp = ka.z[k] * ka.psi;
+        // consistency: +1/2 vol (D s_own + D' s_nb) ; adjoint: +1/2 D G_ai vol sum(du)
+        const double t1 = 0.5 * K.vol * fma(Dk[k], s_own, Dn * s_nb);
+        const double t2 = 0.5 * Dk[k] * K.vol * sdu;
 #pragma unroll
-        for (int a = 0; a < NV; ++a) y[k][a] -= F.dn[a] * t2;
+        for (int a = 0; a < NV; ++a) y[k][a] = fma(K.G[a][I], t2, y[k][a]);
 #pragma unroll
         for (int mm = 0; mm < D; ++mm)
-            y[k][mm + (mm >= I)] += -t1 + am * (pen * (sw + w[mm]) - zp * (su + u[mm]));
+            y[k][mm + (mm >= I)] += t1 + FacetConst<D>::mass * (sw + w[mm]);
     }
 }
 
 template <int D, int NS, bool DIAG>
 __device__ __forceinline__ void knp_cell(const MeshDev& m, const CellGeom<D>& K, const int* nb, uint32_t flags,
-                                         const double (*xv)[D + 1], const double* sv, const double* Dk,
-                                         const double* __restrict__ x, const double* __restrict__ dnphi,
-                                         const double* __restrict__ Dall, int64_t c, const KnpArgs& ka,
-                                         double (*y)[D + 1]) {
+                                         const double (*xv)[D + 1], const double* gp, const double* Dk, double hK,
+                                         const double* __restrict__ x, const double* __restrict__ gphi,
+                                         const double* __restrict__ Dall, const KnpArgs& ka, double (*y)[D + 1]) {
     constexpr int NV = D + 1;
-    // grad(phi).grad(lambda_a) = -|g_a| * (grad(phi).n_a)
-    double gphi[NV];
-#pragma unroll
-    for (int a = 0; a < NV; ++a) gphi[a] = -sqrt(dotD<D>(K.g[a], K.g[a])) * sv[a];
     const double mw = ka.inv_dt * K.vol / (double)((D + 1) * (D + 2));
 #pragma unroll
     for (int k = 0; k < NS; ++k) {
-        double gu[D], sx = 0.0;
-#pragma unroll
-        for (int kk = 0; kk < D; ++kk) {
-            gu[kk] = 0.0;
-#pragma unroll
-            for (int a = 0; a < NV; ++a) gu[kk] += xv[k][a] * K.g[a][kk];
-        }
+        double sx = 0.0;
 #pragma unroll
         for (int a = 0; a < NV; ++a) sx += xv[k][a];
         const double drift = ka.z[k] * ka.psi * Dk[k] * K.vol * sx / (double)NV;
+        const double dv = Dk[k] * K.vol;
 #pragma unroll
-        for (int a = 0; a < NV; ++a)
-            y[k][a] = mw * (sx + xv[k][a]) + Dk[k] * K.vol * dotD<D>(gu, K.g[a]) + drift * gphi[a];
+        for (int a = 0; a < NV; ++a) {
+            double s = 0.0;
+#pragma unroll
+            for (int b = 0; b < NV; ++b) s = fma(K.G[a][b], xv[k][b], s);
+            y[k][a] = fma(mw, sx + xv[k][a], fma(dv, s, drift * gp[a]));
+        }
     }
-    knp_facet<D, NS, 0, DIAG>(m, K, nb, flags, xv, sv, Dk, x, dnphi, Dall, c, ka, y);
-    knp_facet<D, NS, 1, DIAG>(m, K, nb, flags, xv, sv, Dk, x, dnphi, Dall, c, ka, y);
-    knp_facet<D, NS, 2, DIAG>(m, K, nb, flags, xv, sv, Dk, x, dnphi, Dall, c, ka, y);
-    if (D == 3) knp_facet<D, NS, (D == 3 ? 3 : 0), DIAG>(m, K, nb, flags, xv, sv, Dk, x, dnphi, Dall, c, ka, y);
+    knp_facet<D, NS, 0, DIAG>(m, K, nb, flags, xv, gp, Dk, hK, x, gphi, Dall, ka, y);
+    knp_facet<D, NS, 1, DIAG>(m, K, nb, flags, xv, gp, Dk, hK, x, gphi, Dall, ka, y);
+    knp_facet<D, NS, 2, DIAG>(m, K, nb, flags, xv, gp, Dk, hK, x, gphi, Dall, ka, y);
+    if (D == 3) knp_facet<D, NS, (D == 3 ? 3 : 0), DIAG>(m, K, nb, flags, xv, gp, Dk, hK, x, gphi, Dall, ka, y);
 }
 
 template <int D, int NS>
 __global__ __launch_bounds__(KNP_BLOCK) void k_knp_apply(MeshDev m, const double* __restrict__ x,
-                                                         const double* __restrict__ dnphi,
+                                                         const double* __restrict__ gphi,
                                                          const double* __restrict__ Dall, double* __restrict__ yout,
                                                          KnpArgs ka) {
     constexpr int NV = D + 1;
@@ -325,23 +332,24 @@ __global__ __launch_bounds__(KNP_BLOCK) void k_knp_apply(MeshDev m, const double
     load_cell_ints<D>(m.cells, c, verts);
     load_cell_ints<D>(m.nbr, c, nb);
     const uint32_t flags = m.fflag[c];
-    CellGeom<D> K;
-    load_cell_geometry<D>(m, verts, K);
-    double xv[NS][NV], y[NS][NV], sv[NV], Dk[NS];
-    load_nodal<D>(dnphi, c, sv);
+    double xv[NS][NV], y[NS][NV], gp[NV], Dk[NS];
+    load_nodal<D>(gphi, c, gp);
 #pragma unroll
     for (int k = 0; k < NS; ++k) {
         load_nodal<D>(x + (int64_t)k * m.nc * NV, c, xv[k]);
         Dk[k] = Dall[(int64_t)k * m.nc + c];
     }
-    knp_cell<D, NS, false>(m, K, nb, flags, xv, sv, Dk, x, dnphi, Dall, c, ka, y);
+    const double hK = m.h[c];
+    CellGeom<D> K;
+    load_cell_geometry<D>(m, verts, K);
+    knp_cell<D, NS, false>(m, K, nb, flags, xv, gp, Dk, hK, x, gphi, Dall, ka, y);
 #pragma unroll
     for (int k = 0; k < NS; ++k) store_nodal<D>(yout + (int64_t)k * m.nc * NV, c, y[k]);
 }
 
 // one species per launch dimension (setup only, once per KNP solve)
 template <int D>
-__global__ __launch_bounds__(KNP_BLOCK) void k_knp_blockjacobi(MeshDev m, const double* __restrict__ dnphi,
+__global__ __launch_bounds__(KNP_BLOCK) void k_knp_blockjacobi(MeshDev m, const double* __restrict__ gphi,
                                                                const double* __restrict__ Dall,
                                                                double* __restrict__ binv, KnpArgs ka) {
     constexpr int NV = D + 1;
@@ -354,9 +362,10 @@ __global__ __launch_bounds__(KNP_BLOCK) void k_knp_blockjacobi(MeshDev m, const 
     const uint32_t flags = m.fflag[c];
     CellGeom<D> K;
     load_cell_geometry<D>(m, verts, K);
-    double sv[NV], Dk[1];
-    load_nodal<D>(dnphi, c, sv);
+    double gp[NV], Dk[1];
+    load_nodal<D>(gphi, c, gp);
     Dk[0] = Dall[(int64_t)k * m.nc + c];
+    const double hK = m.h[c];
     KnpArgs k1 = ka;
     k1.z[0] = ka.z[k];
     double A[NV][NV];
@@ -365,7 +374,7 @@ __global__ __launch_bounds__(KNP_BLOCK) void k_knp_blockjacobi(MeshDev m, const 
         double e[1][NV], col[1][NV];
 #pragma unroll
         for (int a = 0; a < NV; ++a) e[0][a] = (a == b) ? 1.0 : 0.0;
-        knp_cell<D, 1, true>(m, K, nb, flags, e, sv, Dk, nullptr, dnphi, Dall + (int64_t)k * m.nc, c, k1, col);
+        knp_cell<D, 1, true>(m, K, nb, flags, e, gp, Dk, hK, nullptr, gphi, Dall + (int64_t)k * m.nc, k1, col);
 #pragma unroll
         for (int a = 0; a < NV; ++a) A[a][b] = col[0][a];
     }
@@ -377,9 +386,9 @@ __global__ __launch_bounds__(KNP_BLOCK) void k_knp_blockjacobi(MeshDev m, const 
         for (int b = 0; b < NV; ++b) out[a * NV + b] = A[a][b];
 }
 
-// dnphi[c][i] = grad(phi)_c . n_i
+// gphi[c][a] = grad(phi)_c . grad(lambda_a) = sum_b phi_b G_ab
 template <int D>
-__global__ __launch_bounds__(KNP_BLOCK) void k_dnphi(MeshDev m, const double* __restrict__ phi, double* __restrict__ out) {
+__global__ __launch_bounds__(KNP_BLOCK) void k_gphi(MeshDev m, const double* __restrict__ phi, double* __restrict__ out) {
     constexpr int NV = D + 1;
     const int64_t c = (int64_t)blockIdx.x * KNP_BLOCK + threadIdx.x;
     if (c >= m.nc) return;
@@ -387,16 +396,15 @@ __global__ __launch_bounds__(KNP_BLOCK) void k_dnphi(MeshDev m, const double* __
     load_cell_ints<D>(m.cells, c, verts);
     CellGeom<D> K;
     load_cell_geometry<D>(m, verts, K);
-    double pv[NV], gp[D], s[NV];
+    double pv[NV], s[NV];
     load_nodal<D>(phi, c, pv);
 #pragma unroll
-    for (int k = 0; k < D; ++k) {
-        gp[k] = 0.0;
+    for (int a = 0; a < NV; ++a) {
+        double t = 0.0;
 #pragma unroll
-        for (int a = 0; a < NV; ++a) gp[k] += pv[a] * K.g[a][k];
+        for (int b = 0; b < NV; ++b) t = fma(K.G[a][b], pv[b], t);
+        s[a] = t;
     }
-#pragma unroll
-    for (int a = 0; a < NV; ++a) s[a] = -dotD<D>(gp, K.g[a]) / sqrt(dotD<D>(K.g[a], K.g[a]));
     store_nodal<D>(out, c, s);
 }
 
@@ -427,23 +435,23 @@ static KnpArgs make_knp_args(knp_ctx* c) {
     return ka;
 }
 
-template <int D> static int knp_apply_dispatch(knp_ctx* c, const double* x, const double* dnphi, double* y) {
+template <int D> static int knp_apply_dispatch(knp_ctx* c, const double* x, const double* gphi, double* y) {
     const dim3 g((unsigned)grid8(c->m.nc_owned)), b(KNP_BLOCK);
     const KnpArgs ka = make_knp_args(c);
     switch (c->p.n_sys) {
-        case 1: hipLaunchKernelGGL((k_knp_apply<D, 1>), g, b, 0, c->stream, c->m, x, dnphi, c->D, y, ka); break;
-        case 2: hipLaunchKernelGGL((k_knp_apply<D, 2>), g, b, 0, c->stream, c->m, x, dnphi, c->D, y, ka); break;
-        case 3: hipLaunchKernelGGL((k_knp_apply<D, 3>), g, b, 0, c->stream, c->m, x, dnphi, c->D, y, ka); break;
-        case 4: hipLaunchKernelGGL((k_knp_apply<D, 4>), g, b, 0, c->stream, c->m, x, dnphi, c->D, y, ka); break;
+        case 1: hipLaunchKernelGGL((k_knp_apply<D, 1>), g, b, 0, c->stream, c->m, x, gphi, c->D, y, ka); break;
+        case 2: hipLaunchKernelGGL((k_knp_apply<D, 2>), g, b, 0, c->stream, c->m, x, gphi, c->D, y, ka); break;
+        case 3: hipLaunchKernelGGL((k_knp_apply<D, 3>), g, b, 0, c->stream, c->m, x, gphi, c->D, y, ka); break;
+        case 4: hipLaunchKernelGGL((k_knp_apply<D, 4>), g, b, 0, c->stream, c->m, x, gphi, c->D, y, ka); break;
         default: c->err = "knp_apply supports 1..4 solved species"; return -1;
     }
     HIPCHK(c, hipGetLastError());
     return 0;
 }
 
-int launch_knp_apply(knp_ctx* c, const double* x, const double* dnphi, double* y) {
+int launch_knp_apply(knp_ctx* c, const double* x, const double* gphi, double* y) {
     if (c->degree != 1) { c->err = "P1 kernels only"; return -1; }
-    return c->m.dim == 3 ? knp_apply_dispatch<3>(c, x, dnphi, y) : knp_apply_dispatch<2>(c, x, dnphi, y);
+    return c->m.dim == 3 ? knp_apply_dispatch<3>(c, x, gphi, y) : knp_apply_dispatch<2>(c, x, gphi, y);
 }
 
 int launch_emi_blockjacobi(knp_ctx* c, const double* kappa, double* binv) {
@@ -457,23 +465,23 @@ int launch_emi_blockjacobi(knp_ctx* c, const double* kappa, double* binv) {
     return 0;
 }
 
-int launch_knp_blockjacobi(knp_ctx* c, const double* dnphi, double* binv) {
+int launch_knp_blockjacobi(knp_ctx* c, const double* gphi, double* binv) {
     const dim3 g((unsigned)grid_for(c->m.nc_owned), (unsigned)c->p.n_sys), b(KNP_BLOCK);
     const KnpArgs ka = make_knp_args(c);
     if (c->m.dim == 3)
-        hipLaunchKernelGGL(k_knp_blockjacobi<3>, g, b, 0, c->stream, c->m, dnphi, c->D, binv, ka);
+        hipLaunchKernelGGL(k_knp_blockjacobi<3>, g, b, 0, c->stream, c->m, gphi, c->D, binv, ka);
     else
-        hipLaunchKernelGGL(k_knp_blockjacobi<2>, g, b, 0, c->stream, c->m, dnphi, c->D, binv, ka);
+        hipLaunchKernelGGL(k_knp_blockjacobi<2>, g, b, 0, c->stream, c->m, gphi, c->D, binv, ka);
     HIPCHK(c, hipGetLastError());
     return 0;
 }
 
-int launch_dnphi(knp_ctx* c, const double* phi, double* dnphi) {
+int launch_dnphi(knp_ctx* c, const double* phi, double* gphi) {
     const dim3 g((unsigned)grid_for(c->m.nc)), b(KNP_BLOCK);
     if (c->m.dim == 3)
-        hipLaunchKernelGGL(k_dnphi<3>, g, b, 0, c->stream, c->m, phi, dnphi);
+        hipLaunchKernelGGL(k_gphi<3>, g, b, 0, c->stream, c->m, phi, gphi);
     else
-        hipLaunchKernelGGL(k_dnphi<2>, g, b, 0, c->stream, c->m, phi, dnphi);
+        hipLaunchKernelGGL(k_gphi<2>, g, b, 0, c->stream, c->m, phi, gphi);
     HIPCHK(c, hipGetLastError());
     return 0;
 }

@@ -1,20 +1,50 @@
-// Per-thread affine geometry of one P1 simplex cell and of the neighbour across one facet,
-// recomputed from vertex coordinates on every operator apply (coordinates stay cache
-// resident: 4.2 MB at 10^6 tets) instead of streaming ~130 B/cell of stored Jacobians.
+// Per-thread affine geometry of one P1 simplex cell in "Gram form".
 //
-// Conventions shared with the host tables (knpemidg/tables.py) and the oracle:
+// Everything the SIPG forms need from the geometry of a cell K and of the neighbour K' behind
+// facet i is expressed through
+//   g_a = grad lambda_a (own cell),  G_ab = g_a . g_b,  vol,
+//   L_a = lambda_a(X_o)   (own barycentric coordinates of the NEIGHBOUR's apex vertex X_o; L_i < 0),
+// because on all of space  lambda'_apex = lambda_i / L_i  and  lambda'_b = lambda_b - L_b lambda'_apex:
+//   grad u' . g_i = sum_m x'_m (G_{a_m i} - L_{a_m} G_ii / L_i) + x'_apex G_ii / L_i,
+//   vol' = -L_i vol,   area_i = sqrt(G_ii) D vol,   area_i * (grad w . n_i) = -D vol (grad w . g_i).
+// So no normal vector, height or foot point is ever formed, and only the penalty / membrane terms
+// need one square root per facet.  Geometry is recomputed from vertex coordinates every launch
+// (coordinates stay cache resident: 5.6 MB at 10^6 tets) instead of streaming >= 96 B/cell of Jacobians.
+//
+// Conventions shared with the host tables and the oracle:
 //  * cells hold ascending vertex ids, local facet i is opposite local vertex i;
 //  * facet vertex m (m = 0..D-1) is the cell's local vertex  m + (m >= i);
 //    for the neighbour (whose local facet index is j) it is  m + (m >= j).
 #pragma once
 #include "knpemi_internal.hpp"
 
+// ---- fast reciprocal / square root (hardware seed + 2 Newton steps; operands are normal, positive
+//      or negative, never 0/inf/nan on valid meshes) ------------------------------------------------
+__device__ __forceinline__ double fast_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
+__device__ __forceinline__ double fast_sqrt(double x) {
+    double r = __builtin_amdgcn_rsq(x);
+    double g = x * r, h = 0.5 * r;
+    double e = fma(-h, g, 0.5);
+    g = fma(g, e, g);
+    h = fma(h, e, h);
+    e = fma(-h, g, 0.5);
+    g = fma(g, e, g);
+    h = fma(h, e, h);
+    g = fma(fma(-g, g, x), h, g);
+    return g;
+}
+
 template <int D> struct CellGeom {
     static constexpr int NV = D + 1;
-    double X[NV][D];   // vertex coordinates
+    double X0[D];      // coordinates of local vertex 0
     double g[NV][D];   // grad lambda_a
+    double G[NV][NV];  // Gram matrix (symmetric, both triangles filled)
     double vol;
-    double h2;         // squared cell diameter (longest edge)
 };
 
 template <int D> __device__ __forceinline__ void load_vertex(const double* __restrict__ coords, int v, double* out);
@@ -31,7 +61,7 @@ template <> __device__ __forceinline__ void load_vertex<2>(const double* __restr
 template <int D> __device__ __forceinline__ double dotD(const double* a, const double* b) {
     double s = a[0] * b[0];
 #pragma unroll
-    for (int k = 1; k < D; ++k) s += a[k] * b[k];
+    for (int k = 1; k < D; ++k) s = fma(a[k], b[k], s);
     return s;
 }
 
@@ -62,22 +92,23 @@ template <> __device__ __forceinline__ void load_cell_ints<2>(const int32_t* __r
     v[0] = p[3 * c]; v[1] = p[3 * c + 1]; v[2] = p[3 * c + 2];
 }
 
-// gradients, volume, diameter from the vertex coordinates already in K.X
-template <int D> __device__ __forceinline__ void cell_geometry(CellGeom<D>& K);
+// gradients + volume from vertex coordinates X[a][:]
+template <int D> __device__ __forceinline__ void gradients(const double (*X)[D], CellGeom<D>& K);
 
-template <> __device__ __forceinline__ void cell_geometry<3>(CellGeom<3>& K) {
+template <> __device__ __forceinline__ void gradients<3>(const double (*X)[3], CellGeom<3>& K) {
     double e1[3], e2[3], e3[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        e1[k] = K.X[1][k] - K.X[0][k];
-        e2[k] = K.X[2][k] - K.X[0][k];
-        e3[k] = K.X[3][k] - K.X[0][k];
+        e1[k] = X[1][k] - X[0][k];
+        e2[k] = X[2][k] - X[0][k];
+        e3[k] = X[3][k] - X[0][k];
+        K.X0[k] = X[0][k];
     }
-    double c23[3] = {e2[1] * e3[2] - e2[2] * e3[1], e2[2] * e3[0] - e2[0] * e3[2], e2[0] * e3[1] - e2[1] * e3[0]};
-    double c31[3] = {e3[1] * e1[2] - e3[2] * e1[1], e3[2] * e1[0] - e3[0] * e1[2], e3[0] * e1[1] - e3[1] * e1[0]};
-    double c12[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+    const double c23[3] = {e2[1] * e3[2] - e2[2] * e3[1], e2[2] * e3[0] - e2[0] * e3[2], e2[0] * e3[1] - e2[1] * e3[0]};
+    const double c31[3] = {e3[1] * e1[2] - e3[2] * e1[1], e3[2] * e1[0] - e3[0] * e1[2], e3[0] * e1[1] - e3[1] * e1[0]};
+    const double c12[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
     const double det = e1[0] * c23[0] + e1[1] * c23[1] + e1[2] * c23[2];
-    const double inv = 1.0 / det;
+    const double inv = fast_rcp(det);
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         K.g[1][k] = c23[k] * inv;
@@ -86,101 +117,59 @@ template <> __device__ __forceinline__ void cell_geometry<3>(CellGeom<3>& K) {
         K.g[0][k] = -(K.g[1][k] + K.g[2][k] + K.g[3][k]);
     }
     K.vol = fabs(det) * (1.0 / 6.0);
-    double e23[3], e13[3], e12[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        e12[k] = K.X[2][k] - K.X[1][k];
-        e13[k] = K.X[3][k] - K.X[1][k];
-        e23[k] = K.X[3][k] - K.X[2][k];
-    }
-    double h2 = fmax(dotD<3>(e1, e1), dotD<3>(e2, e2));
-    h2 = fmax(h2, dotD<3>(e3, e3));
-    h2 = fmax(h2, dotD<3>(e12, e12));
-    h2 = fmax(h2, dotD<3>(e13, e13));
-    h2 = fmax(h2, dotD<3>(e23, e23));
-    K.h2 = h2;
 }
 
-template <> __device__ __forceinline__ void cell_geometry<2>(CellGeom<2>& K) {
-    double e1[2] = {K.X[1][0] - K.X[0][0], K.X[1][1] - K.X[0][1]};
-    double e2[2] = {K.X[2][0] - K.X[0][0], K.X[2][1] - K.X[0][1]};
+template <> __device__ __forceinline__ void gradients<2>(const double (*X)[2], CellGeom<2>& K) {
+    const double e1[2] = {X[1][0] - X[0][0], X[1][1] - X[0][1]};
+    const double e2[2] = {X[2][0] - X[0][0], X[2][1] - X[0][1]};
+    K.X0[0] = X[0][0]; K.X0[1] = X[0][1];
     const double det = e1[0] * e2[1] - e1[1] * e2[0];
-    const double inv = 1.0 / det;
+    const double inv = fast_rcp(det);
     K.g[1][0] = e2[1] * inv;  K.g[1][1] = -e2[0] * inv;
     K.g[2][0] = -e1[1] * inv; K.g[2][1] = e1[0] * inv;
     K.g[0][0] = -(K.g[1][0] + K.g[2][0]);
     K.g[0][1] = -(K.g[1][1] + K.g[2][1]);
     K.vol = fabs(det) * 0.5;
-    double e12[2] = {K.X[2][0] - K.X[1][0], K.X[2][1] - K.X[1][1]};
-    K.h2 = fmax(fmax(dotD<2>(e1, e1), dotD<2>(e2, e2)), dotD<2>(e12, e12));
 }
 
 template <int D> __device__ __forceinline__ void load_cell_geometry(const MeshDev& m, const int* verts, CellGeom<D>& K) {
+    double X[D + 1][D];
 #pragma unroll
-    for (int a = 0; a <= D; ++a) load_vertex<D>(m.coords, verts[a], K.X[a]);
-    cell_geometry<D>(K);
-}
-
-// Geometry of facet i of cell K and of the neighbour cell behind it.
-template <int D> struct FacetGeom {
-    double n[D];        // unit normal, outward from K
-    double area;
-    double dn[D + 1];   // grad lambda_a . n  for the own cell
-    double hp;          // height of the neighbour's apex above the facet
-    double beta[D];     // barycentric coordinates (facet vertices) of the apex's foot point
-    double hN2;         // squared diameter of the neighbour
-};
-
-// own part (no neighbour needed)
-template <int D, int I> __device__ __forceinline__ void facet_own(const CellGeom<D>& K, FacetGeom<D>& F) {
-    const double gi2 = dotD<D>(K.g[I], K.g[I]);
-    const double gin = sqrt(gi2);
-    const double rin = 1.0 / gin;
-    F.area = gin * (double)D * K.vol;
+    for (int a = 0; a <= D; ++a) load_vertex<D>(m.coords, verts[a], X[a]);
+    gradients<D>(X, K);
 #pragma unroll
-    for (int k = 0; k < D; ++k) F.n[k] = -K.g[I][k] * rin;
+    for (int a = 0; a <= D; ++a)
 #pragma unroll
-    for (int a = 0; a <= D; ++a) F.dn[a] = dotD<D>(K.g[a], F.n);
-}
-
-// neighbour part from its apex vertex Xo
-template <int D, int I> __device__ __forceinline__ void facet_neighbour(const CellGeom<D>& K, const double* Xo, FacetGeom<D>& F) {
-    constexpr int a0 = (0 >= I) ? 1 : 0;
-    double d0[D];
-#pragma unroll
-    for (int k = 0; k < D; ++k) d0[k] = Xo[k] - K.X[a0][k];
-    F.hp = dotD<D>(d0, F.n);
-    double hN2 = 0.0;
-#pragma unroll
-    for (int mm = 0; mm < D; ++mm) {
-        const int a = mm + (mm >= I);
-        double dv[D];
-#pragma unroll
-        for (int k = 0; k < D; ++k) dv[k] = Xo[k] - K.X[a][k];
-        hN2 = fmax(hN2, dotD<D>(dv, dv));
-        F.beta[mm] = 1.0 + dotD<D>(K.g[a], dv) - F.hp * F.dn[a];
-        // facet edges belong to the neighbour too
-#pragma unroll
-        for (int m2 = mm + 1; m2 < D; ++m2) {
-            const int b = m2 + (m2 >= I);
-            double ev[D];
-#pragma unroll
-            for (int k = 0; k < D; ++k) ev[k] = K.X[b][k] - K.X[a][k];
-            hN2 = fmax(hN2, dotD<D>(ev, ev));
+        for (int b = a; b <= D; ++b) {
+            const double v = dotD<D>(K.g[a], K.g[b]);
+            K.G[a][b] = v;
+            K.G[b][a] = v;
         }
-    }
-    F.hN2 = hN2;
 }
 
-// pick entry (m + (m >= j)) of a (D+1)-vector held in registers, j is a runtime value
+// L_a = lambda_a(Xo) for all own vertices a
+template <int D> __device__ __forceinline__ void apex_bary(const CellGeom<D>& K, const double* Xo, double* L) {
+    double dv[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) dv[k] = Xo[k] - K.X0[k];
+#pragma unroll
+    for (int a = 0; a <= D; ++a) L[a] = dotD<D>(K.g[a], dv) + (a == 0 ? 1.0 : 0.0);
+}
+
+// pick entry (m + (m >= j)) of a (D+1)-vector held in registers; j is a runtime 2-bit value.
+// Written as explicit selects so that the compiler keeps the vector in registers.
 template <int D> __device__ __forceinline__ double pick_facet(const double* v, int mm, int j) {
     return (mm >= j) ? v[mm + 1] : v[mm];
 }
-template <int D> __device__ __forceinline__ double pick_apex(const double* v, int j) {
-    double r = v[0];
-#pragma unroll
-    for (int a = 1; a <= D; ++a) r = (j == a) ? v[a] : r;
-    return r;
+template <int D> __device__ __forceinline__ double pick_apex(const double* v, int j);
+template <> __device__ __forceinline__ double pick_apex<3>(const double* v, int j) {
+    const double lo = (j & 1) ? v[1] : v[0];
+    const double hi = (j & 1) ? v[3] : v[2];
+    return (j & 2) ? hi : lo;
+}
+template <> __device__ __forceinline__ double pick_apex<2>(const double* v, int j) {
+    const double lo = (j & 1) ? v[1] : v[0];
+    return (j & 2) ? v[2] : lo;
 }
 
 // XCD-aware block remap: blocks b, b+8, b+16.. share an XCD (round-robin dispatch), so give

@@ -22,6 +22,7 @@ struct MeshDev {
     int64_t nv = 0, nc = 0, nc_owned = 0, nf = 0, nmf = 0;
     double* coords = nullptr;      // [nv][4] in 3D (padded), [nv][2] in 2D
     int32_t* cells = nullptr;      // [nc][dim+1]
+    double* h = nullptr;           // [nc] cell diameters (UFL CellDiameter: longest edge)
     int32_t* nbr = nullptr;        // [nc][dim+1]
     uint32_t* fflag = nullptr;     // [nc] packed 4 x u8 flag bytes
     int32_t* cfacet = nullptr;     // [nc][dim+1] global facet ids

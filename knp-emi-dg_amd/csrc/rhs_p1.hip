@@ -88,8 +88,6 @@ __device__ __forceinline__ void emi_rhs_facet(const MeshDev& m, const CellGeom<D
     if (kind >= FK_EXTERIOR) return;
     const int j = (int)(fb & 3u);
     const int64_t Kp = nb[I];
-    FacetGeom<D> Fg;
-    facet_own<D, I>(K, Fg);
     if (kind == FK_MEMBRANE) {
         const int64_t f = m.cfacet[c * NV + I];
         double g = phiM[f];
@@ -99,29 +97,35 @@ __device__ __forceinline__ void emi_rhs_facet(const MeshDev& m, const CellGeom<D
             g -= It / C_phi;
         }
         const double sgn = ((fb >> 4) & 1u) ? -1.0 : 1.0;           // JUMP(v) = v_i - v_e
-        const double w = sgn * C_phi * g * Fg.area / (double)D;
+        const double w = sgn * C_phi * g * fast_sqrt(K.G[I][I]) * K.vol;   // area / D = sqrt(G_ii) vol
 #pragma unroll
         for (int mm = 0; mm < D; ++mm) b[mm + (mm >= I)] += w;
         return;
     }
-    double Xo[D];
+    double Xo[D], L[NV];
     load_vertex<D>(m.coords, m.cells[Kp * NV + j], Xo);
-    facet_neighbour<D, I>(K, Xo, Fg);
+    apex_bary<D>(K, Xo, L);
+    const double rLi = fast_rcp(L[I]);
+    const double gr = K.G[I][I] * rLi;
     double flux = 0.0;
     for (int i = 0; i < ia.n; ++i) {
         const double* src = (i < ia.n - 1) ? cc + (int64_t)i * m.nc * NV : celim;
         double cv[NV], cn[NV];
         load_nodal<D>(src, c, cv);
         load_nodal<D>(src, Kp, cn);
-        double dn_own = 0.0, foot = 0.0;
+        double s_own = 0.0;
 #pragma unroll
-        for (int a = 0; a < NV; ++a) dn_own += cv[a] * Fg.dn[a];
+        for (int a = 0; a < NV; ++a) s_own = fma(cv[a], K.G[a][I], s_own);
+        double s_nb = pick_apex<D>(cn, j) * gr;
 #pragma unroll
-        for (int mm = 0; mm < D; ++mm) foot += Fg.beta[mm] * pick_facet<D>(cn, mm, j);
-        const double dn_nb = (pick_apex<D>(cn, j) - foot) / Fg.hp;
-        flux += F * ia.z[i] * 0.5 * (Dall[(int64_t)i * m.nc + c] * dn_own + Dall[(int64_t)i * m.nc + Kp] * dn_nb);
+        for (int mm = 0; mm < D; ++mm) {
+            const int a = mm + (mm >= I);
+            s_nb = fma(pick_facet<D>(cn, mm, j), fma(-L[a], gr, K.G[a][I]), s_nb);
+        }
+        flux += F * ia.z[i] * 0.5 * (Dall[(int64_t)i * m.nc + c] * s_own + Dall[(int64_t)i * m.nc + Kp] * s_nb);
     }
-    const double w = flux * Fg.area / (double)D;
+    // area/D * (grad c . n) = -vol (grad c . g_i)
+    const double w = -flux * K.vol;
 #pragma unroll
     for (int mm = 0; mm < D; ++mm) b[mm + (mm >= I)] += w;
 }
@@ -185,8 +189,7 @@ __device__ __forceinline__ void knp_rhs_facet(const MeshDev& m, const CellGeom<D
     const int j = (int)(fb & 3u);
     const int64_t Kp = nb[I];
     const bool is_e = (fb >> 4) & 1u;
-    FacetGeom<D> Fg;
-    facet_own<D, I>(K, Fg);
+    const double area = fast_sqrt(K.G[I][I]) * (double)D * K.vol;
     const int64_t f = m.cfacet[c * NV + I];
     const double pM = phiM[f];
     const double Ik = Ich[(int64_t)k * m.nf + f];
@@ -222,7 +225,7 @@ __device__ __forceinline__ void knp_rhs_facet(const MeshDev& m, const CellGeom<D
         double g = pM - ra.dt / (ra.C_M * alpha) * Ik;
         if (ra.splitting) g += (ra.dt / ra.C_M) * It;
         const double dphi = is_e ? (pb - po) : (po - pb);            // phi_i - phi_e
-        const double val = w * Fg.area * sgn * C * (g - dphi);
+        const double val = w * area * sgn * C * (g - dphi);
 #pragma unroll
         for (int mm = 0; mm < D; ++mm) b[mm + (mm >= I)] += val * mu[mm];
     }
