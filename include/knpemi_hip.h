@@ -47,7 +47,8 @@ enum knp_field {
  * Uploads the mesh and derives the per-(cell, local facet) neighbour / flag tables and the
  * membrane facet table.  Replaces Solver.setup_domain + interface_normal + subdomain_marking_foo
  * (solver.py:85-121, utils.py:44-85).
- *  cells        i32[nc][dim+1] ascending vertex ids; cells [0,nc_owned) are owned, the rest are ghosts
+ *  cells        i32[nc][dim+1] vertex ids, local order = ascending ids of the caller's mesh (ids may then be
+ *               relabelled for storage locality); cells [0,nc_owned) are owned, the rest are ghosts
  *  cell_tags    u32[nc]         subdomain tags (0 = ECS)
  *  facet_cells  i32[nf][2]      cells sharing each facet, -1 = none
  *  facet_local  i8 [nf][2]      local facet index within those cells

@@ -68,9 +68,9 @@ int knp_ctx_create(knp_ctx** out, int device, int dim, int degree, int n_ions, i
     // ---- host-side validation + derived tables ------------------------------------------------
     for (int64_t i = 0; i < nc * NV; ++i)
         if (cells[i] < 0 || cells[i] >= nv) { g_err = "cell vertex index out of range"; delete c; return -1; }
-    for (int64_t k = 0; k < nc; ++k)
-        for (int a = 1; a < NV; ++a)
-            if (cells[k * NV + a] <= cells[k * NV + a - 1]) { g_err = "cells must hold ascending vertex ids"; delete c; return -1; }
+    // NOTE: the facet matching relies on both cells of a facet listing the shared vertices in the same
+    // relative order (ascending ids in the caller's numbering); the ids themselves may be relabelled for
+    // storage locality, so they are not required to be ascending here.
     std::vector<int32_t> nbr(nc * NV, -1), cfacet(nc * NV, -1);
     std::vector<uint32_t> fflag(nc, 0);
     std::vector<uint8_t> fb(nc * NV, (uint8_t)(FK_EXTERIOR << 2));

@@ -9,6 +9,7 @@
 // geometry enters only through the own cell's Gram matrix and the neighbour apex's barycentric
 // coordinates (cell_geom.hpp).
 #include "cell_geom.hpp"
+#include <cstdlib>
 
 template <int D> struct FacetConst;
 template <> struct FacetConst<3> { static constexpr double mass = 1.0 / 12.0, trip = 1.0 / 60.0; };
@@ -33,23 +34,38 @@ __device__ __forceinline__ double nb_grad_dot(const CellGeom<D>& K, const double
 //          + int_dS0 tau/avg(h) avg(kappa) jump(u) jump(v) + C_phi int_dS(mem) jump(u) jump(v)
 // With s(w) = grad w . g_i:   area * (grad w . n_i) = -D vol s(w),   area = sqrt(G_ii) D vol.
 // ------------------------------------------------------------------------------------------
-template <int D, int I, bool DIAG>
+template <int D, int I, int MODE>
 __device__ __forceinline__ void emi_facet(const MeshDev& m, const CellGeom<D>& K, const int* nb, uint32_t flags,
                                           const double* xv, const double* kv, double hK,
                                           const double* __restrict__ x, const double* __restrict__ kappa,
-                                          double C_phi, double tau, double* y) {
+                                          double C_phi, double tau, const StageView<D>& st, double* y) {
     constexpr int NV = D + 1;
     const uint32_t fb = (flags >> (8 * I)) & 0xffu;
     const uint32_t kind = (fb >> 2) & 3u;
     if (kind >= FK_EXTERIOR) return;
     const int j = (int)(fb & 3u);
     const int64_t Kp = nb[I];
+    // Neighbour data: unconditional LDS read at a clamped slot + global load only for the lanes whose
+    // neighbour lives outside this workgroup (kept as two separate accesses so that the compiler emits
+    // ds_read + exec-masked global_load instead of a pointer select + flat_load).
+    const unsigned loc0 = (unsigned)(Kp - st.c0);
+    constexpr bool DIAG = (MODE == 1);
+    const bool in_block = (MODE == 2) && loc0 < st.nvalid;
+    const unsigned loc = in_block ? loc0 : 0u;
     double xn[NV];
     if (DIAG) {
 #pragma unroll
         for (int a = 0; a < NV; ++a) xn[a] = 0.0;
-    } else {
+    } else if (MODE == 0) {
         load_nodal<D>(x, Kp, xn);
+    } else {
+        double xl[NV], xg[NV];
+        lds_nodal<D>(st.x, loc, xl);
+#pragma unroll
+        for (int a = 0; a < NV; ++a) xg[a] = 0.0;
+        if (!in_block) load_nodal<D>(x, Kp, xg);
+#pragma unroll
+        for (int a = 0; a < NV; ++a) xn[a] = in_block ? xl[a] : xg[a];
     }
     double du[D], sdu = 0.0;
 #pragma unroll
@@ -64,10 +80,32 @@ __device__ __forceinline__ void emi_facet(const MeshDev& m, const CellGeom<D>& K
         for (int mm = 0; mm < D; ++mm) y[mm + (mm >= I)] = fma(w, sdu + du[mm], y[mm + (mm >= I)]);
         return;
     }
-    double kn[NV], Xo[D], L[NV];
-    load_nodal<D>(kappa, Kp, kn);
-    const double hN = m.h[Kp];
-    load_vertex<D>(m.coords, m.cells[Kp * NV + j], Xo);
+    double kn[NV], Xo[D], L[NV], hN;
+    if (MODE != 2) {
+        load_nodal<D>(kappa, Kp, kn);
+        hN = m.h[Kp];
+        load_vertex<D>(m.coords, m.cells[Kp * NV + j], Xo);
+    } else {
+        double kl[NV], kg[NV], Xl[D], Xg[D];
+        lds_nodal<D>(st.k, loc, kl);
+        const double hl = st.h[loc];
+        double hg = 0.0;
+        const lds_double* xa = st.X + (loc * NV + (in_block ? j : 0)) * D;
+#pragma unroll
+        for (int q = 0; q < D; ++q) { Xl[q] = xa[q]; Xg[q] = 0.0; }
+#pragma unroll
+        for (int a = 0; a < NV; ++a) kg[a] = 0.0;
+        if (!in_block) {
+            load_nodal<D>(kappa, Kp, kg);
+            hg = m.h[Kp];
+            load_vertex<D>(m.coords, m.cells[Kp * NV + j], Xg);
+        }
+#pragma unroll
+        for (int a = 0; a < NV; ++a) kn[a] = in_block ? kl[a] : kg[a];
+#pragma unroll
+        for (int q = 0; q < D; ++q) Xo[q] = in_block ? Xl[q] : Xg[q];
+        hN = in_block ? hl : hg;
+    }
     apex_bary<D>(K, Xo, L);
     const double rLi = fast_rcp(L[I]);
     // s = grad u . g_i on both sides
@@ -108,11 +146,11 @@ __device__ __forceinline__ void emi_facet(const MeshDev& m, const CellGeom<D>& K
     }
 }
 
-template <int D, bool DIAG>
+template <int D, int MODE>
 __device__ __forceinline__ void emi_cell(const MeshDev& m, const CellGeom<D>& K, const int* nb, uint32_t flags,
                                          const double* xv, const double* kv, double hK,
                                          const double* __restrict__ x, const double* __restrict__ kappa,
-                                         double C_phi, double tau, double* y) {
+                                         double C_phi, double tau, const StageView<D>& st, double* y) {
     constexpr int NV = D + 1;
     double kbar = 0.0;
 #pragma unroll
@@ -125,16 +163,63 @@ __device__ __forceinline__ void emi_cell(const MeshDev& m, const CellGeom<D>& K,
         for (int b = 0; b < NV; ++b) s = fma(K.G[a][b], xv[b], s);
         y[a] = kbar * s;
     }
-    emi_facet<D, 0, DIAG>(m, K, nb, flags, xv, kv, hK, x, kappa, C_phi, tau, y);
-    emi_facet<D, 1, DIAG>(m, K, nb, flags, xv, kv, hK, x, kappa, C_phi, tau, y);
-    emi_facet<D, 2, DIAG>(m, K, nb, flags, xv, kv, hK, x, kappa, C_phi, tau, y);
-    if (D == 3) emi_facet<D, (D == 3 ? 3 : 0), DIAG>(m, K, nb, flags, xv, kv, hK, x, kappa, C_phi, tau, y);
+    emi_facet<D, 0, MODE>(m, K, nb, flags, xv, kv, hK, x, kappa, C_phi, tau, st, y);
+    emi_facet<D, 1, MODE>(m, K, nb, flags, xv, kv, hK, x, kappa, C_phi, tau, st, y);
+    emi_facet<D, 2, MODE>(m, K, nb, flags, xv, kv, hK, x, kappa, C_phi, tau, st, y);
+    if (D == 3) emi_facet<D, (D == 3 ? 3 : 0), MODE>(m, K, nb, flags, xv, kv, hK, x, kappa, C_phi, tau, st, y);
 }
 
+#define EMI_BLOCK 384   // 6 wavefronts; = one 4x4x4-box Morton brick of a BoxMesh (6 tets per box)
+
 template <int D>
-__global__ __launch_bounds__(KNP_BLOCK) void k_emi_apply(MeshDev m, const double* __restrict__ x,
+__global__ __launch_bounds__(EMI_BLOCK) void k_emi_apply_staged(MeshDev m, const double* __restrict__ x,
                                                          const double* __restrict__ kappa, double* __restrict__ y,
                                                          double C_phi, double tau) {
+    constexpr int NV = D + 1;
+    __shared__ __attribute__((aligned(16))) double s_x[EMI_BLOCK * NV];
+    __shared__ __attribute__((aligned(16))) double s_k[EMI_BLOCK * NV];
+    __shared__ double s_h[EMI_BLOCK];
+    __shared__ double s_X[EMI_BLOCK * NV * D];
+    const int64_t c0 = xcd_block(blockIdx.x, gridDim.x) * EMI_BLOCK;
+    if (c0 >= m.nc_owned) return;
+    const int64_t c = c0 + threadIdx.x;
+    const bool valid = c < m.nc_owned;
+    int verts[NV], nb[NV];
+    uint32_t flags = 0;
+    double xv[NV], kv[NV], yv[NV], hK = 0.0, X[NV][D];
+    if (valid) {
+        load_cell_ints<D>(m.cells, c, verts);
+        load_cell_ints<D>(m.nbr, c, nb);
+        flags = m.fflag[c];
+        load_nodal<D>(x, c, xv);
+        load_nodal<D>(kappa, c, kv);
+        hK = m.h[c];
+#pragma unroll
+        for (int a = 0; a < NV; ++a) load_vertex<D>(m.coords, verts[a], X[a]);
+        const unsigned t = threadIdx.x;
+#pragma unroll
+        for (int a = 0; a < NV; ++a) {
+            s_x[t * NV + a] = xv[a];
+            s_k[t * NV + a] = kv[a];
+#pragma unroll
+            for (int q = 0; q < D; ++q) s_X[(t * NV + a) * D + q] = X[a][q];
+        }
+        s_h[t] = hK;
+    }
+    __syncthreads();
+    if (!valid) return;
+    StageView<D> st{TO_LDS(s_x), TO_LDS(s_k), TO_LDS(s_h), TO_LDS(s_X), c0, (unsigned)((m.nc_owned - c0 < EMI_BLOCK) ? (m.nc_owned - c0) : EMI_BLOCK)};
+    CellGeom<D> K;
+    cell_geometry_from<D>(X, K);
+    emi_cell<D, 2>(m, K, nb, flags, xv, kv, hK, x, kappa, C_phi, tau, st, yv);
+    store_nodal<D>(y, c, yv);
+}
+
+// direct variant: every neighbour access is a global (L1/L2) gather
+template <int D, int WPE>
+__global__ __launch_bounds__(KNP_BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
+void k_emi_apply(MeshDev m, const double* __restrict__ x, const double* __restrict__ kappa, double* __restrict__ y,
+                 double C_phi, double tau) {
     constexpr int NV = D + 1;
     const int64_t c = xcd_block(blockIdx.x, gridDim.x) * KNP_BLOCK + threadIdx.x;
     if (c >= m.nc_owned) return;
@@ -148,7 +233,7 @@ __global__ __launch_bounds__(KNP_BLOCK) void k_emi_apply(MeshDev m, const double
     const double hK = m.h[c];
     CellGeom<D> K;
     load_cell_geometry<D>(m, verts, K);
-    emi_cell<D, false>(m, K, nb, flags, xv, kv, hK, x, kappa, C_phi, tau, yv);
+    emi_cell<D, 0>(m, K, nb, flags, xv, kv, hK, x, kappa, C_phi, tau, StageView<D>{nullptr, nullptr, nullptr, nullptr, 0, 0u}, yv);
     store_nodal<D>(y, c, yv);
 }
 
@@ -195,7 +280,7 @@ __global__ __launch_bounds__(KNP_BLOCK) void k_emi_blockjacobi(MeshDev m, const 
         double e[NV], col[NV];
 #pragma unroll
         for (int a = 0; a < NV; ++a) e[a] = (a == b) ? 1.0 : 0.0;
-        emi_cell<D, true>(m, K, nb, flags, e, kv, hK, nullptr, kappa, C_phi, tau, col);
+        emi_cell<D, 1>(m, K, nb, flags, e, kv, hK, nullptr, kappa, C_phi, tau, StageView<D>{nullptr, nullptr, nullptr, nullptr, 0, 0u}, col);
 #pragma unroll
         for (int a = 0; a < NV; ++a) A[a][b] = col[a];
     }
@@ -416,11 +501,25 @@ static inline int64_t grid8(int64_t n) { return ((grid_for(n) + 7) / 8) * 8; }
 
 int launch_emi_apply(knp_ctx* c, const double* x, const double* kappa, double* y) {
     if (c->degree != 1) { c->err = "P1 kernels only"; return -1; }
-    const dim3 g((unsigned)grid8(c->m.nc_owned)), b(KNP_BLOCK);
-    if (c->m.dim == 3)
-        hipLaunchKernelGGL(k_emi_apply<3>, g, b, 0, c->stream, c->m, x, kappa, y, c->p.C_phi, c->p.tau_emi);
-    else
-        hipLaunchKernelGGL(k_emi_apply<2>, g, b, 0, c->stream, c->m, x, kappa, y, c->p.C_phi, c->p.tau_emi);
+    static const int variant = getenv("KNP_EMI_VARIANT") ? atoi(getenv("KNP_EMI_VARIANT")) : 1;
+    if (variant == 0) {
+        const int64_t nblk = (((c->m.nc_owned + EMI_BLOCK - 1) / EMI_BLOCK + 7) / 8) * 8;
+        const dim3 g((unsigned)nblk), b(EMI_BLOCK);
+        if (c->m.dim == 3)
+            hipLaunchKernelGGL(k_emi_apply_staged<3>, g, b, 0, c->stream, c->m, x, kappa, y, c->p.C_phi, c->p.tau_emi);
+        else
+            hipLaunchKernelGGL(k_emi_apply_staged<2>, g, b, 0, c->stream, c->m, x, kappa, y, c->p.C_phi, c->p.tau_emi);
+    } else {
+        const dim3 g((unsigned)grid8(c->m.nc_owned)), b(KNP_BLOCK);
+        if (c->m.dim == 2)
+            hipLaunchKernelGGL((k_emi_apply<2, 4>), g, b, 0, c->stream, c->m, x, kappa, y, c->p.C_phi, c->p.tau_emi);
+        else if (variant == 2)
+            hipLaunchKernelGGL((k_emi_apply<3, 4>), g, b, 0, c->stream, c->m, x, kappa, y, c->p.C_phi, c->p.tau_emi);
+        else if (variant == 3)
+            hipLaunchKernelGGL((k_emi_apply<3, 2>), g, b, 0, c->stream, c->m, x, kappa, y, c->p.C_phi, c->p.tau_emi);
+        else
+            hipLaunchKernelGGL((k_emi_apply<3, 3>), g, b, 0, c->stream, c->m, x, kappa, y, c->p.C_phi, c->p.tau_emi);
+    }
     HIPCHK(c, hipGetLastError());
     return 0;
 }

@@ -132,10 +132,7 @@ template <> __device__ __forceinline__ void gradients<2>(const double (*X)[2], C
     K.vol = fabs(det) * 0.5;
 }
 
-template <int D> __device__ __forceinline__ void load_cell_geometry(const MeshDev& m, const int* verts, CellGeom<D>& K) {
-    double X[D + 1][D];
-#pragma unroll
-    for (int a = 0; a <= D; ++a) load_vertex<D>(m.coords, verts[a], X[a]);
+template <int D> __device__ __forceinline__ void cell_geometry_from(const double (*X)[D], CellGeom<D>& K) {
     gradients<D>(X, K);
 #pragma unroll
     for (int a = 0; a <= D; ++a)
@@ -145,6 +142,40 @@ template <int D> __device__ __forceinline__ void load_cell_geometry(const MeshDe
             K.G[a][b] = v;
             K.G[b][a] = v;
         }
+}
+
+template <int D> __device__ __forceinline__ void load_cell_geometry(const MeshDev& m, const int* verts, CellGeom<D>& K) {
+    double X[D + 1][D];
+#pragma unroll
+    for (int a = 0; a <= D; ++a) load_vertex<D>(m.coords, verts[a], X[a]);
+    cell_geometry_from<D>(X, K);
+}
+
+// Workgroup-local staging of what facet neighbours need from a cell (x, coefficient, diameter, vertex
+// coordinates): ~85 % of the neighbours of a Morton-ordered block live in the same block and are served
+// from LDS instead of per-lane L1 gathers.
+typedef __attribute__((address_space(3))) double lds_double;   // explicit LDS pointers: ds_read, never flat_load
+#define TO_LDS(p) ((const lds_double*)(p))
+
+template <int D> struct StageView {
+    const lds_double* x;    // [nvalid][NV]      (per species: + k * xstride)
+    const lds_double* k;    // [nvalid][NV]      coefficient (kappa | gphi)
+    const lds_double* h;    // [nvalid]
+    const lds_double* X;    // [nvalid][NV][D]
+    int64_t c0;
+    unsigned nvalid;        // 0 disables staging (setup kernels)
+};
+
+template <int D> __device__ __forceinline__ void lds_nodal(const lds_double* base, unsigned idx, double* v) {
+    if (D == 3) {
+        typedef double __attribute__((ext_vector_type(2))) vdouble2;
+        typedef __attribute__((address_space(3))) vdouble2 lds_vdouble2;
+        const vdouble2 a = *(const lds_vdouble2*)(base + 4 * idx);
+        const vdouble2 b = *(const lds_vdouble2*)(base + 4 * idx + 2);
+        v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y;
+    } else {
+        v[0] = base[3 * idx]; v[1] = base[3 * idx + 1]; v[2] = base[3 * idx + 2];
+    }
 }
 
 // L_a = lambda_a(Xo) for all own vertices a

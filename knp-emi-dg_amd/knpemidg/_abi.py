@@ -81,20 +81,65 @@ def _p(a, typ):
     return a.ctypes.data_as(typ) if a is not None else None
 
 
+def morton_order(points, scale=None):
+    """Stable argsort of points along a Morton (Z-order) curve.  `scale` = typical cell extent per axis, so
+    that the curve's bricks are cubes in units of CELLS (anisotropic meshes: 1 x 0.1 x 0.1 um boxes).
+    Device cell numbering follows this curve: ~85 % of a cell's facet neighbours then sit in the same
+    workgroup (served from LDS) and the rest is close enough to still be in the XCD's 4 MiB L2."""
+    pts = np.asarray(points, dtype=np.float64)
+    if scale is not None:
+        pts = pts / np.asarray(scale, dtype=np.float64)
+    n, d = pts.shape
+    if n == 0:
+        return np.zeros(0, dtype=np.int64)
+    lo = pts.min(axis=0)
+    span = float((pts.max(axis=0) - lo).max())
+    bits = 21 if d == 3 else 31
+    q = np.zeros((n, d), dtype=np.uint64) if span == 0 else \
+        np.minimum(((pts - lo) / span * (2 ** bits - 1)).astype(np.uint64), np.uint64(2 ** bits - 1))
+    code = np.zeros(n, dtype=np.uint64)
+    for b in range(bits):
+        for k in range(d):
+            code |= ((q[:, k] >> np.uint64(b)) & np.uint64(1)) << np.uint64(b * d + k)
+    return np.argsort(code, kind="stable")
+
+
 class Device:
     """One context = one GPU = one partition of the mesh."""
 
-    def __init__(self, mesh, cell_tags, facet_tags, membrane_tags, n_ions, degree=1, device=0, nc_owned=None):
+    def __init__(self, mesh, cell_tags, facet_tags, membrane_tags, n_ions, degree=1, device=0, nc_owned=None,
+                 reorder=None):
         self.lib = load()
         self.ctx = _ctxp()
-        coords = np.ascontiguousarray(mesh.coords, dtype=np.float64)
-        cells = np.ascontiguousarray(mesh.cells, dtype=np.int32)
-        ctags = np.ascontiguousarray(np.asarray(cell_tags), dtype=np.uint32)
+        nc = mesh.cells.shape[0]
+        n_own = nc if nc_owned is None else int(nc_owned)
+        if reorder is None:
+            reorder = os.environ.get("KNP_NO_REORDER", "0") != "1"
+        # device cell numbering: owned cells along a Morton curve, ghosts keep their (peer-grouped) places
+        order = np.arange(nc, dtype=np.int64)
+        scale = None
+        if reorder and nc:
+            xc = mesh.coords[mesh.cells]
+            scale = np.maximum(np.median(xc.max(axis=1) - xc.min(axis=1), axis=0), 1e-300)
+            order[:n_own] = morton_order(mesh.cell_midpoints()[:n_own], scale)
+        rank = np.empty(nc, dtype=np.int64)
+        rank[order] = np.arange(nc)
+        self.cell_order, self.cell_rank = order, rank            # device -> caller, caller -> device
+        assert (np.diff(mesh.cells, axis=1) > 0).all(), "cells must hold ascending vertex ids"
+        # vertex STORAGE order (ids are only used to fetch coordinates on the device; the local vertex order
+        # inside each cell -- which carries the facet matching -- is untouched)
+        nv = mesh.coords.shape[0]
+        vorder = morton_order(mesh.coords, scale) if reorder else np.arange(nv, dtype=np.int64)
+        vrank = np.empty(nv, dtype=np.int64)
+        vrank[vorder] = np.arange(nv)
+        coords = np.ascontiguousarray(mesh.coords[vorder], dtype=np.float64)
+        cells = np.ascontiguousarray(vrank[mesh.cells[order]], dtype=np.int32)
+        ctags = np.ascontiguousarray(np.asarray(cell_tags)[order], dtype=np.uint32)
         ftags = np.ascontiguousarray(np.asarray(facet_tags), dtype=np.uint32)
-        fcells = np.ascontiguousarray(mesh.facet_cells, dtype=np.int32)
+        fc = np.asarray(mesh.facet_cells, dtype=np.int64)
+        fcells = np.ascontiguousarray(np.where(fc >= 0, rank[np.maximum(fc, 0)], -1), dtype=np.int32)
         flocal = np.ascontiguousarray(mesh.facet_local, dtype=np.int8)
         mt = np.ascontiguousarray(np.asarray(list(membrane_tags)), dtype=np.uint32)
-        nc = cells.shape[0]
         assert ctags.shape == (nc,) and ftags.shape == (fcells.shape[0],)
         self.dim = mesh.gdim
         self.nd = self.dim + 1 if degree == 1 else (self.dim + 1) * (self.dim + 2) // 2
@@ -130,24 +175,43 @@ class Device:
 
     def set_params(self, C_M, dt, F, R, T, C_phi, tau_emi, tau_knp, z, D, rho=None, fsrc=None, splitting=True):
         z = np.ascontiguousarray(z, dtype=np.float64)
-        D = np.ascontiguousarray(D, dtype=np.float64)
+        D = np.asarray(D, dtype=np.float64)
         assert z.shape == (self.n_ions,) and D.shape == (self.n_ions, self.nc)
-        rho = None if rho is None else np.ascontiguousarray(rho, dtype=np.float64)
-        fsrc = None if fsrc is None else np.ascontiguousarray(fsrc, dtype=np.float64)
+        o = self.cell_order
+        D = np.ascontiguousarray(D[:, o])
+        rho = None if rho is None else np.ascontiguousarray(np.asarray(rho, dtype=np.float64)[o])
+        fsrc = None if fsrc is None else np.ascontiguousarray(np.asarray(fsrc, dtype=np.float64)[:, o])
         self._chk(self.lib.knp_set_params(self.ctx, C_M, dt, F, R, T, C_phi, tau_emi, tau_knp, _p(z, _f64p), _p(D, _f64p),
                                           _p(rho, _f64p), _p(fsrc, _f64p), int(bool(splitting))), "knp_set_params")
 
     def size(self, field):
         return int(self.lib.knp_field_size(self.ctx, field))
 
+    _FACET_FIELDS = (F_PHI_M, F_I_CH, F_E, F_FACET_TMP)
+
+    def _nodal_blocks(self, field, offset, count):
+        """Nodal fields are stored in device cell order; transfers address whole [nc*nd] blocks."""
+        ndof = self.nc * self.nd
+        if field in self._FACET_FIELDS:
+            return None
+        if offset % ndof or count % ndof:
+            raise KnpError("nodal field transfers must cover whole [nc*nd] blocks")
+        return count // ndof
+
     def upload(self, field, a, offset=0):
         a = np.ascontiguousarray(a, dtype=np.float64).ravel()
+        nb = self._nodal_blocks(field, offset, a.size)
+        if nb is not None:
+            a = np.ascontiguousarray(a.reshape(nb, self.nc, self.nd)[:, self.cell_order]).ravel()
         self._chk(self.lib.knp_upload(self.ctx, field, _p(a, _f64p), offset, a.size), "knp_upload")
 
     def download(self, field, offset=0, count=None):
         n = self.size(field) - offset if count is None else count
         out = np.empty(n, dtype=np.float64)
         self._chk(self.lib.knp_download(self.ctx, field, _p(out, _f64p), offset, n), "knp_download")
+        nb = self._nodal_blocks(field, offset, n)
+        if nb is not None:
+            out = np.ascontiguousarray(out.reshape(nb, self.nc, self.nd)[:, self.cell_rank]).ravel()
         return out
 
     def copy_field(self, dst, src):
@@ -218,7 +282,8 @@ class Device:
     def halo_tables(self, peers, send_lists, recv_offsets, recv_counts):
         peers = np.ascontiguousarray(peers, dtype=np.int32)
         sc = np.ascontiguousarray([len(s) for s in send_lists], dtype=np.int64)
-        cells = np.ascontiguousarray(np.concatenate(send_lists) if len(send_lists) else np.zeros(0), dtype=np.int32)
+        cells = np.concatenate(send_lists) if len(send_lists) else np.zeros(0, dtype=np.int64)
+        cells = np.ascontiguousarray(self.cell_rank[np.asarray(cells, dtype=np.int64)], dtype=np.int32)
         ro = np.ascontiguousarray(recv_offsets, dtype=np.int64)
         rcnt = np.ascontiguousarray(recv_counts, dtype=np.int64)
         self._chk(self.lib.knp_halo_tables(self.ctx, len(peers), _p(peers, _i32p), _p(sc, _i64p), _p(cells, _i32p),

@@ -1,0 +1,18 @@
+"""Runs only the operator-apply kernels on the r=R idealized 3D mesh (profiling helper)."""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "knp-emi-dg_amd")); sys.path.insert(0, os.path.join(ROOT, "examples", "idealized_geometries"))
+from idealized_common import make_solver
+from knpemidg import _abi as A
+r = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+S = make_solver(dim=3, resolution=r)
+dev = S.dev
+rng = np.random.default_rng(0)
+dev.upload(A.F_X, rng.uniform(-1, 1, size=dev.size(A.F_X)))
+dev.upload(A.F_PHI, 0.07 * rng.uniform(-1, 1, size=dev.size(A.F_PHI)))
+dev.update_kappa(); dev.update_dnphi()
+e = dev.bench_apply(0, reps); k = dev.bench_apply(1, reps)
+nc = dev.nc_owned
+print("cells %d  emi %.2f us (%.0f GB/s alg)  knp %.2f us (%.0f GB/s alg)" % (nc, e * 1e3, 137 * nc / e / 1e6, k * 1e3, 217 * nc / k / 1e6))
