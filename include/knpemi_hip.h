@@ -97,6 +97,22 @@ int knp_knp_rhs(knp_ctx* ctx);             /* B_KNP <- L_knp(C, C_PREV, C_ELIM, 
 int knp_emi_solve(knp_ctx* ctx, double rtol, double atol, int maxit, int check_every, int* niter, double* res);
 int knp_knp_solve(knp_ctx* ctx, double rtol, double atol, int maxit, int min_it, int check_every, int* niter, double* res);
 
+/* ---- auxiliary-space AMG preconditioner (stands in for pc_type hypre, solver.py:433, 688) ---------------
+ * M^-1 = cell-block-Jacobi + P Ac^+ P^T with Ac the conforming (membrane-broken) P1 operator; the hierarchy is
+ * built on the host (knpemidg/amg.py) and uploaded level by level.  which: 0 = EMI, 1 + k = KNP species k.
+ *  knp_amg_begin : DG -> conforming dof map [nc*nd] and its inverse as a CSR list (conforming dof -> DG dofs)
+ *  knp_amg_level : one level (A csr, inverse diagonal, spectral radius of D^-1 A, Chebyshev degree / lower
+ *                  fraction; P [n x ncoarse] and R = P^T as CSR; ncoarse = 0 on the last level)
+ *  knp_amg_finish: dense pseudo-inverse [n*n] of the last level; arms the preconditioner
+ *  knp_amg_clear : back to plain block-Jacobi */
+int knp_amg_begin(knp_ctx* ctx, int which, int64_t ncg, const int32_t* dg2cg, const int32_t* cg_ptr, const int32_t* cg_idx);
+int knp_amg_level(knp_ctx* ctx, int which, int64_t n, const int32_t* rowptrA, const int32_t* colA, const double* valA,
+                  const double* dinv, double rho, int cheb_degree, double cheb_lower, int64_t ncoarse,
+                  const int32_t* rowptrP, const int32_t* colP, const double* valP,
+                  const int32_t* rowptrR, const int32_t* colR, const double* valR);
+int knp_amg_finish(knp_ctx* ctx, int which, int64_t n, const double* pinv);
+int knp_amg_clear(knp_ctx* ctx, int which);
+
 /* ---- step III (solver.py:808-845) -------------------------------------------------------------
  * C_PREV <- C ; PHI_M <- facet-avg(phi_i - phi_e) ; C_ELIM <- -(sum z_k c_k + rho)/z_N ; E <- Nernst. */
 int knp_step_updates(knp_ctx* ctx);

@@ -36,6 +36,11 @@ int dev_zeros(knp_ctx* c, double** dst, size_t n) {
 
 }  // namespace
 
+AmgHierarchy* amg_slot(knp_ctx* c, int which) {
+    if (which < 0 || which >= (int)c->amg.size()) return nullptr;
+    return &c->amg[which];
+}
+
 extern "C" {
 
 const char* knp_last_error(knp_ctx* ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
@@ -60,6 +65,7 @@ int knp_ctx_create(knp_ctx** out, int device, int dim, int degree, int n_ions, i
     c->nd = NV;
     c->p.n_ions = n_ions;
     c->p.n_sys = n_ions - 1;
+    c->amg.resize(1 + (size_t)(n_ions - 1));
     if (hipSetDevice(device) != hipSuccess) { g_err = "hipSetDevice failed"; delete c; return -5; }
     if (hipStreamCreate(&c->stream) != hipSuccess) { g_err = "hipStreamCreate failed"; delete c; return -5; }
     hipEventCreate(&c->ev0);
@@ -178,6 +184,7 @@ void knp_ctx_destroy(knp_ctx* c) {
     if (!c) return;
     hipSetDevice(c->device);
     hipDeviceSynchronize();
+    for (auto& H : c->amg) amg_free(H);
     Fields* fl = g_fields[c];
     if (fl) {
         for (int i = 0; i < KNP_F_COUNT; ++i) hipFree(fl->f[i]);
@@ -308,7 +315,7 @@ int knp_emi_solve(knp_ctx* c, double rtol, double atol, int maxit, int check_eve
     if (rc) return rc;
     KrylovVecs kv{};
     kv.x = f->f[KNP_F_PHI]; kv.b = f->f[KNP_F_B_EMI]; kv.coef = f->f[KNP_F_KAPPA]; kv.binv = f->binv_emi;
-    kv.r = f->r; kv.z = f->z; kv.p = f->p; kv.w = f->w;
+    kv.r = f->r; kv.z = f->z; kv.p = f->p; kv.w = f->w; kv.rhat = f->rhat; kv.v = f->v; kv.y = f->y;
     rc = pcg_solve(c, kv, rtol, atol, maxit, check_every, niter, res);
     if (rc) return rc;
     if (c->nranks > 1) return halo_exchange(c, kv.x, 1);     // ghostUpdate (solver.py:529)

@@ -1,0 +1,257 @@
+// Device side of the auxiliary-space preconditioner  M^-1 = B^-1 + P Ac^+ P^T  (setup: knpemidg/amg.py).
+//  * DG <-> conforming-P1 transfers (gather forms, deterministic),
+//  * one V-cycle over a smoothed-aggregation hierarchy stored as CSR levels: Chebyshev-Jacobi polynomial
+//    smoothing (fused SpMV + recurrence kernels, no sequential sweeps), CSR restriction / prolongation,
+//    dense pseudo-inverse on the coarsest level.
+// Stands in for hypre BoomerAMG (reference: src/knpemidg/solver.py:433, 505, 688, 767).
+#include "../../include/knpemi_hip.h"
+#include "knpemi_internal.hpp"
+#include "amg.hpp"
+
+namespace {
+
+template <typename T> int up(knp_ctx* c, T** dst, const T* src, size_t n) {
+    HIPCHK(c, hipMalloc((void**)dst, (n ? n : 1) * sizeof(T)));
+    if (n) HIPCHK(c, hipMemcpy(*dst, src, n * sizeof(T), hipMemcpyHostToDevice));
+    return 0;
+}
+
+int up_csr(knp_ctx* c, CsrDev& M, int64_t nrows, int64_t ncols, const int32_t* rp, const int32_t* ci, const double* v) {
+    M.nrows = nrows; M.ncols = ncols; M.nnz = rp[nrows];
+    int rc = up(c, &M.rowptr, rp, (size_t)nrows + 1);
+    rc |= up(c, &M.col, ci, (size_t)M.nnz);
+    rc |= up(c, &M.val, v, (size_t)M.nnz);
+    return rc;
+}
+
+void free_csr(CsrDev& M) { hipFree(M.rowptr); hipFree(M.col); hipFree(M.val); M = CsrDev(); }
+
+// y = A x (MODE 0) | y = b - A x (MODE 1) | y += A x (MODE 2); G lanes cooperate on one row
+template <int MODE, int G>
+__global__ __launch_bounds__(256) void k_csr(CsrDev A, const double* __restrict__ x, const double* __restrict__ b,
+                                             double* __restrict__ y) {
+    const int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) / G;
+    const int lane = threadIdx.x % G;
+    double s = 0.0;
+    if (row < A.nrows) {
+        const int e = A.rowptr[row + 1];
+        for (int k = A.rowptr[row] + lane; k < e; k += G) s = fma(A.val[k], x[A.col[k]], s);
+    }
+#pragma unroll
+    for (int off = G / 2; off > 0; off >>= 1) s += __shfl_down(s, off, G);
+    if (row < A.nrows && lane == 0) {
+        if (MODE == 0) y[row] = s;
+        else if (MODE == 1) y[row] = b[row] - s;
+        else y[row] += s;
+    }
+}
+
+template <int MODE> void launch_csr(knp_ctx* c, const CsrDev& A, const double* x, const double* b, double* y) {
+    const double avg = A.nrows ? (double)A.nnz / (double)A.nrows : 0.0;
+    if (avg <= 12.0) {
+        hipLaunchKernelGGL((k_csr<MODE, 1>), dim3((unsigned)((A.nrows + 255) / 256)), dim3(256), 0, c->stream, A, x, b, y);
+    } else if (avg <= 96.0) {
+        hipLaunchKernelGGL((k_csr<MODE, 8>), dim3((unsigned)((A.nrows * 8 + 255) / 256)), dim3(256), 0, c->stream, A, x, b, y);
+    } else {
+        hipLaunchKernelGGL((k_csr<MODE, 64>), dim3((unsigned)((A.nrows * 64 + 255) / 256)), dim3(256), 0, c->stream, A, x, b, y);
+    }
+}
+
+// first Chebyshev update:  d = dinv r / theta ;  x = d (zero guess) or x += d
+__global__ void k_cheb_first(int64_t n, const double* __restrict__ dinv, const double* __restrict__ r, double inv_theta,
+                             int zero_guess, double* __restrict__ d, double* __restrict__ x) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double v = dinv[i] * r[i] * inv_theta;
+    d[i] = v;
+    x[i] = zero_guess ? v : x[i] + v;
+}
+
+// fused step:  r -= A d_in ;  d_out = c1 d_in + c2 dinv r ;  x += d_out        (G lanes per row)
+template <int G>
+__global__ __launch_bounds__(256) void k_cheb_step(CsrDev A, const double* __restrict__ dinv, const double* __restrict__ din,
+                                                   double c1, double c2, double* __restrict__ r, double* __restrict__ dout,
+                                                   double* __restrict__ x) {
+    const int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) / G;
+    const int lane = threadIdx.x % G;
+    double s = 0.0;
+    if (row < A.nrows) {
+        const int e = A.rowptr[row + 1];
+        for (int k = A.rowptr[row] + lane; k < e; k += G) s = fma(A.val[k], din[A.col[k]], s);
+    }
+#pragma unroll
+    for (int off = G / 2; off > 0; off >>= 1) s += __shfl_down(s, off, G);
+    if (row < A.nrows && lane == 0) {
+        const double rn = r[row] - s;
+        const double dn = fma(c1, din[row], c2 * dinv[row] * rn);
+        r[row] = rn;
+        dout[row] = dn;
+        x[row] += dn;
+    }
+}
+
+void launch_cheb_step(knp_ctx* c, const CsrDev& A, const double* dinv, const double* din, double c1, double c2, double* r,
+                      double* dout, double* x) {
+    const double avg = A.nrows ? (double)A.nnz / (double)A.nrows : 0.0;
+    if (avg <= 12.0)
+        hipLaunchKernelGGL((k_cheb_step<1>), dim3((unsigned)((A.nrows + 255) / 256)), dim3(256), 0, c->stream, A, dinv, din, c1, c2, r, dout, x);
+    else if (avg <= 96.0)
+        hipLaunchKernelGGL((k_cheb_step<8>), dim3((unsigned)((A.nrows * 8 + 255) / 256)), dim3(256), 0, c->stream, A, dinv, din, c1, c2, r, dout, x);
+    else
+        hipLaunchKernelGGL((k_cheb_step<64>), dim3((unsigned)((A.nrows * 64 + 255) / 256)), dim3(256), 0, c->stream, A, dinv, din, c1, c2, r, dout, x);
+}
+
+// dense y = M b on the coarsest level (n <= ~512): one wavefront per row
+__global__ void k_dense_mv(int n, const double* __restrict__ M, const double* __restrict__ b, double* __restrict__ y) {
+    const int row = blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= n) return;
+    double s = 0.0;
+    for (int k = lane; k < n; k += 64) s = fma(M[(int64_t)row * n + k], b[k], s);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if (lane == 0) y[row] = s;
+}
+
+// rc[v] = sum over the DG dofs mapped to conforming dof v (CSR list, fixed order -> deterministic)
+__global__ void k_dg_restrict(int64_t ncg, const int32_t* __restrict__ ptr, const int32_t* __restrict__ idx,
+                              const double* __restrict__ r, double* __restrict__ rc) {
+    const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= ncg) return;
+    double s = 0.0;
+    for (int k = ptr[v]; k < ptr[v + 1]; ++k) s += r[idx[k]];
+    rc[v] = s;
+}
+
+}  // namespace
+
+// smoother on level lv: Chebyshev polynomial of D^-1 A on [lower*rho, rho]
+static void smooth(knp_ctx* c, AmgLevel& L, bool zero_guess) {
+    const double lmax = L.rho, lmin = L.cheb_lower * L.rho;
+    const double theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin), sigma = theta / delta;
+    double rho = 1.0 / sigma;
+    const unsigned g = (unsigned)((L.n + 255) / 256);
+    if (!zero_guess) launch_csr<1>(c, L.A, L.x, L.b, L.r);       // r = b - A x
+    const double* r0 = zero_guess ? L.b : L.r;
+    hipLaunchKernelGGL(k_cheb_first, dim3(g), dim3(256), 0, c->stream, L.n, L.dinv, r0, 1.0 / theta, zero_guess ? 1 : 0, L.d0, L.x);
+    if (L.cheb_degree > 1 && zero_guess)
+        hipMemcpyAsync(L.r, L.b, sizeof(double) * L.n, hipMemcpyDeviceToDevice, c->stream);
+    double* din = L.d0;
+    double* dout = L.d1;
+    for (int k = 1; k < L.cheb_degree; ++k) {
+        const double rho_new = 1.0 / (2.0 * sigma - rho);
+        launch_cheb_step(c, L.A, L.dinv, din, rho_new * rho, 2.0 * rho_new / delta, L.r, dout, L.x);
+        rho = rho_new;
+        double* t = din; din = dout; dout = t;
+    }
+}
+
+// x_0 = V(b_0) ; level vectors b/x of level 0 are filled / read by the caller
+int amg_vcycle(knp_ctx* c, AmgHierarchy& H) {
+    const int nl = (int)H.levels.size();
+    for (int l = 0; l < nl - 1; ++l) {
+        AmgLevel& L = H.levels[l];
+        smooth(c, L, true);
+        launch_csr<1>(c, L.A, L.x, L.b, L.r);                        // r = b - A x
+        launch_csr<0>(c, L.R, L.r, nullptr, H.levels[l + 1].b);      // b_{l+1} = R r
+    }
+    AmgLevel& C = H.levels[nl - 1];
+    hipLaunchKernelGGL(k_dense_mv, dim3((unsigned)((C.n + 3) / 4)), dim3(256), 0, c->stream, (int)C.n, H.pinv, C.b, C.x);
+    for (int l = nl - 2; l >= 0; --l) {
+        AmgLevel& L = H.levels[l];
+        launch_csr<2>(c, L.P, H.levels[l + 1].x, nullptr, L.x);      // x += P x_{l+1}
+        smooth(c, L, false);
+    }
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
+int amg_restrict_from_dg(knp_ctx* c, AmgHierarchy& H, const double* r_dg) {
+    hipLaunchKernelGGL(k_dg_restrict, dim3((unsigned)((H.ncg + 255) / 256)), dim3(256), 0, c->stream, H.ncg, H.cg_ptr, H.cg_idx,
+                       r_dg, H.levels[0].b);
+    return 0;
+}
+
+void amg_free(AmgHierarchy& H) {
+    for (auto& L : H.levels) {
+        free_csr(L.A); free_csr(L.P); free_csr(L.R);
+        hipFree(L.dinv); hipFree(L.x); hipFree(L.b); hipFree(L.r); hipFree(L.d0); hipFree(L.d1);
+    }
+    H.levels.clear();
+    hipFree(H.pinv); hipFree(H.dg2cg); hipFree(H.cg_ptr); hipFree(H.cg_idx);
+    H.pinv = nullptr; H.dg2cg = nullptr; H.cg_ptr = nullptr; H.cg_idx = nullptr;
+    H.ready = false;
+}
+
+AmgHierarchy* amg_slot(knp_ctx* c, int which);   // abi.hip
+
+extern "C" {
+
+int knp_amg_begin(knp_ctx* c, int which, int64_t ncg, const int32_t* dg2cg, const int32_t* cg_ptr, const int32_t* cg_idx) {
+    if (!c) return -1;
+    AmgHierarchy* H = amg_slot(c, which);
+    if (!H) { c->err = "amg: bad slot"; return -1; }
+    amg_free(*H);
+    const int64_t ndof = c->m.nc * c->nd;
+    for (int64_t i = 0; i < ndof; ++i)
+        if (dg2cg[i] < 0 || dg2cg[i] >= ncg) { c->err = "amg: dg2cg out of range"; return -1; }
+    if (cg_ptr[ncg] > ndof) { c->err = "amg: cg_ptr inconsistent"; return -1; }
+    for (int64_t k = 0; k < cg_ptr[ncg]; ++k)
+        if (cg_idx[k] < 0 || cg_idx[k] >= ndof) { c->err = "amg: cg_idx out of range"; return -1; }
+    H->ncg = ncg;
+    int rc = up(c, &H->dg2cg, dg2cg, (size_t)ndof);
+    rc |= up(c, &H->cg_ptr, cg_ptr, (size_t)ncg + 1);
+    rc |= up(c, &H->cg_idx, cg_idx, (size_t)cg_ptr[ncg]);
+    return rc;
+}
+
+int knp_amg_level(knp_ctx* c, int which, int64_t n, const int32_t* rpA, const int32_t* ciA, const double* vA, const double* dinv,
+                  double rho, int cheb_degree, double cheb_lower, int64_t ncoarse, const int32_t* rpP, const int32_t* ciP,
+                  const double* vP, const int32_t* rpR, const int32_t* ciR, const double* vR) {
+    if (!c) return -1;
+    AmgHierarchy* H = amg_slot(c, which);
+    if (!H) { c->err = "amg: bad slot"; return -1; }
+    if (H->levels.empty() ? (n != H->ncg) : (n != H->levels.back().ncoarse)) { c->err = "amg: level size mismatch"; return -1; }
+    for (int64_t k = 0; k < rpA[n]; ++k)
+        if (ciA[k] < 0 || ciA[k] >= n) { c->err = "amg: A column out of range"; return -1; }
+    AmgLevel L;
+    L.n = n; L.ncoarse = ncoarse; L.rho = rho; L.cheb_degree = cheb_degree; L.cheb_lower = cheb_lower;
+    int rc = up_csr(c, L.A, n, n, rpA, ciA, vA);
+    rc |= up(c, &L.dinv, dinv, (size_t)n);
+    if (ncoarse > 0) {
+        for (int64_t k = 0; k < rpP[n]; ++k)
+            if (ciP[k] < 0 || ciP[k] >= ncoarse) { c->err = "amg: P column out of range"; return -1; }
+        for (int64_t k = 0; k < rpR[ncoarse]; ++k)
+            if (ciR[k] < 0 || ciR[k] >= n) { c->err = "amg: R column out of range"; return -1; }
+        rc |= up_csr(c, L.P, n, ncoarse, rpP, ciP, vP);
+        rc |= up_csr(c, L.R, ncoarse, n, rpR, ciR, vR);
+    }
+    double** w[] = {&L.x, &L.b, &L.r, &L.d0, &L.d1};
+    for (auto p : w) {
+        if (hipMalloc((void**)p, (size_t)(n ? n : 1) * sizeof(double)) != hipSuccess) rc = -2;
+        else hipMemset(*p, 0, (size_t)(n ? n : 1) * sizeof(double));
+    }
+    H->levels.push_back(L);
+    return rc;
+}
+
+int knp_amg_finish(knp_ctx* c, int which, int64_t n, const double* pinv) {
+    if (!c) return -1;
+    AmgHierarchy* H = amg_slot(c, which);
+    if (!H || H->levels.empty() || H->levels.back().n != n || H->levels.back().ncoarse != 0) {
+        c->err = "amg: finish does not match the last level"; return -1;
+    }
+    int rc = up(c, &H->pinv, pinv, (size_t)n * n);
+    H->ready = (rc == 0);
+    return rc;
+}
+
+int knp_amg_clear(knp_ctx* c, int which) {
+    if (!c) return -1;
+    AmgHierarchy* H = amg_slot(c, which);
+    if (!H) return -1;
+    amg_free(*H);
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,34 @@
+// CSR levels of the auxiliary-space AMG hierarchy (device pointers).
+#pragma once
+#include <cstdint>
+#include <vector>
+
+struct CsrDev {
+    int64_t nrows = 0, ncols = 0, nnz = 0;
+    int32_t* rowptr = nullptr;
+    int32_t* col = nullptr;
+    double* val = nullptr;
+};
+
+struct AmgLevel {
+    int64_t n = 0, ncoarse = 0;
+    CsrDev A, P, R;
+    double* dinv = nullptr;
+    double rho = 1.0, cheb_lower = 0.1;
+    int cheb_degree = 3;
+    double *x = nullptr, *b = nullptr, *r = nullptr, *d0 = nullptr, *d1 = nullptr;
+};
+
+struct AmgHierarchy {
+    bool ready = false;
+    int64_t ncg = 0;
+    int32_t* dg2cg = nullptr;       // [nc*nd] conforming dof of every DG dof
+    int32_t *cg_ptr = nullptr, *cg_idx = nullptr;   // CSR list: conforming dof -> DG dofs (owned cells only)
+    std::vector<AmgLevel> levels;
+    double* pinv = nullptr;         // dense pseudo-inverse of the coarsest level
+};
+
+struct knp_ctx;
+int amg_vcycle(knp_ctx* c, AmgHierarchy& H);
+int amg_restrict_from_dg(knp_ctx* c, AmgHierarchy& H, const double* r_dg);
+void amg_free(AmgHierarchy& H);

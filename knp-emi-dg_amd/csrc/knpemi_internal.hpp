@@ -6,6 +6,7 @@
 #include <string>
 #include <vector>
 #include <map>
+#include "amg.hpp"
 
 #define KNP_MAX_IONS 8          // total species incl. the eliminated one
 #define KNP_MAX_SYS 7           // solved species (batched KNP systems)
@@ -64,6 +65,8 @@ struct knp_ctx {
     int* status = nullptr;         // device: [0]=converged flag, [1]=iterations
     void* pinned = nullptr;        // host pinned mirror for status/scalars
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // auxiliary-space AMG hierarchies: [0] EMI, [1 + k] KNP species k
+    std::vector<AmgHierarchy> amg;
     // distributed
     void* comm = nullptr;          // ncclComm_t
     int rank = 0, nranks = 1;

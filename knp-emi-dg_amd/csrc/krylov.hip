@@ -242,6 +242,69 @@ __global__ __launch_bounds__(KNP_BLOCK) void k_cg_update(VecDims d, const double
     write_partials<2>(partial, 1, acc);
 }
 
+// z += P e (conforming correction, gathered through dg2cg) ; partials r.z, z.z  [+ (Minv b).(Minv b) on init]
+template <int NV, int NR>
+__global__ __launch_bounds__(KNP_BLOCK) void k_prolong_dot(VecDims d, const int* __restrict__ status, int use_status,
+                                                           const int32_t* __restrict__ dg2cg, const double* __restrict__ e,
+                                                           const double* __restrict__ r, double* __restrict__ z,
+                                                           const double* __restrict__ e2, double* __restrict__ z2,
+                                                           double* __restrict__ partial) {
+    if (use_status && status[0]) return;
+    const int64_t c = (int64_t)blockIdx.x * KNP_BLOCK + threadIdx.x;
+    double acc[NR];
+#pragma unroll
+    for (int k = 0; k < NR; ++k) acc[k] = 0.0;
+    if (c < d.nc_owned) {
+        double rv[NV], zv[NV];
+        ldv<NV>(r, c, rv);
+        ldv<NV>(z, c, zv);
+#pragma unroll
+        for (int a = 0; a < NV; ++a) {
+            zv[a] += e[dg2cg[c * NV + a]];
+            acc[0] += rv[a] * zv[a];
+            acc[1] += zv[a] * zv[a];
+        }
+        stv<NV>(z, c, zv);
+        if (NR == 3) {
+            double bv[NV];
+            ldv<NV>(z2, c, bv);
+#pragma unroll
+            for (int a = 0; a < NV; ++a) {
+                bv[a] += e2[dg2cg[c * NV + a]];
+                acc[NR - 1] += bv[a] * bv[a];
+            }
+        }
+    }
+    write_partials<NR>(partial, 1, acc);
+}
+
+// y += P e for one species block (BiCGStab preconditioner application)
+template <int NV>
+__global__ __launch_bounds__(KNP_BLOCK) void k_prolong_add(VecDims d, const int* __restrict__ status, int sys,
+                                                           const int32_t* __restrict__ dg2cg, const double* __restrict__ e,
+                                                           double* __restrict__ y) {
+    if (status[2 * sys]) return;
+    const int64_t c = (int64_t)blockIdx.x * KNP_BLOCK + threadIdx.x;
+    if (c >= d.nc_owned) return;
+    double yv[NV];
+    ldv<NV>(y, c, yv);
+#pragma unroll
+    for (int a = 0; a < NV; ++a) yv[a] += e[dg2cg[c * NV + a]];
+    stv<NV>(y, c, yv);
+}
+
+// z = Binv r (plain block-Jacobi apply, used to precondition b on init when the AMG term is active)
+template <int NV>
+__global__ __launch_bounds__(KNP_BLOCK) void k_bj_apply(VecDims d, const double* __restrict__ binv, const double* __restrict__ r,
+                                                        double* __restrict__ z) {
+    const int64_t c = (int64_t)blockIdx.x * KNP_BLOCK + threadIdx.x;
+    if (c >= d.nc_owned) return;
+    double rv[NV], zv[NV];
+    ldv<NV>(r, c, rv);
+    block_matvec<NV>(binv, c, rv, zv);
+    stv<NV>(z, c, zv);
+}
+
 // p = z + beta p
 template <int NV>
 __global__ __launch_bounds__(KNP_BLOCK) void k_cg_p(VecDims d, const double* __restrict__ scal, const int* __restrict__ status,
@@ -384,7 +447,20 @@ static int pcg_impl(knp_ctx* c, KrylovVecs& kv, double rtol, double atol, int ma
     int rc;
     if (c->nranks > 1 && (rc = halo_exchange(c, kv.x, 1))) return rc;
     if ((rc = launch_emi_apply(c, kv.x, kv.coef, kv.w))) return rc;
+    AmgHierarchy* H = (c->amg.size() && c->amg[0].ready && c->nranks == 1) ? &c->amg[0] : nullptr;
     hipLaunchKernelGGL(k_cg_init<NV>, g, b, 0, c->stream, d, kv.b, kv.w, kv.binv, kv.r, kv.z, kv.p, c->partial);
+    if (H) {
+        // z = Binv r + P V(P^T r) ; reference norm uses the same preconditioner on b (stored in y)
+        hipLaunchKernelGGL(k_bj_apply<NV>, g, b, 0, c->stream, d, kv.binv, kv.b, kv.y);
+        amg_restrict_from_dg(c, *H, kv.b);
+        if ((rc = amg_vcycle(c, *H))) return rc;
+        HIPCHK(c, hipMemcpyAsync(kv.v, H->levels[0].x, sizeof(double) * H->ncg, hipMemcpyDeviceToDevice, c->stream));
+        amg_restrict_from_dg(c, *H, kv.r);
+        if ((rc = amg_vcycle(c, *H))) return rc;
+        hipLaunchKernelGGL((k_prolong_dot<NV, 3>), g, b, 0, c->stream, d, c->status, 0, H->dg2cg, H->levels[0].x, kv.r, kv.z,
+                           kv.v, kv.y, c->partial);
+        HIPCHK(c, hipMemcpyAsync(kv.p, kv.z, sizeof(double) * c->m.nc * NV, hipMemcpyDeviceToDevice, c->stream));
+    }
     if ((rc = finalize(c, OP_CG_INIT, 1, 3, rtol, atol, 0))) return rc;
     int hs[2] = {0, 0};
     int it = 0;
@@ -399,6 +475,12 @@ static int pcg_impl(knp_ctx* c, KrylovVecs& kv, double rtol, double atol, int ma
             if ((rc = finalize(c, OP_CG_ALPHA, 1, 1, rtol, atol, 0))) return rc;
             hipLaunchKernelGGL(k_cg_update<NV>, g, b, 0, c->stream, d, c->scal, c->status, kv.p, kv.w, kv.binv, kv.x, kv.r, kv.z,
                                c->partial);
+            if (H) {
+                amg_restrict_from_dg(c, *H, kv.r);
+                if ((rc = amg_vcycle(c, *H))) return rc;
+                hipLaunchKernelGGL((k_prolong_dot<NV, 2>), g, b, 0, c->stream, d, c->status, 1, H->dg2cg, H->levels[0].x, kv.r,
+                                   kv.z, (const double*)nullptr, (double*)nullptr, c->partial);
+            }
             if ((rc = finalize(c, OP_CG_BETA, 1, 2, rtol, atol, 0))) return rc;
             hipLaunchKernelGGL(k_cg_p<NV>, g, b, 0, c->stream, d, c->scal, c->status, kv.z, kv.p);
         }

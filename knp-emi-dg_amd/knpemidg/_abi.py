@@ -52,6 +52,11 @@ SIGNATURES = {
     "knp_comm_init": (C.c_int, [_ctxp, C.c_int, C.c_int, C.c_char_p]),
     "knp_halo_tables": (C.c_int, [_ctxp, C.c_int, _i32p, _i64p, _i32p, _i64p, _i64p]),
     "knp_halo_exchange": (C.c_int, [_ctxp, C.c_int]),
+    "knp_amg_begin": (C.c_int, [_ctxp, C.c_int, C.c_int64, _i32p, _i32p, _i32p]),
+    "knp_amg_level": (C.c_int, [_ctxp, C.c_int, C.c_int64, _i32p, _i32p, _f64p, _f64p, C.c_double, C.c_int, C.c_double,
+                                C.c_int64, _i32p, _i32p, _f64p, _i32p, _i32p, _f64p]),
+    "knp_amg_finish": (C.c_int, [_ctxp, C.c_int, C.c_int64, _f64p]),
+    "knp_amg_clear": (C.c_int, [_ctxp, C.c_int]),
 }
 
 _lib = None
@@ -288,6 +293,43 @@ class Device:
         rcnt = np.ascontiguousarray(recv_counts, dtype=np.int64)
         self._chk(self.lib.knp_halo_tables(self.ctx, len(peers), _p(peers, _i32p), _p(sc, _i64p), _p(cells, _i32p),
                                            _p(ro, _i64p), _p(rcnt, _i64p)), "knp_halo_tables")
+
+    # -- auxiliary-space AMG (knpemidg/amg.py builds, csrc/amg.hip applies) ------------------
+    def amg_upload(self, which, dg2cg, levels):
+        """dg2cg [nc, nd] in the caller's cell order; levels from amg.build_hierarchy."""
+        nd = self.nd
+        d2c = np.ascontiguousarray(np.asarray(dg2cg)[self.cell_order].ravel(), dtype=np.int32)
+        ncg = levels[0].A.shape[0]
+        own = d2c[:self.nc_owned * nd]
+        idx = np.argsort(own, kind="stable").astype(np.int32)
+        ptr = np.zeros(ncg + 1, dtype=np.int32)
+        np.cumsum(np.bincount(own, minlength=ncg), out=ptr[1:])
+        self._chk(self.lib.knp_amg_begin(self.ctx, which, ncg, _p(d2c, _i32p), _p(ptr, _i32p), _p(idx, _i32p)), "knp_amg_begin")
+
+        def csr(M):
+            M = M.tocsr()
+            M.sort_indices()
+            return (np.ascontiguousarray(M.indptr, dtype=np.int32), np.ascontiguousarray(M.indices, dtype=np.int32),
+                    np.ascontiguousarray(M.data, dtype=np.float64))
+        for l, lv in enumerate(levels):
+            rpA, ciA, vA = csr(lv.A)
+            dinv = np.ascontiguousarray(lv.dinv, dtype=np.float64)
+            last = l == len(levels) - 1
+            if last:
+                z32, z64 = np.zeros(1, np.int32), np.zeros(1, np.float64)
+                args = (0, _p(z32, _i32p), _p(z32, _i32p), _p(z64, _f64p), _p(z32, _i32p), _p(z32, _i32p), _p(z64, _f64p))
+            else:
+                rpP, ciP, vP = csr(lv.P)
+                rpR, ciR, vR = csr(lv.R)
+                args = (lv.P.shape[1], _p(rpP, _i32p), _p(ciP, _i32p), _p(vP, _f64p), _p(rpR, _i32p), _p(ciR, _i32p), _p(vR, _f64p))
+            self._chk(self.lib.knp_amg_level(self.ctx, which, lv.A.shape[0], _p(rpA, _i32p), _p(ciA, _i32p), _p(vA, _f64p),
+                                             _p(dinv, _f64p), float(lv.rho), int(lv.cheb_degree), float(lv.cheb_lower), *args),
+                      "knp_amg_level")
+        pinv = np.ascontiguousarray(levels[-1].pinv, dtype=np.float64)
+        self._chk(self.lib.knp_amg_finish(self.ctx, which, pinv.shape[0], _p(pinv, _f64p)), "knp_amg_finish")
+
+    def amg_clear(self, which):
+        self._chk(self.lib.knp_amg_clear(self.ctx, which), "knp_amg_clear")
 
     def halo_exchange(self, field):
         self._chk(self.lib.knp_halo_exchange(self.ctx, field), "knp_halo_exchange")

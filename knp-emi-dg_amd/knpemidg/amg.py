@@ -1,0 +1,200 @@
+"""Host-side SETUP of the auxiliary-space preconditioner (the apply runs on the GPU, csrc/amg.hip).
+
+The reference preconditions both Krylov solves with hypre BoomerAMG built from the assembled matrix
+(reference: src/knpemidg/solver.py:433, 505, 688, 767).  There is no assembled DG matrix here, so the
+preconditioner is the classical two-level splitting of an interior-penalty DG space,
+
+    M^-1  =  B^-1  +  P  Ac^+  P^T ,
+
+* B    cell-block-Jacobi of the DG operator (device, csrc/apply_p1.hip),
+* P    injection of the CONFORMING P1 space, broken only across membrane facets (phi and c jump there),
+       into DG-P1:  DG dof (cell c, vertex a)  ->  conforming dof (vertex id, membrane-connected component of c),
+* Ac   = P^T A P.  Conforming functions have no jumps on ordinary facets, so every SIPG facet term
+       vanishes and Ac is the plain P1 stiffness matrix  sum_cells vol * mean(coef) * G  plus the membrane
+       coupling  C int_F (u_i - u_e)(v_i - v_e)  (and the mass / dt term for KNP) -- assembled here with numpy,
+* Ac^+ one V-cycle of a smoothed-aggregation AMG hierarchy built here (scipy.sparse), smoothed on the
+       device with Chebyshev-Jacobi polynomials (no sequential sweeps), coarsest level as a dense
+       pseudo-inverse.
+
+Setup is host work done once per solver (the hierarchy is reused across time steps: kappa changes by
+<1 % per step and a lagged SPD preconditioner does not change the converged solution).
+"""
+import numpy as np
+import scipy.sparse as sp
+import scipy.sparse.csgraph as csg
+
+
+# ----------------------------------------------------------------------------------------------
+# conforming (membrane-broken) P1 space
+# ----------------------------------------------------------------------------------------------
+class ConformingSpace:
+    def __init__(self, mesh, facet_tags, membrane_tags, nc_owned=None):
+        nc = mesh.num_cells()
+        fc = mesh.facet_cells
+        interior = fc[:, 1] >= 0
+        ordinary = interior & ~np.isin(np.asarray(facet_tags), list(membrane_tags))
+        g = sp.coo_matrix((np.ones(int(ordinary.sum())), (fc[ordinary, 0], fc[ordinary, 1])), shape=(nc, nc))
+        ncomp, comp = csg.connected_components(g, directed=False)
+        key = mesh.cells.astype(np.int64) * ncomp + comp[:, None]
+        uniq, inv = np.unique(key.ravel(), return_inverse=True)
+        self.n = len(uniq)
+        self.dof = inv.reshape(nc, -1).astype(np.int32)            # [nc, nd] conforming dof of each DG dof
+        self.mesh = mesh
+        self.ncomp = ncomp
+
+    def stiffness(self, coef_nodal, mass_coef=None, membrane=None):
+        """Ac = sum_cells vol * mean(coef) * G (+ mass_coef * M) (+ C int_F jump jump on membrane facets).
+        coef_nodal [nc, nd] (kappa) or [nc] (D); membrane = (facet ids, cell_e, cell_i, C)."""
+        mesh = self.mesh
+        d = mesh.gdim
+        x = mesh.coords[mesh.cells]
+        J = (x[:, 1:, :] - x[:, :1, :]).transpose(0, 2, 1)
+        det = np.linalg.det(J)
+        vol = np.abs(det) / {2: 2.0, 3: 6.0}[d]
+        Jinv = np.linalg.inv(J)
+        g = np.empty((x.shape[0], d + 1, d))
+        g[:, 1:, :] = Jinv
+        g[:, 0, :] = -Jinv.sum(axis=1)
+        G = np.einsum("cad,cbd->cab", g, g)
+        cbar = coef_nodal.mean(axis=1) if np.ndim(coef_nodal) == 2 else np.asarray(coef_nodal)
+        blk = (vol * cbar)[:, None, None] * G
+        nv = d + 1
+        if mass_coef is not None:
+            Mloc = (np.ones((nv, nv)) + np.eye(nv)) / ((d + 1) * (d + 2))
+            blk = blk + (mass_coef * vol)[:, None, None] * Mloc[None]
+        rows = np.repeat(self.dof[:, :, None], nv, axis=2).ravel()
+        cols = np.repeat(self.dof[:, None, :], nv, axis=1).ravel()
+        A = sp.coo_matrix((blk.ravel(), (rows, cols)), shape=(self.n, self.n))
+        if membrane is not None:
+            fids, C = membrane
+            fcl = mesh.facet_cells[fids]
+            fl = mesh.facet_local[fids].astype(np.int64)
+            fx = mesh.coords[mesh.facets[fids]]
+            if d == 2:
+                area = np.linalg.norm(fx[:, 1] - fx[:, 0], axis=1)
+            else:
+                area = 0.5 * np.linalg.norm(np.cross(fx[:, 1] - fx[:, 0], fx[:, 2] - fx[:, 0]), axis=1)
+            # facet vertex m of side s is the cell's local vertex m + (m >= local facet)
+            mm = np.arange(d)[None, :]
+            d0 = np.take_along_axis(self.dof[fcl[:, 0]], mm + (mm >= fl[:, 0:1]), axis=1)
+            d1 = np.take_along_axis(self.dof[fcl[:, 1]], mm + (mm >= fl[:, 1:2]), axis=1)
+            Mf = (np.ones((d, d)) + np.eye(d)) / (d * (d + 1))
+            blkf = (C * area)[:, None, None] * Mf[None]
+            dofs = np.concatenate([d0, d1], axis=1)                              # [F, 2d]
+            sgn = np.concatenate([np.ones(d), -np.ones(d)])
+            full = np.einsum("a,b,fab->fab", sgn, sgn, np.tile(blkf, (1, 2, 2)))
+            rows = np.repeat(dofs[:, :, None], 2 * d, axis=2).ravel()
+            cols = np.repeat(dofs[:, None, :], 2 * d, axis=1).ravel()
+            A = A + sp.coo_matrix((full.ravel(), (rows, cols)), shape=(self.n, self.n))
+        A = A.tocsr()
+        A.sum_duplicates()
+        return A
+
+
+# ----------------------------------------------------------------------------------------------
+# smoothed aggregation
+# ----------------------------------------------------------------------------------------------
+def _rowmax(S, vals):
+    """max over the stored neighbours of each row of vals[col]; -inf for empty rows."""
+    out = np.full(S.shape[0], -np.inf)
+    nz = np.diff(S.indptr) > 0
+    if S.nnz:
+        red = np.maximum.reduceat(vals[S.indices], S.indptr[:-1][nz])
+        out[nz] = red
+    return out
+
+
+def mis2_aggregate(S, seed=0):
+    """Aggregation from a distance-2 maximal independent set of the strength graph S (symmetric pattern,
+    no diagonal).  Vectorised Luby rounds (the same algorithm maps 1:1 onto GPU kernels).
+    Returns agg[n] in [0, nagg)."""
+    n = S.shape[0]
+    rng = np.random.default_rng(seed)
+    key = rng.permutation(n).astype(np.float64) + 1.0
+    state = np.zeros(n, dtype=np.int8)                 # 0 undecided, 1 root, 2 covered
+    isolated = np.diff(S.indptr) == 0
+    state[isolated] = 1
+    while (state == 0).any():
+        k = np.where(state == 0, key, -np.inf)
+        m1 = np.maximum(k, _rowmax(S, k))
+        m2 = np.maximum(m1, _rowmax(S, m1))
+        new_root = (state == 0) & (k >= m2)
+        state[new_root] = 1
+        r = np.where(state == 1, 1.0, -np.inf)
+        c1 = np.maximum(r, _rowmax(S, r))
+        c2 = np.maximum(c1, _rowmax(S, c1))
+        state[(state == 0) & (c2 > 0)] = 2
+    roots = np.nonzero(state == 1)[0]
+    agg = np.full(n, -1, dtype=np.int64)
+    agg[roots] = np.arange(len(roots))
+    # distance-1 members take the neighbouring root with the largest key, distance-2 members follow a neighbour
+    for _ in range(2):
+        lab = np.where(agg >= 0, key * 0 + agg.astype(np.float64), -np.inf)
+        best = _rowmax(S, lab)
+        take = (agg < 0) & np.isfinite(best)
+        agg[take] = best[take].astype(np.int64)
+    left = agg < 0
+    if left.any():                                     # safety: singletons
+        agg[left] = len(roots) + np.arange(int(left.sum()))
+    return agg, int(agg.max()) + 1
+
+
+def _spectral_radius_DinvA(A, dinv, iters=15, seed=1):
+    x = np.random.default_rng(seed).standard_normal(A.shape[0])
+    lam = 1.0
+    for _ in range(iters):
+        y = dinv * (A @ x)
+        lam = np.linalg.norm(y) / max(np.linalg.norm(x), 1e-300)
+        x = y / max(np.linalg.norm(y), 1e-300)
+    return 1.1 * lam
+
+
+class Level:
+    pass
+
+
+def build_hierarchy(A, theta=0.08, max_coarse=300, max_levels=12, cheb_degree=3, cheb_lower=0.1):
+    """Smoothed-aggregation hierarchy for an SPD (possibly singular, constants) matrix.
+    Each level: A (csr), dinv, rho = spectral radius estimate of D^-1 A, P (csr, to the next level).
+    Last level: dense pseudo-inverse."""
+    levels = []
+    A = A.tocsr().astype(np.float64)
+    while True:
+        lv = Level()
+        lv.A = A
+        d = A.diagonal()
+        lv.dinv = 1.0 / d
+        lv.rho = _spectral_radius_DinvA(A, lv.dinv)
+        lv.cheb_degree, lv.cheb_lower = cheb_degree, cheb_lower
+        levels.append(lv)
+        n = A.shape[0]
+        if n <= max_coarse or len(levels) >= max_levels:
+            break
+        # symmetric strength of connection
+        C = A.tocoo()
+        off = C.row != C.col
+        strong = off & (np.abs(C.data) >= theta * np.sqrt(np.abs(d[C.row] * d[C.col])))
+        S = sp.csr_matrix((np.ones(int(strong.sum())), (C.row[strong], C.col[strong])), shape=A.shape)
+        agg, nagg = mis2_aggregate(S, seed=len(levels))
+        if nagg >= n:
+            break
+        cnt = np.bincount(agg, minlength=nagg).astype(np.float64)
+        T = sp.csr_matrix((1.0 / np.sqrt(cnt[agg]), (np.arange(n), agg)), shape=(n, nagg))
+        omega = (4.0 / 3.0) / lv.rho
+        P = (T - sp.diags(omega * lv.dinv) @ (A @ T)).tocsr()
+        P.sort_indices()
+        lv.P = P
+        lv.R = P.T.tocsr()
+        lv.R.sort_indices()
+        A = (lv.R @ A @ P).tocsr()
+        A.sort_indices()
+    last = levels[-1]
+    last.pinv = np.linalg.pinv(last.A.toarray(), hermitian=True, rcond=1e-12)
+    return levels
+
+
+def cheb_coefficients(rho, degree, lower):
+    """Chebyshev polynomial smoother on D^-1 A for eigenvalues in [lower*rho, rho] (Saad, Alg. 12.1)."""
+    lmax, lmin = rho, lower * rho
+    theta, delta = 0.5 * (lmax + lmin), 0.5 * (lmax - lmin)
+    return theta, delta

@@ -65,6 +65,7 @@ class Solver:
         # Krylov caps: the reference sets ksp_max_it 1000 behind BoomerAMG (solver.py:429,687);
         # the block-Jacobi preconditioner here needs more, so the cap is a solver_params option.
         self.max_it_emi = 50000
+        self.use_amg = os.environ.get("KNP_NO_AMG", "0") != "1"
         self.max_it_knp = 5000
 
     # ------------------------------------------------------------------ setup_domain (solver.py:85-121)
@@ -246,7 +247,29 @@ class Solver:
 
     def setup_solver_emi(self):
         self._read_solver_params()
+        if self.use_amg and getattr(self, "nc_owned", None) is None:
+            self._setup_amg_emi()
         return
+
+    def _setup_amg_emi(self):
+        """Preconditioner setup (the reference builds BoomerAMG from BB_emi, solver.py:433, 505): conforming
+        P1 operator from the current kappa + smoothed-aggregation hierarchy, built on the host once and reused
+        across time steps."""
+        from knpemidg import amg
+        ts = time.perf_counter()
+        dev = self.dev
+        dev.update_kappa()
+        kappa = dev.download(_abi.F_KAPPA).reshape(self.mesh.num_cells(), self.nd)
+        if not hasattr(self, "_cspace"):
+            self._cspace = amg.ConformingSpace(self.mesh, self.surfaces.array(), self.membrane_tags)
+        ft = self.surfaces.array()
+        mem = np.nonzero((self.mesh.facet_cells[:, 1] >= 0) & np.isin(ft, self.membrane_tags))[0]
+        Ac = self._cspace.stiffness(kappa, membrane=(mem, _f(self.C_phi)))
+        levels = amg.build_hierarchy(Ac)
+        dev.amg_upload(0, self._cspace.dof, levels)
+        self.amg_setup_timer = time.perf_counter() - ts
+        if self.verbose:
+            print(" AMG(EMI) levels:", [lv.A.shape[0] for lv in levels], "setup %.2f s" % self.amg_setup_timer)
 
     def setup_solver_knp(self):
         return
