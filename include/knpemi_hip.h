@@ -121,6 +121,20 @@ int knp_nernst(knp_ctx* ctx);              /* E only, from the current C / C_ELI
  * species indexes into [n_sys] fields (update_ode hook, examples/idealized-geometries/run_3D.py:39-51). */
 int knp_facet_trace(knp_ctx* ctx, int field, int species, int side);
 
+/* ---- membrane ODEs: batched device integrator replacing the per-facet LSODA loop of
+ * MembraneModel.step_lsoda (membrane.py:84-119).  model: 1 = Hodgkin-Huxley + stimulus (mm_hh.py), 2 = without
+ * (mm_hh_no_stim.py).  Tables are [n][ns] states and [n][np] parameters in the reference's column layout.
+ *  knp_ode_create  : returns a handle >= 0; facets[n] = facet id of every ODE node
+ *  knp_ode_table   : what 0 = states, 1 = parameters; upload != 0 copies host -> device, else device -> host
+ *  knp_ode_exchange: table column <- facet field (to_facet = 0, set_state/set_parameter) or facet field <- table
+ *                    column (to_facet = 1, get_state/get_parameter); offset selects the row of [n_ions][nf] fields
+ *  knp_ode_step    : adaptive Dormand-Prince 5(4) from t0 to t0+dt per node; -4 if a node fails (assert success) */
+int knp_ode_create(knp_ctx* ctx, int model, int64_t n, const int32_t* facets, int ns, int np, const double* states,
+                   const double* params);
+int knp_ode_table(knp_ctx* ctx, int handle, int what, int upload, double* host);
+int knp_ode_exchange(knp_ctx* ctx, int handle, int what, int col, int field, int64_t offset, int to_facet);
+int knp_ode_step(knp_ctx* ctx, int handle, double t0, double dt, double rtol, double atol);
+
 /* ---- timing / sync ------------------------------------------------------------------------------ */
 int knp_sync(knp_ctx* ctx);
 int knp_timer_begin(knp_ctx* ctx);         /* records a HIP event on the context's stream */

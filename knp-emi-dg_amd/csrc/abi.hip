@@ -36,6 +36,14 @@ int dev_zeros(knp_ctx* c, double** dst, size_t n) {
 
 }  // namespace
 
+double* knp_field_ptr(knp_ctx* c, int field, int64_t* n) {
+    if (!c || field < 0 || field >= KNP_F_COUNT) return nullptr;
+    if (n) *n = F(c)->n[field];
+    return F(c)->f[field];
+}
+
+void ode_destroy_all(knp_ctx* c);
+
 AmgHierarchy* amg_slot(knp_ctx* c, int which) {
     if (which < 0 || which >= (int)c->amg.size()) return nullptr;
     return &c->amg[which];
@@ -185,6 +193,7 @@ void knp_ctx_destroy(knp_ctx* c) {
     hipSetDevice(c->device);
     hipDeviceSynchronize();
     for (auto& H : c->amg) amg_free(H);
+    ode_destroy_all(c);
     Fields* fl = g_fields[c];
     if (fl) {
         for (int i = 0; i < KNP_F_COUNT; ++i) hipFree(fl->f[i]);

@@ -504,6 +504,23 @@ int pcg_solve(knp_ctx* c, KrylovVecs& kv, double rtol, double atol, int maxit, i
                          : pcg_impl<3>(c, kv, rtol, atol, maxit, check_every, niter, res);
 }
 
+// out_s += P_s V_s(P_s^T in_s) for every species s with an armed hierarchy (slot 1 + s)
+template <int NV>
+static int knp_coarse_correction(knp_ctx* c, const VecDims& d, const double* in, double* out) {
+    if (c->nranks != 1) return 0;
+    const dim3 g1((unsigned)grid_for(c->m.nc_owned)), b(KNP_BLOCK);
+    for (int s = 0; s < d.nsys; ++s) {
+        if ((int)c->amg.size() <= 1 + s || !c->amg[1 + s].ready) continue;
+        AmgHierarchy& H = c->amg[1 + s];
+        const int64_t off = (int64_t)s * d.nc * NV;
+        amg_restrict_from_dg(c, H, in + off);
+        int rc = amg_vcycle(c, H);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_prolong_add<NV>, g1, b, 0, c->stream, d, c->status, s, H.dg2cg, H.levels[0].x, out + off);
+    }
+    return 0;
+}
+
 template <int NV>
 static int bicgstab_impl(knp_ctx* c, KrylovVecs& kv, double rtol, double atol, int maxit, int min_it, int check_every,
                          int* niter, double* res) {
@@ -523,12 +540,14 @@ static int bicgstab_impl(knp_ctx* c, KrylovVecs& kv, double rtol, double atol, i
         const int chunk = (maxit - it < check_every) ? (maxit - it) : check_every;
         for (int k = 0; k < chunk; ++k) {
             hipLaunchKernelGGL(k_bi_p<NV>, g, b, 0, c->stream, d, c->scal, c->status, kv.r, kv.v, kv.binv, kv.p, kv.y);
+            if ((rc = knp_coarse_correction<NV>(c, d, kv.p, kv.y))) return rc;
             if (c->nranks > 1 && (rc = halo_exchange(c, kv.y, ns))) return rc;
             if ((rc = launch_knp_apply(c, kv.y, kv.coef, kv.v))) return rc;
             hipLaunchKernelGGL(k_dot2<NV>, g, b, 0, c->stream, d, kv.rhat, kv.v, (const double*)nullptr, (const double*)nullptr,
                                c->partial, c->status);
             if ((rc = finalize(c, OP_BI_ALPHA, ns, 1, rtol, atol, min_it))) return rc;
             hipLaunchKernelGGL(k_bi_s<NV>, g, b, 0, c->stream, d, c->scal, c->status, kv.v, kv.binv, kv.r, kv.z);
+            if ((rc = knp_coarse_correction<NV>(c, d, kv.r, kv.z))) return rc;
             if (c->nranks > 1 && (rc = halo_exchange(c, kv.z, ns))) return rc;
             if ((rc = launch_knp_apply(c, kv.z, kv.coef, kv.w))) return rc;
             hipLaunchKernelGGL(k_dot2<NV>, g, b, 0, c->stream, d, kv.w, kv.r, kv.w, kv.w, c->partial, c->status);

@@ -1,0 +1,236 @@
+// Batched membrane ODE integrator: one thread per membrane facet, per-thread adaptive Dormand-Prince 5(4)
+// (same pair, step controller and tolerances as knpemidg/membrane.py:integrate_batch, which it replaces on
+// the device).  Every row carries its own time and step, so a facet's result does not depend on which other
+// facets share the launch (ranks that both hold a cut facet compute bitwise identical outputs).
+// Stands in for the per-facet numbalsoda.lsoda loop (reference: src/knpemidg/membrane.py:84-119) for the
+// membrane models of the idealized examples (reference: examples/idealized-geometries/mm_hh.py:118-161).
+#include "../../include/knpemi_hip.h"
+#include "knpemi_internal.hpp"
+
+#define ODE_MAX_STATES 4
+#define ODE_MAX_PARAMS 20
+
+struct OdeSet {
+    int model = 0;              // 1 = HH with synaptic stimulus, 2 = HH without
+    int ns = 0, np = 0;
+    int64_t n = 0;
+    int32_t* facet = nullptr;   // [n] facet id of every node
+    double* states = nullptr;   // [n][ns]
+    double* params = nullptr;   // [n][np]
+    double* h = nullptr;        // [n] last accepted step size
+    int* fail = nullptr;        // device flag
+};
+
+static std::map<knp_ctx*, std::vector<OdeSet>> g_ode;
+
+// Hodgkin-Huxley squid axon + leak + Na/K pump (+ decaying synaptic conductance), SI units.
+// parameter layout (mm_hh.py:56-64): 0 g_Na_bar 1 g_K_bar 2 g_leak_Na 3 g_leak_K 4 E_Na 5 E_K 6 Cm 7 stim_amplitude
+//  8 I_ch_Na 9 I_ch_K 10 I_ch_Cl 11 K_e 12 Na_i 13 m_K 14 m_Na 15 I_max 16 E_Cl ; states: m h n V
+template <bool STIM> __device__ __forceinline__ void hh_rhs(double t, const double* y, double* p, double* dy) {
+    const double m = y[0], h = y[1], n = y[2], V = y[3];
+    const double u = 1.0e3 * (V + 65.0e-3);
+    const double alpha_m = 0.1e3 * (25.0 - u) / (exp((25.0 - u) / 10.0) - 1.0);
+    const double beta_m = 4.0e3 * exp(-u / 18.0);
+    dy[0] = (1 - m) * alpha_m - m * beta_m;
+    const double alpha_h = 0.07e3 * exp(-u / 20.0);
+    const double beta_h = 1.0e3 / (exp((30.0 - u) / 10.0) + 1.0);
+    dy[1] = (1 - h) * alpha_h - h * beta_h;
+    const double alpha_n = 0.01e3 * (10.0 - u) / (exp((10.0 - u) / 10.0) - 1.0);
+    const double beta_n = 0.125e3 * exp(-u / 80.0);
+    dy[2] = (1 - n) * alpha_n - n * beta_n;
+    const double a = 1 + p[13] / p[11], b = 1 + p[14] / p[12];
+    const double i_pump = p[15] / (a * a * b * b * b);
+    double g_stim = 0.0;
+    if (STIM) g_stim = (t < 125e-3) ? p[7] * exp(-fmod(t, 0.03) / 0.002) : 0.0;
+    const double i_Na = (p[2] + p[0] * h * m * m * m + g_stim) * (V - p[4]) + 3 * i_pump;
+    const double n2 = n * n;
+    const double i_K = (p[3] + p[1] * n2 * n2) * (V - p[5]) - 2 * i_pump;
+    p[8] = i_Na;
+    p[9] = i_K;
+    p[10] = 0.0;
+    dy[3] = (-i_K - i_Na) / p[6];
+}
+
+template <int MODEL> __device__ __forceinline__ void model_rhs(double t, const double* y, double* p, double* dy) {
+    if (MODEL == 1) hh_rhs<true>(t, y, p, dy);
+    else hh_rhs<false>(t, y, p, dy);
+}
+
+template <int MODEL, int NS, int NP>
+__global__ __launch_bounds__(64) void k_ode_step(int64_t n, double t0, double t1, double rtol, double atol, int max_steps,
+                                                 double* __restrict__ states, double* __restrict__ params,
+                                                 double* __restrict__ hstore, int* __restrict__ fail) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double y[NS], p[NP], k[7][NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) y[s] = states[i * NS + s];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) p[q] = params[i * NP + q];
+    // Dormand-Prince 5(4)
+    const double C[7] = {0, 1.0 / 5, 3.0 / 10, 4.0 / 5, 8.0 / 9, 1, 1};
+    const double A[7][6] = {{0, 0, 0, 0, 0, 0},
+                            {1.0 / 5, 0, 0, 0, 0, 0},
+                            {3.0 / 40, 9.0 / 40, 0, 0, 0, 0},
+                            {44.0 / 45, -56.0 / 15, 32.0 / 9, 0, 0, 0},
+                            {19372.0 / 6561, -25360.0 / 2187, 64448.0 / 6561, -212.0 / 729, 0, 0},
+                            {9017.0 / 3168, -355.0 / 33, 46732.0 / 5247, 49.0 / 176, -5103.0 / 18656, 0},
+                            {35.0 / 384, 0, 500.0 / 1113, 125.0 / 192, -2187.0 / 6784, 11.0 / 84}};
+    const double B5[7] = {35.0 / 384, 0, 500.0 / 1113, 125.0 / 192, -2187.0 / 6784, 11.0 / 84, 0};
+    const double B4[7] = {5179.0 / 57600, 0, 7571.0 / 16695, 393.0 / 640, -92097.0 / 339200, 187.0 / 2100, 1.0 / 40};
+    double t = t0;
+    double h = hstore[i];
+    if (!(h > 0.0)) h = (t1 - t0) / 16;
+    const double tiny = 1e-14 * fmax(fabs(t1), 1e-30);
+    model_rhs<MODEL>(t, y, p, k[0]);
+    int steps = 0;
+    bool done = false;
+    while (!done && steps < max_steps) {
+        const double hh = fmin(h, t1 - t);
+#pragma unroll
+        for (int s = 1; s < 7; ++s) {
+            double ys[NS];
+#pragma unroll
+            for (int q = 0; q < NS; ++q) {
+                double acc = 0.0;
+#pragma unroll
+                for (int j = 0; j < 6; ++j)
+                    if (j < s) acc += A[s][j] * k[j][q];
+                ys[q] = y[q] + hh * acc;
+            }
+            model_rhs<MODEL>(t + C[s] * hh, ys, p, k[s]);
+        }
+        double e = 0.0, y5[NS];
+#pragma unroll
+        for (int q = 0; q < NS; ++q) {
+            double a5 = 0.0, ae = 0.0;
+#pragma unroll
+            for (int j = 0; j < 7; ++j) { a5 += B5[j] * k[j][q]; ae += (B5[j] - B4[j]) * k[j][q]; }
+            y5[q] = y[q] + hh * a5;
+            const double scale = atol + rtol * fmax(fabs(y[q]), fabs(y5[q]));
+            e = fmax(e, fabs(hh * ae) / scale);
+        }
+        if (!(e == e) || isinf(e)) e = 1e10;
+        ++steps;
+        if (e <= 1.0 || hh < tiny) {
+            t += hh;
+#pragma unroll
+            for (int q = 0; q < NS; ++q) { y[q] = y5[q]; k[0][q] = k[6][q]; }
+            if (t >= t1 - 1e-15 * fabs(t1)) done = true;
+        }
+        const double fac = fmin(5.0, fmax(0.2, 0.9 * pow(1.0 / fmax(e, 1e-10), 0.2)));
+        if (!done) h = hh * fac;
+    }
+    if (!done) atomicExch(fail, 1);
+    model_rhs<MODEL>(t1, y, p, k[0]);                 // leave I_ch_k evaluated at the end state
+#pragma unroll
+    for (int s = 0; s < NS; ++s) states[i * NS + s] = y[s];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) params[i * NP + q] = p[q];
+    hstore[i] = h;
+}
+
+// table[node][col] <- facet_field[facet[node]]   (PDE -> ODE, membrane.py:122-139)
+__global__ void k_ode_from_facet(int64_t n, const int32_t* __restrict__ facet, const double* __restrict__ field, int stride,
+                                 int col, double* __restrict__ table) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) table[i * stride + col] = field[facet[i]];
+}
+// facet_field[facet[node]] <- table[node][col]   (ODE -> PDE, membrane.py:141-162)
+__global__ void k_ode_to_facet(int64_t n, const int32_t* __restrict__ facet, const double* __restrict__ table, int stride,
+                               int col, double* __restrict__ field) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) field[facet[i]] = table[i * stride + col];
+}
+
+double* knp_field_ptr(knp_ctx* c, int field, int64_t* n);   // abi.hip
+
+static OdeSet* get_set(knp_ctx* c, int handle) {
+    auto it = g_ode.find(c);
+    if (it == g_ode.end() || handle < 0 || handle >= (int)it->second.size()) return nullptr;
+    return &it->second[handle];
+}
+
+void ode_destroy_all(knp_ctx* c) {
+    auto it = g_ode.find(c);
+    if (it == g_ode.end()) return;
+    for (auto& S : it->second) { hipFree(S.facet); hipFree(S.states); hipFree(S.params); hipFree(S.h); hipFree(S.fail); }
+    g_ode.erase(it);
+}
+
+extern "C" {
+
+int knp_ode_create(knp_ctx* c, int model, int64_t n, const int32_t* facets, int ns, int np, const double* states,
+                   const double* params) {
+    if (!c) return -1;
+    if (model != 1 && model != 2) { c->err = "ode: unknown device model id"; return -1; }
+    if (ns != 4 || np != 17) { c->err = "ode: HH models have 4 states and 17 parameters"; return -1; }
+    for (int64_t i = 0; i < n; ++i)
+        if (facets[i] < 0 || facets[i] >= c->m.nf) { c->err = "ode: facet id out of range"; return -1; }
+    OdeSet S;
+    S.model = model; S.ns = ns; S.np = np; S.n = n;
+    const size_t m = (size_t)(n ? n : 1);
+    HIPCHK(c, hipMalloc((void**)&S.facet, m * sizeof(int32_t)));
+    HIPCHK(c, hipMalloc((void**)&S.states, m * ns * sizeof(double)));
+    HIPCHK(c, hipMalloc((void**)&S.params, m * np * sizeof(double)));
+    HIPCHK(c, hipMalloc((void**)&S.h, m * sizeof(double)));
+    HIPCHK(c, hipMalloc((void**)&S.fail, sizeof(int)));
+    HIPCHK(c, hipMemset(S.h, 0, m * sizeof(double)));
+    HIPCHK(c, hipMemset(S.fail, 0, sizeof(int)));
+    if (n) {
+        HIPCHK(c, hipMemcpy(S.facet, facets, n * sizeof(int32_t), hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(S.states, states, n * ns * sizeof(double), hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(S.params, params, n * np * sizeof(double), hipMemcpyHostToDevice));
+    }
+    g_ode[c].push_back(S);
+    return (int)g_ode[c].size() - 1;
+}
+
+// what: 0 = states, 1 = parameters
+int knp_ode_table(knp_ctx* c, int handle, int what, int upload, double* host) {
+    OdeSet* S = get_set(c, handle);
+    if (!S || !host) return -1;
+    double* dev = what == 0 ? S->states : S->params;
+    const size_t bytes = (size_t)S->n * (what == 0 ? S->ns : S->np) * sizeof(double);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (bytes) HIPCHK(c, hipMemcpy(upload ? (void*)dev : (void*)host, upload ? (void*)host : (void*)dev, bytes,
+                                   upload ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// ODE table column <- device facet field (offset = row * nf for multi-row fields), or the reverse
+int knp_ode_exchange(knp_ctx* c, int handle, int what, int col, int field, int64_t offset, int to_facet) {
+    OdeSet* S = get_set(c, handle);
+    if (!S) return -1;
+    int64_t nfld = 0;
+    double* f = knp_field_ptr(c, field, &nfld);
+    const int stride = what == 0 ? S->ns : S->np;
+    if (!f || col < 0 || col >= stride || offset < 0 || offset + c->m.nf > nfld) { c->err = "ode_exchange: bad field / column"; return -1; }
+    if (!S->n) return 0;
+    double* table = what == 0 ? S->states : S->params;
+    const dim3 g((unsigned)((S->n + 255) / 256)), b(256);
+    if (to_facet) hipLaunchKernelGGL(k_ode_to_facet, g, b, 0, c->stream, S->n, S->facet, table, stride, col, f + offset);
+    else hipLaunchKernelGGL(k_ode_from_facet, g, b, 0, c->stream, S->n, S->facet, f + offset, stride, col, table);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
+int knp_ode_step(knp_ctx* c, int handle, double t0, double dt, double rtol, double atol) {
+    OdeSet* S = get_set(c, handle);
+    if (!S) return -1;
+    if (!S->n) return 0;
+    const dim3 g((unsigned)((S->n + 63) / 64)), b(64);
+    const int max_steps = 100000;
+    if (S->model == 1)
+        hipLaunchKernelGGL((k_ode_step<1, 4, 17>), g, b, 0, c->stream, S->n, t0, t0 + dt, rtol, atol, max_steps, S->states, S->params, S->h, S->fail);
+    else
+        hipLaunchKernelGGL((k_ode_step<2, 4, 17>), g, b, 0, c->stream, S->n, t0, t0 + dt, rtol, atol, max_steps, S->states, S->params, S->h, S->fail);
+    HIPCHK(c, hipGetLastError());
+    int fail = 0;
+    HIPCHK(c, hipMemcpyAsync(&fail, S->fail, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (fail) { c->err = "ODE integrator did not reach the end time"; return -4; }   // `assert success`, membrane.py:113
+    return 0;
+}
+
+}  // extern "C"

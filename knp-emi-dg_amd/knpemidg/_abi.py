@@ -52,6 +52,10 @@ SIGNATURES = {
     "knp_comm_init": (C.c_int, [_ctxp, C.c_int, C.c_int, C.c_char_p]),
     "knp_halo_tables": (C.c_int, [_ctxp, C.c_int, _i32p, _i64p, _i32p, _i64p, _i64p]),
     "knp_halo_exchange": (C.c_int, [_ctxp, C.c_int]),
+    "knp_ode_create": (C.c_int, [_ctxp, C.c_int, C.c_int64, _i32p, C.c_int, C.c_int, _f64p, _f64p]),
+    "knp_ode_table": (C.c_int, [_ctxp, C.c_int, C.c_int, C.c_int, _f64p]),
+    "knp_ode_exchange": (C.c_int, [_ctxp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int]),
+    "knp_ode_step": (C.c_int, [_ctxp, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double]),
     "knp_amg_begin": (C.c_int, [_ctxp, C.c_int, C.c_int64, _i32p, _i32p, _i32p]),
     "knp_amg_level": (C.c_int, [_ctxp, C.c_int, C.c_int64, _i32p, _i32p, _f64p, _f64p, C.c_double, C.c_int, C.c_double,
                                 C.c_int64, _i32p, _i32p, _f64p, _i32p, _i32p, _f64p]),
@@ -260,9 +264,9 @@ class Device:
     def nernst(self):
         self._chk(self.lib.knp_nernst(self.ctx), "knp_nernst")
 
-    def facet_trace(self, field, species, side):
+    def facet_trace(self, field, species, side, download=True):
         self._chk(self.lib.knp_facet_trace(self.ctx, field, species, side), "knp_facet_trace")
-        return self.download(F_FACET_TMP)
+        return self.download(F_FACET_TMP) if download else None
 
     def sync(self):
         self._chk(self.lib.knp_sync(self.ctx), "knp_sync")
@@ -293,6 +297,29 @@ class Device:
         rcnt = np.ascontiguousarray(recv_counts, dtype=np.int64)
         self._chk(self.lib.knp_halo_tables(self.ctx, len(peers), _p(peers, _i32p), _p(sc, _i64p), _p(cells, _i32p),
                                            _p(ro, _i64p), _p(rcnt, _i64p)), "knp_halo_tables")
+
+    # -- membrane ODEs on the device ------------------------------------------------------
+    def ode_create(self, model, facets, states, params):
+        facets = np.ascontiguousarray(facets, dtype=np.int32)
+        states = np.ascontiguousarray(states, dtype=np.float64)
+        params = np.ascontiguousarray(params, dtype=np.float64)
+        h = self.lib.knp_ode_create(self.ctx, int(model), len(facets), _p(facets, _i32p), states.shape[1], params.shape[1],
+                                    _p(states, _f64p), _p(params, _f64p))
+        if h < 0:
+            self._chk(h, "knp_ode_create")
+        return h
+
+    def ode_table(self, handle, what, shape, upload=None):
+        a = np.empty(shape, dtype=np.float64) if upload is None else np.ascontiguousarray(upload, dtype=np.float64)
+        self._chk(self.lib.knp_ode_table(self.ctx, handle, what, 0 if upload is None else 1, _p(a, _f64p)), "knp_ode_table")
+        return a
+
+    def ode_exchange(self, handle, what, col, field, row, to_facet):
+        self._chk(self.lib.knp_ode_exchange(self.ctx, handle, what, int(col), field, int(row) * self.nf, int(to_facet)),
+                  "knp_ode_exchange")
+
+    def ode_step(self, handle, t0, dt, rtol=1.0e-8, atol=1.0e-12):
+        self._chk(self.lib.knp_ode_step(self.ctx, handle, t0, dt, rtol, atol), "knp_ode_step")
 
     # -- auxiliary-space AMG (knpemidg/amg.py builds, csrc/amg.hip applies) ------------------
     def amg_upload(self, which, dg2cg, levels):

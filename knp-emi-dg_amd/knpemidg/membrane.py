@@ -102,13 +102,54 @@ class MembraneModel:
         self.dof_locations = V.tabulate_dof_coordinates()[self.indices]
         nodes = len(self.indices)
         self.nodes = nodes
-        self.states = np.array([ode.init_state_values() for _ in range(nodes)], dtype=np.float64)
-        self.parameters = np.array([ode.init_parameter_values() for _ in range(nodes)], dtype=np.float64)
+        self._states = np.array([ode.init_state_values() for _ in range(nodes)], dtype=np.float64).reshape(nodes, -1)
+        self._parameters = np.array([ode.init_parameter_values() for _ in range(nodes)], dtype=np.float64).reshape(nodes, -1)
         self.tag = tag
         self.ode = ode
         self.prefix = getattr(ode, "__name__", "ode")
         self.time = 0
         self._h = None
+        self._dev = None
+        self._handle = None
+        self._stim_applied = None
+
+    # --- device backing: tables live on the GPU, the batched HIP integrator steps them (csrc/ode.hip) ---
+    def attach_device(self, dev):
+        """Move the ODE tables to the device if the model has a device implementation (ode.MODEL_ID)."""
+        if getattr(self.ode, "MODEL_ID", None) is None:
+            return False
+        self._handle = dev.ode_create(self.ode.MODEL_ID, self.indices, self._states, self._parameters)
+        self._dev = dev
+        return True
+
+    @property
+    def on_device(self):
+        return self._dev is not None
+
+    @property
+    def states(self):
+        """ODE states [nodes, n_states] (a snapshot when device backed; assign the whole array to write)."""
+        if self.on_device:
+            return self._dev.ode_table(self._handle, 0, self._states.shape)
+        return self._states
+
+    @states.setter
+    def states(self, a):
+        self._states = np.ascontiguousarray(a, dtype=np.float64).reshape(self._states.shape)
+        if self.on_device:
+            self._dev.ode_table(self._handle, 0, self._states.shape, upload=self._states)
+
+    @property
+    def parameters(self):
+        if self.on_device:
+            return self._dev.ode_table(self._handle, 1, self._parameters.shape)
+        return self._parameters
+
+    @parameters.setter
+    def parameters(self, a):
+        self._parameters = np.ascontiguousarray(a, dtype=np.float64).reshape(self._parameters.shape)
+        if self.on_device:
+            self._dev.ode_table(self._handle, 1, self._parameters.shape, upload=self._parameters)
 
     # --- ODE <- PDE
     def set_state(self, which, u, locator=None):
@@ -146,14 +187,27 @@ class MembraneModel:
             stimulus = {}
         if stimulus_locator is None:
             stimulus_locator = lambda x: True
+        if self.on_device:
+            # the stimulus overwrites the same parameter entries every step (membrane.py:102-104): apply once
+            sig = (tuple(sorted(stimulus.items())), id(stimulus_locator))
+            if sig != self._stim_applied and stimulus:
+                mask = np.fromiter(map(stimulus_locator, self.dof_locations), dtype=bool, count=self.nodes)
+                p = self.parameters
+                for key, value in stimulus.items():
+                    p[mask, self.ode.parameter_indices(key)] = value
+                self.parameters = p
+            self._stim_applied = sig
+            self._dev.ode_step(self._handle, float(self.time), float(dt), rtol=1.0e-8, atol=1.0e-12)
+            self.time = self.time + dt
+            return None
         mask = np.fromiter(map(stimulus_locator, self.dof_locations), dtype=bool, count=self.nodes)
         for key, value in stimulus.items():
-            self.parameters[mask, self.ode.parameter_indices(key)] = value
+            self._parameters[mask, self.ode.parameter_indices(key)] = value
         if self.nodes:
-            self.states, self._h = integrate_batch(self.ode.rhs, self.time, self.time + dt, self.states,
-                                                   self.parameters, rtol=1.0e-8, h0=self._h)
+            self._states, self._h = integrate_batch(self.ode.rhs, self.time, self.time + dt, self._states,
+                                                    self._parameters, rtol=1.0e-8, h0=self._h)
         self.time = self.time + dt
-        return self.states
+        return self._states
 
     # --- work horses (membrane.py:122-186)
     def _lidx(self, locator):
@@ -162,20 +216,43 @@ class MembraneModel:
             lidx = lidx[np.fromiter(map(locator, self.dof_locations), dtype=bool, count=self.nodes)]
         return lidx
 
+    def _device_field(self, u):
+        """(field, row) if `u` lives in a facet field of this model's device, else None."""
+        if self.on_device and getattr(u, "dev", None) is self._dev and hasattr(u, "field"):
+            return u.field, getattr(u, "row", 0)
+        return None
+
     def __set_ODE(self, what, which, u, locator=None):
-        get_index, destination = {'state': (self.ode.state_indices, self.states),
-                                  'parameter': (self.ode.parameter_indices, self.parameters)}[what]
+        get_index = {'state': self.ode.state_indices, 'parameter': self.ode.parameter_indices}[what]
         the_index = get_index(which)
+        if self.on_device and locator is None:
+            from knpemidg import _abi
+            loc = self._device_field(u)
+            if loc is None:                                     # host data: stage through the facet scratch field
+                self._dev.upload(_abi.F_FACET_TMP, u.array() if hasattr(u, "array") else np.asarray(u))
+                loc = (_abi.F_FACET_TMP, 0)
+            self._dev.ode_exchange(self._handle, 0 if what == 'state' else 1, the_index, loc[0], loc[1], to_facet=0)
+            return None
+        destination = self.states if what == 'state' else self.parameters
         lidx = self._lidx(locator)
         source = u.array() if hasattr(u, "array") else np.asarray(u)
         if len(lidx) > 0:
             destination[lidx, the_index] = source[self.indices[lidx]]
-        return self.states
+        if self.on_device:
+            if what == 'state':
+                self.states = destination
+            else:
+                self.parameters = destination
+        return destination
 
     def __get_PDE(self, what, which, u, locator=None):
-        get_index, source = {'state': (self.ode.state_indices, self.states),
-                             'parameter': (self.ode.parameter_indices, self.parameters)}[what]
+        get_index = {'state': self.ode.state_indices, 'parameter': self.ode.parameter_indices}[what]
         the_index = get_index(which)
+        loc = self._device_field(u)
+        if loc is not None and locator is None:
+            self._dev.ode_exchange(self._handle, 0 if what == 'state' else 1, the_index, loc[0], loc[1], to_facet=1)
+            return u
+        source = self.states if what == 'state' else self.parameters
         lidx = self._lidx(locator)
         destination = np.array(u.array(), dtype=np.float64, copy=True)
         if len(lidx) > 0:
@@ -184,8 +261,8 @@ class MembraneModel:
         return u
 
     def __set_ODE_values(self, what, value_dict, locator=None):
-        destination, get_col = {'state': (self.states, self.ode.state_indices),
-                                'parameter': (self.parameters, self.ode.parameter_indices)}[what]
+        destination = self.states if what == 'state' else self.parameters
+        get_col = self.ode.state_indices if what == 'state' else self.ode.parameter_indices
         lidx = self._lidx(locator)
         if len(lidx) == 0:
             return destination
@@ -195,4 +272,9 @@ class MembraneModel:
             get_value = value_dict[param]
             for row, x in zip(lidx, coords):
                 destination[row, col] = get_value(x)
+        if self.on_device:
+            if what == 'state':
+                self.states = destination
+            else:
+                self.parameters = destination
         return destination

@@ -66,6 +66,7 @@ class Solver:
         # the block-Jacobi preconditioner here needs more, so the cap is a solver_params option.
         self.max_it_emi = 50000
         self.use_amg = os.environ.get("KNP_NO_AMG", "0") != "1"
+        self.use_device_ode = os.environ.get("KNP_HOST_ODE", "0") != "1"
         self.max_it_knp = 5000
 
     # ------------------------------------------------------------------ setup_domain (solver.py:85-121)
@@ -185,9 +186,10 @@ class Solver:
         for tag, ode in odes.items():
             ode_model = MembraneModel(ode, facet_f=self.surfaces, tag=int(tag), V=self.Q)
             ode_model.set_parameter_values({'Cm': lambda x: self.params.C_M})
+            on_dev = self.use_device_ode and ode_model.attach_device(self.dev)
             I_ch_k = {}
             for i, ion in enumerate(self.ion_list):
-                I_ch_k_ = FacetFunction(self.Q)
+                I_ch_k_ = DeviceFacetFunction(self.Q, self.dev, _abi.F_I_CH, row=i) if on_dev else FacetFunction(self.Q)
                 ode_model.get_parameter("I_ch_" + ion['name'], I_ch_k_)
                 I_ch_k[ion['name']] = I_ch_k_
             self.mem_models.append({'ode': ode_model, 'I_ch_k': I_ch_k})
@@ -272,7 +274,25 @@ class Solver:
             print(" AMG(EMI) levels:", [lv.A.shape[0] for lv in levels], "setup %.2f s" % self.amg_setup_timer)
 
     def setup_solver_knp(self):
+        if self.use_amg and getattr(self, "nc_owned", None) is None:
+            self._setup_amg_knp()
         return
+
+    def _setup_amg_knp(self):
+        """Preconditioner of the KNP systems (reference: BoomerAMG on AA_knp, solver.py:688, 767): per species the
+        conforming-P1 operator  1/dt M + D_k K  (symmetric part; the drift enters only the Krylov operator)."""
+        from knpemidg import amg
+        ts = time.perf_counter()
+        if not hasattr(self, "_cspace"):
+            self._cspace = amg.ConformingSpace(self.mesh, self.surfaces.array(), self.membrane_tags)
+        nc = self.mesh.num_cells()
+        for k, ion in enumerate(self.ion_list[:-1]):
+            Ac = self._cspace.stiffness(ion['D'], mass_coef=np.full(nc, 1.0 / _f(self.dt)))
+            levels = amg.build_hierarchy(Ac)
+            self.dev.amg_upload(1 + k, self._cspace.dof, levels)
+            if self.verbose:
+                print(" AMG(KNP %s) levels:" % ion['name'], [lv.A.shape[0] for lv in levels])
+        self.amg_setup_timer = getattr(self, "amg_setup_timer", 0.0) + time.perf_counter() - ts
 
     def _read_solver_params(self):
         sp = getattr(self, "solver_params", None)
@@ -287,12 +307,16 @@ class Solver:
 
     def _sync_membrane_to_device(self):
         """phi_M and I_ch_k facet fields produced by the ODE step -> device."""
-        if not self.mem_models:
+        if not self.mem_models or all(mm['ode'].on_device for mm in self.mem_models):
             return
         A = _abi
         nf = self.mesh.num_facets()
         Ich = np.zeros((len(self.ion_list), nf))
+        if any(mm['ode'].on_device for mm in self.mem_models):
+            Ich = self.dev.download(A.F_I_CH).reshape(len(self.ion_list), nf)
         for mm in self.mem_models:
+            if mm['ode'].on_device:
+                continue
             idx = mm['ode'].indices
             for k, ion in enumerate(self.ion_list):
                 Ich[k, idx] = mm['I_ch_k'][ion['name']].array()[idx]

@@ -89,11 +89,14 @@ def pcws_constant_project(f, V, fV=None):
     u = f.f
     if not isinstance(u, DeviceFunction):
         raise NotImplementedError("pcws_constant_project expects a device-backed nodal function")
-    vals = u.dev.facet_trace(u.field, u.component, f.side)
-    if fV is None:
-        fV = FacetFunction(V)
-    fV.vector()[:] = vals
-    return fV
+    from knpemidg import _abi
+    from knpemidg.functions import DeviceFacetFunction
+    u.dev.facet_trace(u.field, u.component, f.side, download=False)
+    out = DeviceFacetFunction(V, u.dev, _abi.F_FACET_TMP)     # lives in the device's facet scratch field: consume it
+    if fV is not None:                                        # before the next projection (every reference hook does)
+        fV.assign(out)
+        return fV
+    return out
 
 
 def CellCenterDistance(mesh):

@@ -131,3 +131,41 @@ def test_amg_vcycle_matches_reference_and_cuts_iterations(hip_lib):
     assert relerr(mean_free(phi_amg, vol), mean_free(phi_bj, vol)) < 1e-5
     assert n_amg * 10 < n_bj, (n_amg, n_bj)
     dev.close()
+
+
+def test_device_ode_matches_host(hip_lib):
+    """Batched HIP Dormand-Prince integrator (csrc/ode.hip) vs the host numpy integrator on the HH model with a
+    spatially varying stimulus: same pair, controller and tolerances -> agreement far below rtol 1e-8 * steps."""
+    from knpemidg import _abi as A
+    from knpemidg.mesh import make_mesh_2D
+    from knpemidg.functions import FacetSpace, FacetFunction
+    from knpemidg.membrane import MembraneModel
+    from knpemidg.models import mm_hh
+    m, s, f = make_mesh_2D(1)
+    pb = ko.build_idealized(m, s.array(), f.array(), membrane_tags=(1,))
+    dev = device_for(pb)
+    Q = FacetSpace(m)
+    models = []
+    for on_dev in (False, True):
+        mm = MembraneModel(mm_hh, facet_f=f, tag=1, V=Q)
+        mm.set_parameter_values({'Cm': lambda x: 0.02})
+        if on_dev:
+            assert mm.attach_device(dev)
+        for name, val in (('K_e', 3.32), ('Na_i', 12.8), ('E_K', -0.0936), ('E_Na', 0.0533)):
+            mm.set_parameter(name, FacetFunction(Q, np.full(Q.dim(), val)))
+        models.append(mm)
+    for k in range(10):
+        for mm in models:
+            mm.step_lsoda(dt=1e-4, stimulus={'stim_amplitude': 40.0}, stimulus_locator=lambda x: x[0] < 20e-6)
+    sh, sd = models[0].states, models[1].states
+    ph, pd = models[0].parameters, models[1].parameters
+    assert np.abs(sh - sd).max() < 1e-9 * np.abs(sh).max()
+    assert np.abs(ph[:, 8:10] - pd[:, 8:10]).max() < 1e-8 * np.abs(ph[:, 8:10]).max()
+    assert sh[:, 3].max() > -0.07                                  # stimulated nodes depolarised
+    # ODE -> PDE scatter lands on the right facets
+    dev.upload(A.F_PHI_M, np.zeros(Q.dim()))
+    from knpemidg.functions import DeviceFacetFunction
+    models[1].get_membrane_potential(DeviceFacetFunction(Q, dev, A.F_PHI_M))
+    out = dev.download(A.F_PHI_M)
+    assert np.allclose(out[models[1].indices], sd[:, 3]) and (np.delete(out, models[1].indices) == 0).all()
+    dev.close()
