@@ -149,7 +149,9 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "3D idealized 4-axon mesh r=%d (%d tets, %d P1-DG DoFs: phi + K,Cl solved, Na eliminated), "
                                    "HH membranes + stimulus, full splitting step" % (r, nc_global, dofs),
-                       "parallelism": "slab%d" % world, "preconditioner": "cell-block-Jacobi",
+                       "parallelism": "slab%d" % world,
+                       "preconditioner": "cell-block-Jacobi + conforming-P1 smoothed-aggregation AMG V-cycle" if S.use_amg
+                       else "cell-block-Jacobi",
                        "emi_iters_per_step": float(np.mean(S.emi_niter[-args.steps:])),
                        "knp_iters_per_step": float(np.mean([max(n) for n in S.knp_niter[-args.steps:]])),
                        "emi_solve_s": S.emi_solve_timer, "knp_solve_s": S.knp_solve_timer,

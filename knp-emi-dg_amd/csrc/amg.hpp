@@ -26,6 +26,8 @@ struct AmgHierarchy {
     int32_t *cg_ptr = nullptr, *cg_idx = nullptr;   // CSR list: conforming dof -> DG dofs (owned cells only)
     std::vector<AmgLevel> levels;
     double* pinv = nullptr;         // dense pseudo-inverse of the coarsest level
+    void* graph_exec = nullptr;     // hipGraphExec_t of one V-cycle (fixed kernel sequence on fixed buffers)
+    bool graph_tried = false;
 };
 
 struct knp_ctx;

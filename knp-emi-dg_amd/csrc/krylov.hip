@@ -447,15 +447,15 @@ static int pcg_impl(knp_ctx* c, KrylovVecs& kv, double rtol, double atol, int ma
     int rc;
     if (c->nranks > 1 && (rc = halo_exchange(c, kv.x, 1))) return rc;
     if ((rc = launch_emi_apply(c, kv.x, kv.coef, kv.w))) return rc;
-    AmgHierarchy* H = (c->amg.size() && c->amg[0].ready && c->nranks == 1) ? &c->amg[0] : nullptr;
+    AmgHierarchy* H = (c->amg.size() && c->amg[0].ready) ? &c->amg[0] : nullptr;
     hipLaunchKernelGGL(k_cg_init<NV>, g, b, 0, c->stream, d, kv.b, kv.w, kv.binv, kv.r, kv.z, kv.p, c->partial);
     if (H) {
         // z = Binv r + P V(P^T r) ; reference norm uses the same preconditioner on b (stored in y)
         hipLaunchKernelGGL(k_bj_apply<NV>, g, b, 0, c->stream, d, kv.binv, kv.b, kv.y);
-        amg_restrict_from_dg(c, *H, kv.b);
+        if ((rc = amg_restrict_from_dg(c, *H, kv.b))) return rc;
         if ((rc = amg_vcycle(c, *H))) return rc;
         HIPCHK(c, hipMemcpyAsync(kv.v, H->levels[0].x, sizeof(double) * H->ncg, hipMemcpyDeviceToDevice, c->stream));
-        amg_restrict_from_dg(c, *H, kv.r);
+        if ((rc = amg_restrict_from_dg(c, *H, kv.r))) return rc;
         if ((rc = amg_vcycle(c, *H))) return rc;
         hipLaunchKernelGGL((k_prolong_dot<NV, 3>), g, b, 0, c->stream, d, c->status, 0, H->dg2cg, H->levels[0].x, kv.r, kv.z,
                            kv.v, kv.y, c->partial);
@@ -476,7 +476,7 @@ static int pcg_impl(knp_ctx* c, KrylovVecs& kv, double rtol, double atol, int ma
             hipLaunchKernelGGL(k_cg_update<NV>, g, b, 0, c->stream, d, c->scal, c->status, kv.p, kv.w, kv.binv, kv.x, kv.r, kv.z,
                                c->partial);
             if (H) {
-                amg_restrict_from_dg(c, *H, kv.r);
+                if ((rc = amg_restrict_from_dg(c, *H, kv.r))) return rc;
                 if ((rc = amg_vcycle(c, *H))) return rc;
                 hipLaunchKernelGGL((k_prolong_dot<NV, 2>), g, b, 0, c->stream, d, c->status, 1, H->dg2cg, H->levels[0].x, kv.r,
                                    kv.z, (const double*)nullptr, (double*)nullptr, c->partial);
@@ -507,15 +507,14 @@ int pcg_solve(knp_ctx* c, KrylovVecs& kv, double rtol, double atol, int maxit, i
 // out_s += P_s V_s(P_s^T in_s) for every species s with an armed hierarchy (slot 1 + s)
 template <int NV>
 static int knp_coarse_correction(knp_ctx* c, const VecDims& d, const double* in, double* out) {
-    if (c->nranks != 1) return 0;
     const dim3 g1((unsigned)grid_for(c->m.nc_owned)), b(KNP_BLOCK);
     for (int s = 0; s < d.nsys; ++s) {
         if ((int)c->amg.size() <= 1 + s || !c->amg[1 + s].ready) continue;
         AmgHierarchy& H = c->amg[1 + s];
         const int64_t off = (int64_t)s * d.nc * NV;
-        amg_restrict_from_dg(c, H, in + off);
-        int rc = amg_vcycle(c, H);
+        int rc = amg_restrict_from_dg(c, H, in + off);
         if (rc) return rc;
+        if ((rc = amg_vcycle(c, H))) return rc;
         hipLaunchKernelGGL(k_prolong_add<NV>, g1, b, 0, c->stream, d, c->status, s, H.dg2cg, H.levels[0].x, out + off);
     }
     return 0;

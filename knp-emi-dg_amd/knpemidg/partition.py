@@ -152,6 +152,7 @@ def make_distributed_solver(dim, resolution, rank, world, local_rank, dist, n_ax
     S.nc_owned = loc.nc_owned
     S.global_num_cells = mesh.num_cells()
     S.local_mesh = loc
+    S.global_mesh_tuple = mesh_tuple
     S.setup_domain(loc.mesh, sub_l, surf_l)
     S.setup_parameters()
     S.setup_FEM_spaces()

@@ -249,7 +249,7 @@ class Solver:
 
     def setup_solver_emi(self):
         self._read_solver_params()
-        if self.use_amg and getattr(self, "nc_owned", None) is None:
+        if self.use_amg:
             self._setup_amg_emi()
         return
 
@@ -260,36 +260,66 @@ class Solver:
         from knpemidg import amg
         ts = time.perf_counter()
         dev = self.dev
-        dev.update_kappa()
-        kappa = dev.download(_abi.F_KAPPA).reshape(self.mesh.num_cells(), self.nd)
-        if not hasattr(self, "_cspace"):
-            self._cspace = amg.ConformingSpace(self.mesh, self.surfaces.array(), self.membrane_tags)
-        ft = self.surfaces.array()
-        mem = np.nonzero((self.mesh.facet_cells[:, 1] >= 0) & np.isin(ft, self.membrane_tags))[0]
+        gmesh, gsub, gsurf = self._amg_global()
+        if gmesh is self.mesh:
+            dev.update_kappa()
+            kappa = dev.download(_abi.F_KAPPA).reshape(self.mesh.num_cells(), self.nd)
+        else:
+            # distributed: every rank builds the SAME global hierarchy from the tag-wise initial state (no
+            # communication; the preconditioner is lagged anyway)
+            kappa = np.zeros(gmesh.num_cells())
+            for ion in self.ion_list:
+                if ion['c_init_sub_type'] != 'constant':
+                    raise NotImplementedError("distributed AMG setup needs tag-wise constant initial concentrations")
+                D = self._by_tag(ion['D_sub'], gsub)
+                c0 = self._by_tag(ion['c_init_sub'], gsub)
+                kappa += _f(self.F) * float(ion['z']) ** 2 * self.psi * D * c0
+        ft = gsurf.array()
+        mem = np.nonzero((gmesh.facet_cells[:, 1] >= 0) & np.isin(ft, self.membrane_tags))[0]
         Ac = self._cspace.stiffness(kappa, membrane=(mem, _f(self.C_phi)))
         levels = amg.build_hierarchy(Ac)
-        dev.amg_upload(0, self._cspace.dof, levels)
+        dev.amg_upload(0, self._local_dg2cg(), levels)
         self.amg_setup_timer = time.perf_counter() - ts
         if self.verbose:
             print(" AMG(EMI) levels:", [lv.A.shape[0] for lv in levels], "setup %.2f s" % self.amg_setup_timer)
 
     def setup_solver_knp(self):
-        if self.use_amg and getattr(self, "nc_owned", None) is None:
+        if self.use_amg:
             self._setup_amg_knp()
         return
+
+    def _amg_global(self):
+        """(mesh, subdomains, surfaces) the conforming hierarchy is built on: the global mesh when this solver
+        holds one partition of it (make_distributed_solver), else its own mesh."""
+        from knpemidg import amg
+        g = getattr(self, "global_mesh_tuple", None) or (self.mesh, self.subdomains, self.surfaces)
+        if not hasattr(self, "_cspace"):
+            self._cspace = amg.ConformingSpace(g[0], g[2].array(), self.membrane_tags)
+        return g
+
+    def _local_dg2cg(self):
+        loc = getattr(self, "local_mesh", None)
+        return self._cspace.dof if loc is None else self._cspace.dof[loc.cells_global]
+
+    @staticmethod
+    def _by_tag(d, subdomains):
+        tags = subdomains.array()
+        q = np.zeros(len(tags), dtype=np.float64)
+        for key, value in d.items():
+            q[tags == int(key)] = float(value)
+        return q
 
     def _setup_amg_knp(self):
         """Preconditioner of the KNP systems (reference: BoomerAMG on AA_knp, solver.py:688, 767): per species the
         conforming-P1 operator  1/dt M + D_k K  (symmetric part; the drift enters only the Krylov operator)."""
         from knpemidg import amg
         ts = time.perf_counter()
-        if not hasattr(self, "_cspace"):
-            self._cspace = amg.ConformingSpace(self.mesh, self.surfaces.array(), self.membrane_tags)
-        nc = self.mesh.num_cells()
+        gmesh, gsub, gsurf = self._amg_global()
+        nc = gmesh.num_cells()
         for k, ion in enumerate(self.ion_list[:-1]):
-            Ac = self._cspace.stiffness(ion['D'], mass_coef=np.full(nc, 1.0 / _f(self.dt)))
+            Ac = self._cspace.stiffness(self._by_tag(ion['D_sub'], gsub), mass_coef=np.full(nc, 1.0 / _f(self.dt)))
             levels = amg.build_hierarchy(Ac)
-            self.dev.amg_upload(1 + k, self._cspace.dof, levels)
+            self.dev.amg_upload(1 + k, self._local_dg2cg(), levels)
             if self.verbose:
                 print(" AMG(KNP %s) levels:" % ion['name'], [lv.A.shape[0] for lv in levels])
         self.amg_setup_timer = getattr(self, "amg_setup_timer", 0.0) + time.perf_counter() - ts

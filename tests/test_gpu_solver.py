@@ -169,3 +169,39 @@ def test_device_ode_matches_host(hip_lib):
     out = dev.download(A.F_PHI_M)
     assert np.allclose(out[models[1].indices], sd[:, 3]) and (np.delete(out, models[1].indices) == 0).all()
     dev.close()
+
+
+def test_distributed_setup_path_world1(hip_lib):
+    """make_distributed_solver with a single rank walks the whole distributed code path except the RCCL calls
+    (partition -> local mesh -> owned/ghost device context -> replicated global AMG hierarchy built from the
+    tag-wise initial state) and must reproduce the plain single-GPU solver."""
+    from common_examples import make_solver, solver_parameters, Constant
+    from knpemidg.partition import make_distributed_solver
+    from knpemidg.mesh import make_mesh_3D
+
+    class FakeDist:
+        @staticmethod
+        def broadcast_object_list(lst, src=0):
+            return None
+    out = []
+    for distributed in (False, True):
+        mt = make_mesh_3D(0, n_axons=1)
+        if distributed:
+            S = make_distributed_solver(3, 0, rank=0, world=1, local_rank=0, dist=FakeDist, n_axons=1, mesh_tuple=mt)
+        else:
+            S = make_solver(dim=3, resolution=0, n_axons=1, mesh_tuple=mt)
+        S._unpack_solver_params(solver_parameters(3, 0))
+        S.save_fields = S.save_solver_stats = False
+        S.splitting_scheme = True
+        S.setup_varform_emi(); S.setup_varform_knp(); S.setup_solver_emi(); S.setup_solver_knp()
+        t = Constant(0.0)
+        for k in range(2):
+            S.step_membrane_models(k)
+            S.solve_for_time_step(k, t)
+        phi = S.phi.array()
+        out.append((phi - phi.mean(), S.c.array(), S.phi_M_prev_PDE.array(), list(S.emi_niter)))
+        S.dev.close()
+    assert relerr(out[1][0], out[0][0]) < 1e-4          # both solved to rtol 1e-5 with (slightly) different AMG setups
+    assert relerr(out[1][1], out[0][1]) < 1e-6
+    assert relerr(out[1][2], out[0][2]) < 1e-4
+    assert max(out[1][3]) < 200 and max(out[0][3]) < 200   # AMG active in both
