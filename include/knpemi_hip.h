@@ -69,6 +69,11 @@ int knp_set_params(knp_ctx* ctx, double C_M, double dt, double F, double R, doub
                    double tau_emi, double tau_knp, const double* z, const double* D, const double* rho,
                    const double* fsrc, int splitting);
 
+/* Optional geometry classes for (block-)structured meshes: cells with identical shape and neighbour-apex
+ * positions share one 36-double record {vol, G upper triangle (10), per facet: L[4], sqrt(G_ii), 2/(h+h')}; the
+ * operator applies then read no coordinates at all.  ncls = 0 switches back to the coordinate path. */
+int knp_set_geometry_classes(knp_ctx* ctx, int ncls, const uint16_t* cls, const double* table);
+
 int64_t knp_field_size(knp_ctx* ctx, int field);
 int knp_upload(knp_ctx* ctx, int field, const double* src, int64_t offset, int64_t count);
 int knp_download(knp_ctx* ctx, int field, double* dst, int64_t offset, int64_t count);

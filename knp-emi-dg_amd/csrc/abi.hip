@@ -202,7 +202,7 @@ void knp_ctx_destroy(knp_ctx* c) {
         delete fl;
         g_fields.erase(c);
     }
-    hipFree(c->m.coords); hipFree(c->m.h); hipFree(c->m.cells); hipFree(c->m.nbr); hipFree(c->m.fflag); hipFree(c->m.cfacet); hipFree(c->m.mf);
+    hipFree(c->m.cls); hipFree(c->m.cls_table); hipFree(c->m.coords); hipFree(c->m.h); hipFree(c->m.cells); hipFree(c->m.nbr); hipFree(c->m.fflag); hipFree(c->m.cfacet); hipFree(c->m.mf);
     hipFree(c->D); hipFree(c->rho); hipFree(c->fsrc); hipFree(c->partial); hipFree(c->scal); hipFree(c->status);
     hipFree(c->halo_send_idx); hipFree(c->halo_sendbuf);
     if (c->pinned) hipHostFree(c->pinned);
@@ -241,6 +241,22 @@ int knp_set_params(knp_ctx* c, double C_M, double dt, double Fc, double R, doubl
 static int chk_field(knp_ctx* c, int field) {
     if (!c) return -1;
     if (field < 0 || field >= KNP_F_COUNT) { c->err = "unknown field id"; return -1; }
+    return 0;
+}
+
+int knp_set_geometry_classes(knp_ctx* c, int ncls, const uint16_t* cls, const double* table) {
+    if (!c) return -1;
+    hipFree(c->m.cls); hipFree(c->m.cls_table);
+    c->m.cls = nullptr; c->m.cls_table = nullptr; c->m.ncls = 0;
+    if (ncls <= 0) return 0;
+    if (ncls > 65535 || !cls || !table) { c->err = "geometry classes: bad arguments"; return -1; }
+    for (int64_t k = 0; k < c->m.nc; ++k)
+        if (cls[k] >= ncls) { c->err = "geometry class id out of range"; return -1; }
+    HIPCHK(c, hipMalloc((void**)&c->m.cls, sizeof(uint16_t) * c->m.nc));
+    HIPCHK(c, hipMemcpy(c->m.cls, cls, sizeof(uint16_t) * c->m.nc, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMalloc((void**)&c->m.cls_table, sizeof(double) * (size_t)ncls * KNP_CLS_STRIDE));
+    HIPCHK(c, hipMemcpy(c->m.cls_table, table, sizeof(double) * (size_t)ncls * KNP_CLS_STRIDE, hipMemcpyHostToDevice));
+    c->m.ncls = ncls;
     return 0;
 }
 

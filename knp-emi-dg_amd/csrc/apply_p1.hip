@@ -50,13 +50,13 @@ __device__ __forceinline__ void emi_facet(const MeshDev& m, const CellGeom<D>& K
     // ds_read + exec-masked global_load instead of a pointer select + flat_load).
     const unsigned loc0 = (unsigned)(Kp - st.c0);
     constexpr bool DIAG = (MODE == 1);
-    const bool in_block = (MODE == 2) && loc0 < st.nvalid;
+    const bool in_block = (MODE == 2 || MODE == 4) && loc0 < st.nvalid;
     const unsigned loc = in_block ? loc0 : 0u;
     double xn[NV];
     if (DIAG) {
 #pragma unroll
         for (int a = 0; a < NV; ++a) xn[a] = 0.0;
-    } else if (MODE == 0) {
+    } else if (MODE == 0 || MODE == 3) {
         load_nodal<D>(x, Kp, xn);
     } else {
         double xl[NV], xg[NV];
@@ -74,14 +74,28 @@ __device__ __forceinline__ void emi_facet(const MeshDev& m, const CellGeom<D>& K
         sdu += du[mm];
     }
     const double DV = (double)D * K.vol;
+    // MODE 3: per-class record  [0] vol, [1..10] G upper triangle, [11+6i .. +3] L_i, [+4] sqrt(G_ii), [+5] 2/(hK+hN_i)
+    const double sqG = (MODE == 3) ? st.rec[11 + 6 * I + 4] : ((MODE == 4) ? st.lrec[11 + 6 * I + 4] : fast_sqrt(K.G[I][I]));
     if (kind == FK_MEMBRANE) {
-        const double w = C_phi * fast_sqrt(K.G[I][I]) * DV * FacetConst<D>::mass;
+        const double w = C_phi * sqG * DV * FacetConst<D>::mass;
 #pragma unroll
         for (int mm = 0; mm < D; ++mm) y[mm + (mm >= I)] = fma(w, sdu + du[mm], y[mm + (mm >= I)]);
         return;
     }
-    double kn[NV], Xo[D], L[NV], hN;
-    if (MODE != 2) {
+    double kn[NV], Xo[D], L[NV], hN = 1.0;
+    if (MODE == 3) {
+        load_nodal<D>(kappa, Kp, kn);
+#pragma unroll
+        for (int a = 0; a < NV; ++a) L[a] = st.rec[11 + 6 * I + a];
+    } else if (MODE == 4) {
+        double kl[NV], kg[NV];
+        lds_nodal<D>(st.k, loc, kl);
+#pragma unroll
+        for (int a = 0; a < NV; ++a) kg[a] = 0.0;
+        if (!in_block) load_nodal<D>(kappa, Kp, kg);
+#pragma unroll
+        for (int a = 0; a < NV; ++a) { kn[a] = in_block ? kl[a] : kg[a]; L[a] = st.lrec[11 + 6 * I + a]; }
+    } else if (MODE != 2) {
         load_nodal<D>(kappa, Kp, kn);
         hN = m.h[Kp];
         load_vertex<D>(m.coords, m.cells[Kp * NV + j], Xo);
@@ -106,7 +120,7 @@ __device__ __forceinline__ void emi_facet(const MeshDev& m, const CellGeom<D>& K
         for (int q = 0; q < D; ++q) Xo[q] = in_block ? Xl[q] : Xg[q];
         hN = in_block ? hl : hg;
     }
-    apex_bary<D>(K, Xo, L);
+    if (MODE != 3 && MODE != 4) apex_bary<D>(K, Xo, L);
     const double rLi = fast_rcp(L[I]);
     // s = grad u . g_i on both sides
     double s_own = 0.0;
@@ -129,7 +143,8 @@ __device__ __forceinline__ void emi_facet(const MeshDev& m, const CellGeom<D>& K
 #pragma unroll
     for (int a = 0; a < NV; ++a) y[a] = fma(K.G[a][I], q, y[a]);
     // penalty: tau/avg(h) int avg(k) jump(u) v
-    const double pw = tau * fast_rcp(0.5 * (hK + hN)) * fast_sqrt(K.G[I][I]) * DV * FacetConst<D>::trip;
+    const double hinv = (MODE == 3) ? st.rec[11 + 6 * I + 5] : ((MODE == 4) ? st.lrec[11 + 6 * I + 5] : fast_rcp(0.5 * (hK + hN)));
+    const double pw = tau * hinv * sqG * DV * FacetConst<D>::trip;
     double kb[D], skb = 0.0, skd = 0.0;
 #pragma unroll
     for (int mm = 0; mm < D; ++mm) {
@@ -208,10 +223,91 @@ __global__ __launch_bounds__(EMI_BLOCK) void k_emi_apply_staged(MeshDev m, const
     }
     __syncthreads();
     if (!valid) return;
-    StageView<D> st{TO_LDS(s_x), TO_LDS(s_k), TO_LDS(s_h), TO_LDS(s_X), c0, (unsigned)((m.nc_owned - c0 < EMI_BLOCK) ? (m.nc_owned - c0) : EMI_BLOCK)};
+    StageView<D> st{TO_LDS(s_x), TO_LDS(s_k), TO_LDS(s_h), TO_LDS(s_X), c0, (unsigned)((m.nc_owned - c0 < EMI_BLOCK) ? (m.nc_owned - c0) : EMI_BLOCK), nullptr, nullptr};
     CellGeom<D> K;
     cell_geometry_from<D>(X, K);
     emi_cell<D, 2>(m, K, nb, flags, xv, kv, hK, x, kappa, C_phi, tau, st, yv);
+    store_nodal<D>(y, c, yv);
+}
+
+// "geometry class" variant for (block-)structured meshes: cells whose own shape AND neighbour apex positions
+// coincide (up to 1e-9 of the cell size) share one precomputed 36-double record (Gram matrix, volume, per facet
+// L / sqrt(G_ii) / 2/(h+h')), read through L1 (a wavefront touches a handful of records).  No coordinate, cell
+// or apex gathers and no geometry flops remain: 118 B/cell of compulsory traffic.
+template <int D>
+__global__ __launch_bounds__(KNP_BLOCK) void k_emi_apply_cls(MeshDev m, const double* __restrict__ x,
+                                                             const double* __restrict__ kappa, double* __restrict__ y,
+                                                             double C_phi, double tau) {
+    constexpr int NV = D + 1;
+    const int64_t c = xcd_block(blockIdx.x, gridDim.x) * KNP_BLOCK + threadIdx.x;
+    if (c >= m.nc_owned) return;
+    int nb[NV];
+    load_cell_ints<D>(m.nbr, c, nb);
+    const uint32_t flags = m.fflag[c];
+    const double* rec = m.cls_table + (int64_t)m.cls[c] * KNP_CLS_STRIDE;
+    double xv[NV], kv[NV], yv[NV];
+    load_nodal<D>(x, c, xv);
+    load_nodal<D>(kappa, c, kv);
+    CellGeom<D> K;
+    K.vol = rec[0];
+    {
+        int q = 1;
+#pragma unroll
+        for (int a = 0; a < NV; ++a)
+#pragma unroll
+            for (int b = a; b < NV; ++b) { K.G[a][b] = rec[q]; K.G[b][a] = rec[q]; ++q; }
+    }
+    StageView<D> st{nullptr, nullptr, nullptr, nullptr, 0, 0u, rec, nullptr};
+    emi_cell<D, 3>(m, K, nb, flags, xv, kv, 0.0, x, kappa, C_phi, tau, st, yv);
+    store_nodal<D>(y, c, yv);
+}
+
+// classed + LDS-staged: the class table and the workgroup's own x / kappa live in LDS, so in-block neighbours
+// (~83 % under the Morton ordering) cost ds_reads instead of per-lane L1 gathers (the texture addresser, not HBM,
+// is what saturates first in the direct variants: TA_BUSY ~75-90 %).
+#define CLS_MAX_LDS 64
+template <int D, int BLK>
+__global__ __launch_bounds__(BLK) void k_emi_apply_cls_staged(MeshDev m, const double* __restrict__ x,
+                                                              const double* __restrict__ kappa, double* __restrict__ y,
+                                                              double C_phi, double tau) {
+    constexpr int NV = D + 1;
+    __shared__ __attribute__((aligned(16))) double s_x[BLK * NV];
+    __shared__ __attribute__((aligned(16))) double s_k[BLK * NV];
+    __shared__ __attribute__((aligned(16))) double s_tab[CLS_MAX_LDS * KNP_CLS_STRIDE];
+    const int64_t c0 = xcd_block(blockIdx.x, gridDim.x) * BLK;
+    if (c0 >= m.nc_owned) return;
+    const int64_t c = c0 + threadIdx.x;
+    const bool valid = c < m.nc_owned;
+    for (int i = threadIdx.x; i < m.ncls * KNP_CLS_STRIDE; i += BLK) s_tab[i] = m.cls_table[i];
+    int nb[NV];
+    uint32_t flags = 0;
+    unsigned cls = 0;
+    double xv[NV], kv[NV], yv[NV];
+    if (valid) {
+        load_cell_ints<D>(m.nbr, c, nb);
+        flags = m.fflag[c];
+        cls = m.cls[c];
+        load_nodal<D>(x, c, xv);
+        load_nodal<D>(kappa, c, kv);
+        const unsigned t = threadIdx.x;
+#pragma unroll
+        for (int a = 0; a < NV; ++a) { s_x[t * NV + a] = xv[a]; s_k[t * NV + a] = kv[a]; }
+    }
+    __syncthreads();
+    if (!valid) return;
+    const lds_double* rec = TO_LDS(s_tab) + cls * KNP_CLS_STRIDE;
+    CellGeom<D> K;
+    K.vol = rec[0];
+    {
+        int q = 1;
+#pragma unroll
+        for (int a = 0; a < NV; ++a)
+#pragma unroll
+            for (int b = a; b < NV; ++b) { K.G[a][b] = rec[q]; K.G[b][a] = rec[q]; ++q; }
+    }
+    StageView<D> st{TO_LDS(s_x), TO_LDS(s_k), nullptr, nullptr, c0,
+                    (unsigned)((m.nc_owned - c0 < BLK) ? (m.nc_owned - c0) : BLK), nullptr, rec};
+    emi_cell<D, 4>(m, K, nb, flags, xv, kv, 0.0, x, kappa, C_phi, tau, st, yv);
     store_nodal<D>(y, c, yv);
 }
 
@@ -233,7 +329,7 @@ void k_emi_apply(MeshDev m, const double* __restrict__ x, const double* __restri
     const double hK = m.h[c];
     CellGeom<D> K;
     load_cell_geometry<D>(m, verts, K);
-    emi_cell<D, 0>(m, K, nb, flags, xv, kv, hK, x, kappa, C_phi, tau, StageView<D>{nullptr, nullptr, nullptr, nullptr, 0, 0u}, yv);
+    emi_cell<D, 0>(m, K, nb, flags, xv, kv, hK, x, kappa, C_phi, tau, StageView<D>{nullptr, nullptr, nullptr, nullptr, 0, 0u, nullptr, nullptr}, yv);
     store_nodal<D>(y, c, yv);
 }
 
@@ -280,7 +376,7 @@ __global__ __launch_bounds__(KNP_BLOCK) void k_emi_blockjacobi(MeshDev m, const 
         double e[NV], col[NV];
 #pragma unroll
         for (int a = 0; a < NV; ++a) e[a] = (a == b) ? 1.0 : 0.0;
-        emi_cell<D, 1>(m, K, nb, flags, e, kv, hK, nullptr, kappa, C_phi, tau, StageView<D>{nullptr, nullptr, nullptr, nullptr, 0, 0u}, col);
+        emi_cell<D, 1>(m, K, nb, flags, e, kv, hK, nullptr, kappa, C_phi, tau, StageView<D>{nullptr, nullptr, nullptr, nullptr, 0, 0u, nullptr, nullptr}, col);
 #pragma unroll
         for (int a = 0; a < NV; ++a) A[a][b] = col[a];
     }
@@ -502,7 +598,21 @@ static inline int64_t grid8(int64_t n) { return ((grid_for(n) + 7) / 8) * 8; }
 int launch_emi_apply(knp_ctx* c, const double* x, const double* kappa, double* y) {
     if (c->degree != 1) { c->err = "P1 kernels only"; return -1; }
     static const int variant = getenv("KNP_EMI_VARIANT") ? atoi(getenv("KNP_EMI_VARIANT")) : 1;
-    if (variant == 0) {
+    if (c->m.cls && c->m.dim == 3 && variant != 4) {
+        if (c->m.ncls <= CLS_MAX_LDS && variant != 5) {
+            if (variant == 6) {
+                const int64_t nblk = (((c->m.nc_owned + 383) / 384 + 7) / 8) * 8;
+                hipLaunchKernelGGL((k_emi_apply_cls_staged<3, 384>), dim3((unsigned)nblk), dim3(384), 0, c->stream, c->m, x, kappa, y,
+                                   c->p.C_phi, c->p.tau_emi);
+            } else {
+                hipLaunchKernelGGL((k_emi_apply_cls_staged<3, 256>), dim3((unsigned)grid8(c->m.nc_owned)), dim3(256), 0, c->stream,
+                                   c->m, x, kappa, y, c->p.C_phi, c->p.tau_emi);
+            }
+        } else {
+            const dim3 g((unsigned)grid8(c->m.nc_owned)), b(KNP_BLOCK);
+            hipLaunchKernelGGL(k_emi_apply_cls<3>, g, b, 0, c->stream, c->m, x, kappa, y, c->p.C_phi, c->p.tau_emi);
+        }
+    } else if (variant == 0) {
         const int64_t nblk = (((c->m.nc_owned + EMI_BLOCK - 1) / EMI_BLOCK + 7) / 8) * 8;
         const dim3 g((unsigned)nblk), b(EMI_BLOCK);
         if (c->m.dim == 3)

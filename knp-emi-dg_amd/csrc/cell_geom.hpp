@@ -164,6 +164,8 @@ template <int D> struct StageView {
     const lds_double* X;    // [nvalid][NV][D]
     int64_t c0;
     unsigned nvalid;        // 0 disables staging (setup kernels)
+    const double* rec;      // geometry-class record of the cell (MODE 3), else null
+    const lds_double* lrec; // the same record in LDS (MODE 4)
 };
 
 template <int D> __device__ __forceinline__ void lds_nodal(const lds_double* base, unsigned idx, double* v) {

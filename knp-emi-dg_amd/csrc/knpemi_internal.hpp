@@ -28,7 +28,11 @@ struct MeshDev {
     uint32_t* fflag = nullptr;     // [nc] packed 4 x u8 flag bytes
     int32_t* cfacet = nullptr;     // [nc][dim+1] global facet ids
     int32_t* mf = nullptr;         // [nmf][6]: cell_e, cell_i, lf_e, lf_i, facet, owner flag
+    uint16_t* cls = nullptr;       // [nc] geometry class of every cell (structured meshes), or null
+    double* cls_table = nullptr;   // [ncls][KNP_CLS_STRIDE]
+    int ncls = 0;
 };
+#define KNP_CLS_STRIDE 36
 
 struct Params {
     int n_ions = 0;                // total species, last one eliminated

@@ -29,6 +29,7 @@ SIGNATURES = {
     "knp_ctx_destroy": (None, [_ctxp]),
     "knp_last_error": (C.c_char_p, [_ctxp]),
     "knp_set_params": (C.c_int, [_ctxp] + [C.c_double] * 8 + [_f64p, _f64p, _f64p, _f64p, C.c_int]),
+    "knp_set_geometry_classes": (C.c_int, [_ctxp, C.c_int, C.POINTER(C.c_uint16), _f64p]),
     "knp_field_size": (C.c_int64, [_ctxp, C.c_int]),
     "knp_upload": (C.c_int, [_ctxp, C.c_int, _f64p, C.c_int64, C.c_int64]),
     "knp_download": (C.c_int, [_ctxp, C.c_int, _f64p, C.c_int64, C.c_int64]),
@@ -113,6 +114,66 @@ def morton_order(points, scale=None):
     return np.argsort(code, kind="stable")
 
 
+def geometry_classes(mesh, order, max_classes=4096, tol=1.0e-9):
+    """Group cells whose own shape and neighbour-apex positions coincide (relative tolerance `tol` of the
+    cell size) and precompute one geometry record per group (layout: include/knpemi_hip.h,
+    knp_set_geometry_classes).  Returns (cls uint16[nc] in device order, table [ncls, 36]) or None when the
+    mesh is not (block-)structured enough (more than `max_classes` distinct shapes) or not 3D."""
+    d = mesh.gdim
+    if d != 3:
+        return None
+    nc, nv = mesh.cells.shape
+    fc, fl = mesh.facet_cells, mesh.facet_local.astype(np.int64)
+    cf = mesh.cell_facets                                   # [nc, 4] facet ids
+    side = (fc[cf, 0] != np.arange(nc)[:, None]).astype(np.int64)          # which side of the facet this cell is
+    nb = np.take_along_axis(fc[cf], (1 - side)[:, :, None], axis=2)[:, :, 0]     # neighbour cell or -1
+    nj = np.take_along_axis(fl[cf], (1 - side)[:, :, None], axis=2)[:, :, 0]     # neighbour's local facet
+    X = mesh.coords[mesh.cells]                             # [nc, 4, 3]
+    X0 = X[:, 0]
+    has = nb >= 0
+    apex_v = mesh.cells[np.maximum(nb, 0), np.maximum(nj, 0)]
+    apex = np.where(has[:, :, None], mesh.coords[apex_v] - X0[:, None, :], 0.0)
+    e = X[:, :, None, :] - X[:, None, :, :]
+    h = np.sqrt((e ** 2).sum(axis=3).max(axis=(1, 2)))
+    hN = np.where(has, h[np.maximum(nb, 0)], 0.0)
+    feat = np.concatenate([(X[:, 1:] - X[:, :1]).reshape(nc, 9), apex.reshape(nc, 12), h[:, None], hN], axis=1)
+    q = np.round(feat / (np.median(h) * tol)).astype(np.int64)
+    rng = np.random.default_rng(12345)
+    h1 = (q * rng.integers(1, 2 ** 62, size=q.shape[1], dtype=np.int64)[None, :]).sum(axis=1)     # wraps mod 2^64
+    h2 = (q * rng.integers(1, 2 ** 62, size=q.shape[1], dtype=np.int64)[None, :]).sum(axis=1)
+    _, first, inv = np.unique(np.stack([h1, h2], axis=1), axis=0, return_index=True, return_inverse=True)
+    inv = inv.ravel()
+    ncls = len(first)
+    if ncls > max_classes:
+        return None
+    if not np.array_equal(q[first][inv], q):               # hash collision (astronomically unlikely): give up
+        return None
+    # records of the representatives
+    Xr = X[first]
+    J = (Xr[:, 1:, :] - Xr[:, :1, :]).transpose(0, 2, 1)
+    Jinv = np.linalg.inv(J)
+    g = np.empty((ncls, 4, 3))
+    g[:, 1:, :] = Jinv
+    g[:, 0, :] = -Jinv.sum(axis=1)
+    G = np.einsum("cad,cbd->cab", g, g)
+    vol = np.abs(np.linalg.det(J)) / 6.0
+    table = np.zeros((ncls, 36))
+    table[:, 0] = vol
+    k = 1
+    for a in range(4):
+        for b in range(a, 4):
+            table[:, k] = G[:, a, b]
+            k += 1
+    L = np.einsum("cad,cid->cia", g, apex[first])          # [cls, facet i, vertex a]
+    L[:, :, 0] += 1.0
+    hasr = has[first]
+    for i in range(4):
+        table[:, 11 + 6 * i:11 + 6 * i + 4] = np.where(hasr[:, i:i + 1], L[:, i, :], 0.0)
+        table[:, 11 + 6 * i + 4] = np.sqrt(G[:, i, i])
+        table[:, 11 + 6 * i + 5] = np.where(hasr[:, i], 2.0 / (h[first] + np.where(hasr[:, i], hN[first, i], 1.0)), 0.0)
+    return np.ascontiguousarray(inv[order].astype(np.uint16)), np.ascontiguousarray(table)
+
+
 class Device:
     """One context = one GPU = one partition of the mesh."""
 
@@ -164,6 +225,14 @@ class Device:
             msg = self.lib.knp_last_error(None)
             self.ctx = None
             raise KnpError("knp_ctx_create failed (%d): %s" % (rc, msg.decode() if msg else "?"))
+        self.n_geometry_classes = 0
+        if os.environ.get("KNP_NO_CLASSES", "0") != "1":
+            gc = geometry_classes(mesh, order)
+            if gc is not None:
+                cls, table = gc
+                self._chk(self.lib.knp_set_geometry_classes(self.ctx, table.shape[0], _p(cls, C.POINTER(C.c_uint16)),
+                                                            _p(table, _f64p)), "knp_set_geometry_classes")
+                self.n_geometry_classes = table.shape[0]
 
     # -- helpers -------------------------------------------------------------------
     def _chk(self, rc, what):
