@@ -528,6 +528,169 @@ __global__ __launch_bounds__(KNP_BLOCK) void k_knp_apply(MeshDev m, const double
     for (int k = 0; k < NS; ++k) store_nodal<D>(yout + (int64_t)k * m.nc * NV, c, y[k]);
 }
 
+// ---- geometry-class + LDS-staged KNP variant (structured meshes), see k_emi_apply_cls_staged ----
+template <int D, int NS, int BLK> struct KnpStage {
+    const lds_double* x;     // [NS][BLK][NV]
+    const lds_double* g;     // [BLK][NV]   gphi
+    const lds_double* Dd;    // [NS][BLK]
+    const lds_double* rec;   // class record of this cell
+    int64_t c0;
+    unsigned nvalid;
+};
+
+template <int D, int NS, int BLK, int I>
+__device__ __forceinline__ void knp_facet_cls(const MeshDev& m, const CellGeom<D>& K, const int* nb, uint32_t flags,
+                                              const double (*xv)[D + 1], const double* gp, const double* Dk,
+                                              const double* __restrict__ x, const double* __restrict__ gphi,
+                                              const double* __restrict__ Dall, const KnpArgs& ka,
+                                              const KnpStage<D, NS, BLK>& st, double (*y)[D + 1]) {
+    constexpr int NV = D + 1;
+    const uint32_t fb = (flags >> (8 * I)) & 0xffu;
+    const uint32_t kind = (fb >> 2) & 3u;
+    if (kind != FK_SIPG) return;
+    const int j = (int)(fb & 3u);
+    const int64_t Kp = nb[I];
+    const unsigned loc0 = (unsigned)(Kp - st.c0);
+    const bool in_block = loc0 < st.nvalid;
+    const unsigned loc = in_block ? loc0 : 0u;
+    double L[NV];
+#pragma unroll
+    for (int a = 0; a < NV; ++a) L[a] = st.rec[11 + 6 * I + a];
+    const double sqG = st.rec[11 + 6 * I + 4], hinv = st.rec[11 + 6 * I + 5];
+    const double gl = st.g[loc * NV + (in_block ? j : 0)];
+    double gg = 0.0;
+    if (!in_block) gg = gphi[Kp * NV + j];
+    const double gp_nb = in_block ? gl : gg;
+    const double rLi = fast_rcp(L[I]);
+    const double DV = (double)D * K.vol;
+    const double up_own = fmax(-gp[I], 0.0) * DV;
+    const double up_nb = fmax(-gp_nb, 0.0) * DV * (-L[I]);
+    const double penA = ka.tau * hinv * sqG * DV;
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+        // in-block neighbours: LDS is addressed per lane, so the facet-vertex permutation costs nothing;
+        // out-of-block: exec-masked global gather + register selects
+        const lds_double* xl = st.x + ((unsigned)k * BLK + loc) * NV;
+        double xf[D], xap, Dn;
+        xap = xl[in_block ? j : 0];
+#pragma unroll
+        for (int mm = 0; mm < D; ++mm) xf[mm] = xl[mm + ((in_block && mm >= j) ? 1 : 0)];
+        Dn = st.Dd[k * BLK + loc];
+        if (!in_block) {
+            // conditional overwrite with scalars (no arrays): the runtime-j selects stay v_cndmask
+            const double* px = x + (int64_t)k * m.nc * NV + Kp * NV;
+            const double2 q0 = *reinterpret_cast<const double2*>(px);
+            const double2 q1 = *reinterpret_cast<const double2*>(px + 2);
+            const double g0 = q0.x, g1 = q0.y, g2 = q1.x, g3 = q1.y;
+            Dn = Dall[(int64_t)k * m.nc + Kp];
+            xf[0] = (j == 0) ? g1 : g0;
+            xf[1] = (j <= 1) ? g2 : g1;
+            xf[2] = (j <= 2) ? g3 : g2;
+            xap = (j & 2) ? ((j & 1) ? g3 : g2) : ((j & 1) ? g1 : g0);
+        }
+        double s_own = 0.0;
+#pragma unroll
+        for (int a = 0; a < NV; ++a) s_own = fma(xv[k][a], K.G[a][I], s_own);
+        const double gr = K.G[I][I] * rLi;
+        double s_nb = xap * gr;
+#pragma unroll
+        for (int mm = 0; mm < D; ++mm) s_nb = fma(xf[mm], fma(-L[mm + (mm >= I)], gr, K.G[mm + (mm >= I)][I]), s_nb);
+        const double zp = ka.z[k] * ka.psi;
+        const double c_own = penA * Dk[k] - zp * Dk[k] * up_own;
+        const double c_nb = penA * Dn - zp * Dn * up_nb;
+        double sdu = 0.0, w[D], sw = 0.0;
+#pragma unroll
+        for (int mm = 0; mm < D; ++mm) {
+            const double xo = xv[k][mm + (mm >= I)];
+            sdu += xo - xf[mm];
+            w[mm] = fma(c_own, xo, -c_nb * xf[mm]);
+            sw += w[mm];
+        }
+        const double t1 = 0.5 * K.vol * fma(Dk[k], s_own, Dn * s_nb);
+        const double t2 = 0.5 * Dk[k] * K.vol * sdu;
+#pragma unroll
+        for (int a = 0; a < NV; ++a) y[k][a] = fma(K.G[a][I], t2, y[k][a]);
+#pragma unroll
+        for (int mm = 0; mm < D; ++mm)
+            y[k][mm + (mm >= I)] += t1 + FacetConst<D>::mass * (sw + w[mm]);
+    }
+}
+
+template <int D, int NS, int BLK>
+__global__ __launch_bounds__(BLK) void k_knp_apply_cls_staged(MeshDev m, const double* __restrict__ x,
+                                                              const double* __restrict__ gphi,
+                                                              const double* __restrict__ Dall, double* __restrict__ yout,
+                                                              KnpArgs ka) {
+    constexpr int NV = D + 1;
+    __shared__ __attribute__((aligned(16))) double s_x[NS * BLK * NV];
+    __shared__ __attribute__((aligned(16))) double s_g[BLK * NV];
+    __shared__ double s_D[NS * BLK];
+    __shared__ __attribute__((aligned(16))) double s_tab[CLS_MAX_LDS * KNP_CLS_STRIDE];
+    const int64_t c0 = xcd_block(blockIdx.x, gridDim.x) * BLK;
+    if (c0 >= m.nc_owned) return;
+    const int64_t c = c0 + threadIdx.x;
+    const bool valid = c < m.nc_owned;
+    for (int i = threadIdx.x; i < m.ncls * KNP_CLS_STRIDE; i += BLK) s_tab[i] = m.cls_table[i];
+    int nb[NV];
+    uint32_t flags = 0;
+    unsigned cls = 0;
+    double xv[NS][NV], y[NS][NV], gp[NV], Dk[NS];
+    if (valid) {
+        load_cell_ints<D>(m.nbr, c, nb);
+        flags = m.fflag[c];
+        cls = m.cls[c];
+        load_nodal<D>(gphi, c, gp);
+        const unsigned t = threadIdx.x;
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            load_nodal<D>(x + (int64_t)k * m.nc * NV, c, xv[k]);
+            Dk[k] = Dall[(int64_t)k * m.nc + c];
+            s_D[k * BLK + t] = Dk[k];
+#pragma unroll
+            for (int a = 0; a < NV; ++a) s_x[(k * BLK + t) * NV + a] = xv[k][a];
+        }
+#pragma unroll
+        for (int a = 0; a < NV; ++a) s_g[t * NV + a] = gp[a];
+    }
+    __syncthreads();
+    if (!valid) return;
+    const lds_double* rec = TO_LDS(s_tab) + cls * KNP_CLS_STRIDE;
+    CellGeom<D> K;
+    K.vol = rec[0];
+    {
+        int q = 1;
+#pragma unroll
+        for (int a = 0; a < NV; ++a)
+#pragma unroll
+            for (int b = a; b < NV; ++b) { K.G[a][b] = rec[q]; K.G[b][a] = rec[q]; ++q; }
+    }
+    KnpStage<D, NS, BLK> st{TO_LDS(s_x), TO_LDS(s_g), TO_LDS(s_D), rec, c0,
+                            (unsigned)((m.nc_owned - c0 < BLK) ? (m.nc_owned - c0) : BLK)};
+    // volume terms (same as knp_cell)
+    const double mw = ka.inv_dt * K.vol / (double)((D + 1) * (D + 2));
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+        double sx = 0.0;
+#pragma unroll
+        for (int a = 0; a < NV; ++a) sx += xv[k][a];
+        const double drift = ka.z[k] * ka.psi * Dk[k] * K.vol * sx / (double)NV;
+        const double dv = Dk[k] * K.vol;
+#pragma unroll
+        for (int a = 0; a < NV; ++a) {
+            double s = 0.0;
+#pragma unroll
+            for (int b = 0; b < NV; ++b) s = fma(K.G[a][b], xv[k][b], s);
+            y[k][a] = fma(mw, sx + xv[k][a], fma(dv, s, drift * gp[a]));
+        }
+    }
+    knp_facet_cls<D, NS, BLK, 0>(m, K, nb, flags, xv, gp, Dk, x, gphi, Dall, ka, st, y);
+    knp_facet_cls<D, NS, BLK, 1>(m, K, nb, flags, xv, gp, Dk, x, gphi, Dall, ka, st, y);
+    knp_facet_cls<D, NS, BLK, 2>(m, K, nb, flags, xv, gp, Dk, x, gphi, Dall, ka, st, y);
+    if (D == 3) knp_facet_cls<D, NS, BLK, (D == 3 ? 3 : 0)>(m, K, nb, flags, xv, gp, Dk, x, gphi, Dall, ka, st, y);
+#pragma unroll
+    for (int k = 0; k < NS; ++k) store_nodal<D>(yout + (int64_t)k * m.nc * NV, c, y[k]);
+}
+
 // one species per launch dimension (setup only, once per KNP solve)
 template <int D>
 __global__ __launch_bounds__(KNP_BLOCK) void k_knp_blockjacobi(MeshDev m, const double* __restrict__ gphi,
@@ -647,6 +810,16 @@ static KnpArgs make_knp_args(knp_ctx* c) {
 template <int D> static int knp_apply_dispatch(knp_ctx* c, const double* x, const double* gphi, double* y) {
     const dim3 g((unsigned)grid8(c->m.nc_owned)), b(KNP_BLOCK);
     const KnpArgs ka = make_knp_args(c);
+    static const int variant = getenv("KNP_KNP_VARIANT") ? atoi(getenv("KNP_KNP_VARIANT")) : 0;
+    if (D == 3 && c->m.cls && c->m.ncls <= CLS_MAX_LDS && variant == 0 && c->p.n_sys <= 3) {
+        switch (c->p.n_sys) {
+            case 1: hipLaunchKernelGGL((k_knp_apply_cls_staged<3, 1, 256>), g, b, 0, c->stream, c->m, x, gphi, c->D, y, ka); break;
+            case 2: hipLaunchKernelGGL((k_knp_apply_cls_staged<3, 2, 256>), g, b, 0, c->stream, c->m, x, gphi, c->D, y, ka); break;
+            default: hipLaunchKernelGGL((k_knp_apply_cls_staged<3, 3, 256>), g, b, 0, c->stream, c->m, x, gphi, c->D, y, ka); break;
+        }
+        HIPCHK(c, hipGetLastError());
+        return 0;
+    }
     switch (c->p.n_sys) {
         case 1: hipLaunchKernelGGL((k_knp_apply<D, 1>), g, b, 0, c->stream, c->m, x, gphi, c->D, y, ka); break;
         case 2: hipLaunchKernelGGL((k_knp_apply<D, 2>), g, b, 0, c->stream, c->m, x, gphi, c->D, y, ka); break;
