@@ -156,10 +156,10 @@ def main():
                        "knp_iters_per_step": float(np.mean([max(n) for n in S.knp_niter[-args.steps:]])),
                        "emi_solve_s": S.emi_solve_timer, "knp_solve_s": S.knp_solve_timer,
                        "assemble_s": S.emi_ass_timer + S.knp_ass_timer, "ode_s": S.ode_solve_timer},
-            "roofline": {"bound": "hbm", "kernel": "k_emi_apply<3>", "achieved": emi_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": "k_emi_apply_cls_staged<3,256>" if S.dev.n_geometry_classes else "k_emi_apply<3,3>", "achieved": emi_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": emi_gbs / HBM_PEAK_GBS, "traffic": None, "avg_kernel_us": emi_ms * 1e3,
                          "algorithmic_bytes_per_cell": EMI_BYTES_PER_CELL, "cells_per_launch": nc_local,
-                         "knp_apply": {"kernel": "k_knp_apply<3,2>", "achieved": knp_gbs, "frac": knp_gbs / HBM_PEAK_GBS,
+                         "knp_apply": {"kernel": "k_knp_apply_cls_staged<3,2,256>" if S.dev.n_geometry_classes else "k_knp_apply<3,2>", "achieved": knp_gbs, "frac": knp_gbs / HBM_PEAK_GBS,
                                        "avg_kernel_us": knp_ms * 1e3, "algorithmic_bytes_per_cell": KNP_BYTES_PER_CELL}},
         }
         if not args.no_cpu_baseline and world == 1:
