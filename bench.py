@@ -142,6 +142,17 @@ def main():
     emi_gbs = EMI_BYTES_PER_CELL * nc_local / (emi_ms * 1e-3) / 1e9
     knp_gbs = KNP_BYTES_PER_CELL * nc_local / (knp_ms * 1e-3) / 1e9
 
+    # HBM-side traffic of the same kernel on the same workload, from the committed rocprofv3 --pmc passes
+    # (counters cannot be read from inside this process); null when the workload differs
+    emi_name = "k_emi_apply_cls_staged<3,256>" if S.dev.n_geometry_classes else "k_emi_apply<3,3>"
+    traffic = None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+        if pmc.get(emi_name, {}).get("cells_per_launch") == nc_local:
+            traffic = pmc[emi_name]["traffic_bytes"]
+    except (OSError, ValueError):
+        pass
+
     if rank == 0:
         out = {
             "metric": "DoF-updates/sec per PDE timestep", "value": dofs * args.steps / elapsed, "unit": "DoF/s",
@@ -157,7 +168,7 @@ def main():
                        "emi_solve_s": S.emi_solve_timer, "knp_solve_s": S.knp_solve_timer,
                        "assemble_s": S.emi_ass_timer + S.knp_ass_timer, "ode_s": S.ode_solve_timer},
             "roofline": {"bound": "hbm", "kernel": "k_emi_apply_cls_staged<3,256>" if S.dev.n_geometry_classes else "k_emi_apply<3,3>", "achieved": emi_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": emi_gbs / HBM_PEAK_GBS, "traffic": None, "avg_kernel_us": emi_ms * 1e3,
+                         "frac": emi_gbs / HBM_PEAK_GBS, "traffic": traffic, "avg_kernel_us": emi_ms * 1e3,
                          "algorithmic_bytes_per_cell": EMI_BYTES_PER_CELL, "cells_per_launch": nc_local,
                          "knp_apply": {"kernel": "k_knp_apply_cls_staged<3,2,256>" if S.dev.n_geometry_classes else "k_knp_apply<3,2>", "achieved": knp_gbs, "frac": knp_gbs / HBM_PEAK_GBS,
                                        "avg_kernel_us": knp_ms * 1e3, "algorithmic_bytes_per_cell": KNP_BYTES_PER_CELL}},
