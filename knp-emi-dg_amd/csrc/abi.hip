@@ -193,6 +193,9 @@ void knp_ctx_destroy(knp_ctx* c) {
     hipSetDevice(c->device);
     hipDeviceSynchronize();
     for (auto& H : c->amg) amg_free(H);
+    for (auto st : c->aux_streams) hipStreamDestroy(st);
+    for (auto ev : c->aux_events) hipEventDestroy(ev);
+    if (c->fork_event) hipEventDestroy(c->fork_event);
     ode_destroy_all(c);
     Fields* fl = g_fields[c];
     if (fl) {

@@ -60,13 +60,39 @@ template <int MODE> void launch_csr(knp_ctx* c, const CsrDev& A, const double* x
 }
 
 // first Chebyshev update:  d = dinv r / theta ;  x = d (zero guess) or x += d
-__global__ void k_cheb_first(int64_t n, const double* __restrict__ dinv, const double* __restrict__ r, double inv_theta,
-                             int zero_guess, double* __restrict__ d, double* __restrict__ x) {
+__global__ void k_cheb_first(int64_t n, const double* __restrict__ dinv, const double* __restrict__ b, double inv_theta,
+                             double* __restrict__ r, double* __restrict__ d, double* __restrict__ x) {
+    // zero initial guess: r = b ; d = dinv r / theta ; x = d
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const double v = dinv[i] * r[i] * inv_theta;
+    const double bi = b[i];
+    const double v = dinv[i] * bi * inv_theta;
+    r[i] = bi;
     d[i] = v;
-    x[i] = zero_guess ? v : x[i] + v;
+    x[i] = v;
+}
+
+// non-zero guess, fused:  r = b - A x ;  d = dinv r / theta ;  xout = x + d     (xout != x: neighbours still read x)
+template <int G>
+__global__ __launch_bounds__(256) void k_cheb_first_res(CsrDev A, const double* __restrict__ dinv, const double* __restrict__ b,
+                                                        const double* __restrict__ x, double inv_theta, double* __restrict__ r,
+                                                        double* __restrict__ d, double* __restrict__ xout) {
+    const int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) / G;
+    const int lane = threadIdx.x % G;
+    double s = 0.0;
+    if (row < A.nrows) {
+        const int e = A.rowptr[row + 1];
+        for (int k = A.rowptr[row] + lane; k < e; k += G) s = fma(A.val[k], x[A.col[k]], s);
+    }
+#pragma unroll
+    for (int off = G / 2; off > 0; off >>= 1) s += __shfl_down(s, off, G);
+    if (row < A.nrows && lane == 0) {
+        const double rn = b[row] - s;
+        const double v = dinv[row] * rn * inv_theta;
+        r[row] = rn;
+        d[row] = v;
+        xout[row] = x[row] + v;
+    }
 }
 
 // fused step:  r -= A d_in ;  d_out = c1 d_in + c2 dinv r ;  x += d_out        (G lanes per row)
@@ -140,11 +166,19 @@ static void smooth(knp_ctx* c, AmgLevel& L, bool zero_guess) {
     const double theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin), sigma = theta / delta;
     double rho = 1.0 / sigma;
     const unsigned g = (unsigned)((L.n + 255) / 256);
-    if (!zero_guess) launch_csr<1>(c, L.A, L.x, L.b, L.r);       // r = b - A x
-    const double* r0 = zero_guess ? L.b : L.r;
-    hipLaunchKernelGGL(k_cheb_first, dim3(g), dim3(256), 0, c->stream, L.n, L.dinv, r0, 1.0 / theta, zero_guess ? 1 : 0, L.d0, L.x);
-    if (L.cheb_degree > 1 && zero_guess)
-        hipMemcpyAsync(L.r, L.b, sizeof(double) * L.n, hipMemcpyDeviceToDevice, c->stream);
+    if (zero_guess) {
+        hipLaunchKernelGGL(k_cheb_first, dim3(g), dim3(256), 0, c->stream, L.n, L.dinv, L.b, 1.0 / theta, L.r, L.d0, L.x);
+    } else {
+        // x lives in L.x; the fused kernel writes the updated iterate to L.d1 (free at this point), then swap
+        const double avg = L.A.nrows ? (double)L.A.nnz / (double)L.A.nrows : 0.0;
+        if (avg <= 12.0)
+            hipLaunchKernelGGL((k_cheb_first_res<1>), dim3((unsigned)((L.n + 255) / 256)), dim3(256), 0, c->stream, L.A, L.dinv, L.b, L.x, 1.0 / theta, L.r, L.d0, L.d1);
+        else if (avg <= 96.0)
+            hipLaunchKernelGGL((k_cheb_first_res<8>), dim3((unsigned)((L.n * 8 + 255) / 256)), dim3(256), 0, c->stream, L.A, L.dinv, L.b, L.x, 1.0 / theta, L.r, L.d0, L.d1);
+        else
+            hipLaunchKernelGGL((k_cheb_first_res<64>), dim3((unsigned)((L.n * 64 + 255) / 256)), dim3(256), 0, c->stream, L.A, L.dinv, L.b, L.x, 1.0 / theta, L.r, L.d0, L.d1);
+        double* t = L.x; L.x = L.d1; L.d1 = t;
+    }
     double* din = L.d0;
     double* dout = L.d1;
     for (int k = 1; k < L.cheb_degree; ++k) {
@@ -177,7 +211,7 @@ static int amg_vcycle_eager(knp_ctx* c, AmgHierarchy& H) {
 
 // The V-cycle is ~40 tiny launch-bound kernels on fixed buffers: capture it once into a hipGraph and replay it
 // (kernel boundaries ~1.5 us instead of ~5 us of eager launch latency each).
-int amg_vcycle(knp_ctx* c, AmgHierarchy& H) {
+int amg_vcycle(knp_ctx* c, AmgHierarchy& H, hipStream_t on_stream) {
     static const bool use_graph = !(getenv("KNP_NO_GRAPH") && atoi(getenv("KNP_NO_GRAPH")));
     if (use_graph && !H.graph_tried) {
         H.graph_tried = true;
@@ -196,10 +230,10 @@ int amg_vcycle(knp_ctx* c, AmgHierarchy& H) {
         (void)hipGetLastError();
     }
     if (H.graph_exec) {
-        HIPCHK(c, hipGraphLaunch((hipGraphExec_t)H.graph_exec, c->stream));
+        HIPCHK(c, hipGraphLaunch((hipGraphExec_t)H.graph_exec, on_stream ? on_stream : c->stream));
         return 0;
     }
-    return amg_vcycle_eager(c, H);
+    return amg_vcycle_eager(c, H);      // eager fallback always runs on the context's stream
 }
 
 int amg_restrict_from_dg(knp_ctx* c, AmgHierarchy& H, const double* r_dg) {

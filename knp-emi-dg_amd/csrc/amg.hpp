@@ -1,6 +1,7 @@
 // CSR levels of the auxiliary-space AMG hierarchy (device pointers).
 #pragma once
 #include <cstdint>
+#include <hip/hip_runtime.h>
 #include <vector>
 
 struct CsrDev {
@@ -31,6 +32,6 @@ struct AmgHierarchy {
 };
 
 struct knp_ctx;
-int amg_vcycle(knp_ctx* c, AmgHierarchy& H);
+int amg_vcycle(knp_ctx* c, AmgHierarchy& H, hipStream_t on_stream = nullptr);
 int amg_restrict_from_dg(knp_ctx* c, AmgHierarchy& H, const double* r_dg);
 void amg_free(AmgHierarchy& H);

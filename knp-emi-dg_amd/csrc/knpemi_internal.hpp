@@ -71,6 +71,9 @@ struct knp_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // auxiliary-space AMG hierarchies: [0] EMI, [1 + k] KNP species k
     std::vector<AmgHierarchy> amg;
+    std::vector<hipStream_t> aux_streams;   // one per extra KNP species: their V-cycles run concurrently
+    std::vector<hipEvent_t> aux_events;
+    hipEvent_t fork_event = nullptr;
     // distributed
     void* comm = nullptr;          // ncclComm_t
     int rank = 0, nranks = 1;

@@ -504,18 +504,50 @@ int pcg_solve(knp_ctx* c, KrylovVecs& kv, double rtol, double atol, int maxit, i
                          : pcg_impl<3>(c, kv, rtol, atol, maxit, check_every, niter, res);
 }
 
-// out_s += P_s V_s(P_s^T in_s) for every species s with an armed hierarchy (slot 1 + s)
+// out_s += P_s V_s(P_s^T in_s) for every species s with an armed hierarchy (slot 1 + s).  The species' V-cycles are
+// independent chains of tiny latency-bound kernels: species 0 runs on the context's stream, every further species
+// on its own auxiliary stream (fork / join with events), so the chains overlap.
 template <int NV>
 static int knp_coarse_correction(knp_ctx* c, const VecDims& d, const double* in, double* out) {
     const dim3 g1((unsigned)grid_for(c->m.nc_owned)), b(KNP_BLOCK);
-    for (int s = 0; s < d.nsys; ++s) {
-        if ((int)c->amg.size() <= 1 + s || !c->amg[1 + s].ready) continue;
+    int active[KNP_MAX_SYS], na = 0;
+    for (int s = 0; s < d.nsys; ++s)
+        if ((int)c->amg.size() > 1 + s && c->amg[1 + s].ready) active[na++] = s;
+    if (!na) return 0;
+    int rc;
+    for (int i = 0; i < na; ++i) {
+        const int s = active[i];
+        if ((rc = amg_restrict_from_dg(c, c->amg[1 + s], in + (int64_t)s * d.nc * NV))) return rc;
+    }
+    const bool fork = na > 1 && c->amg[1 + active[0]].graph_tried && c->amg[1 + active[0]].graph_exec;
+    if (fork) {
+        while ((int)c->aux_streams.size() < na - 1) {
+            hipStream_t st; hipEvent_t ev;
+            HIPCHK(c, hipStreamCreate(&st));
+            HIPCHK(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            c->aux_streams.push_back(st);
+            c->aux_events.push_back(ev);
+        }
+        if (!c->fork_event) HIPCHK(c, hipEventCreateWithFlags(&c->fork_event, hipEventDisableTiming));
+        HIPCHK(c, hipEventRecord(c->fork_event, c->stream));
+    }
+    for (int i = 0; i < na; ++i) {
+        AmgHierarchy& H = c->amg[1 + active[i]];
+        hipStream_t st = nullptr;
+        if (fork && i > 0 && H.graph_exec) {
+            st = c->aux_streams[i - 1];
+            HIPCHK(c, hipStreamWaitEvent(st, c->fork_event, 0));
+        }
+        if ((rc = amg_vcycle(c, H, st))) return rc;
+        if (st) {
+            HIPCHK(c, hipEventRecord(c->aux_events[i - 1], st));
+            HIPCHK(c, hipStreamWaitEvent(c->stream, c->aux_events[i - 1], 0));
+        }
+    }
+    for (int i = 0; i < na; ++i) {
+        const int s = active[i];
         AmgHierarchy& H = c->amg[1 + s];
-        const int64_t off = (int64_t)s * d.nc * NV;
-        int rc = amg_restrict_from_dg(c, H, in + off);
-        if (rc) return rc;
-        if ((rc = amg_vcycle(c, H))) return rc;
-        hipLaunchKernelGGL(k_prolong_add<NV>, g1, b, 0, c->stream, d, c->status, s, H.dg2cg, H.levels[0].x, out + off);
+        hipLaunchKernelGGL(k_prolong_add<NV>, g1, b, 0, c->stream, d, c->status, s, H.dg2cg, H.levels[0].x, out + (int64_t)s * d.nc * NV);
     }
     return 0;
 }

@@ -153,7 +153,7 @@ class Level:
     pass
 
 
-def build_hierarchy(A, theta=0.08, max_coarse=300, max_levels=12, cheb_degree=3, cheb_lower=0.1):
+def build_hierarchy(A, theta=0.08, max_coarse=1000, max_levels=12, cheb_degree=3, cheb_lower=0.1):
     """Smoothed-aggregation hierarchy for an SPD (possibly singular, constants) matrix.
     Each level: A (csr), dinv, rho = spectral radius estimate of D^-1 A, P (csr, to the next level).
     Last level: dense pseudo-inverse."""
