@@ -65,9 +65,10 @@ int halo_exchange(knp_ctx* c, double* v, int nfields) {
     NCCLCHK(c, ncclGroupStart());
     for (int p = 0; p < np; ++p) {
         const int peer = c->halo_peer[p];
-        if (c->halo_send_cnt[p])
-            NCCLCHK(c, ncclSend(c->halo_sendbuf + c->halo_send_off[p] * KNP_MAX_SYS * NV,
-                                (size_t)(c->halo_send_cnt[p] * nfields * NV), ncclDouble, peer, comm, c->stream));
+        // one message per field, matching the receiver's per-field ncclRecv calls one-to-one (same order)
+        for (int f = 0; f < nfields && c->halo_send_cnt[p]; ++f)
+            NCCLCHK(c, ncclSend(c->halo_sendbuf + c->halo_send_off[p] * KNP_MAX_SYS * NV + (int64_t)f * c->halo_send_cnt[p] * NV,
+                                (size_t)(c->halo_send_cnt[p] * NV), ncclDouble, peer, comm, c->stream));
         for (int f = 0; f < nfields && c->halo_recv_cnt[p]; ++f)
             NCCLCHK(c, ncclRecv(v + (int64_t)f * stride + c->halo_recv_off[p] * NV, (size_t)(c->halo_recv_cnt[p] * NV), ncclDouble,
                                 peer, comm, c->stream));

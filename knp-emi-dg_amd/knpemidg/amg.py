@@ -153,10 +153,15 @@ class Level:
     pass
 
 
-def build_hierarchy(A, theta=0.08, max_coarse=1000, max_levels=12, cheb_degree=3, cheb_lower=0.1):
+def build_hierarchy(A, theta=0.08, max_coarse=1000, max_levels=12, cheb_degree=2, cheb_lower=0.3):
     """Smoothed-aggregation hierarchy for an SPD (possibly singular, constants) matrix.
     Each level: A (csr), dinv, rho = spectral radius estimate of D^-1 A, P (csr, to the next level).
     Last level: dense pseudo-inverse."""
+    import os
+    theta = float(os.environ.get("KNP_AMG_THETA", theta))
+    cheb_degree = int(os.environ.get("KNP_AMG_DEGREE", cheb_degree))
+    cheb_lower = float(os.environ.get("KNP_AMG_LOWER", cheb_lower))
+    max_coarse = int(os.environ.get("KNP_AMG_MAXCOARSE", max_coarse))
     levels = []
     A = A.tocsr().astype(np.float64)
     while True:
