@@ -161,6 +161,95 @@ __device__ __forceinline__ void emi_facet(const MeshDev& m, const CellGeom<D>& K
     }
 }
 
+// EMI facet for the geometry-class + LDS-staged kernel: in-block neighbours are read from LDS with the facet-vertex
+// permutation folded into the per-lane address (no register selects); out-of-block lanes overwrite from global.
+template <int D, int I>
+__device__ __forceinline__ void emi_facet_cls(const MeshDev& m, const CellGeom<D>& K, const int* nb, uint32_t flags,
+                                              const double* xv, const double* kv,
+                                              const double* __restrict__ x, const double* __restrict__ kappa,
+                                              double C_phi, double tau, const StageView<D>& st, double* y) {
+    constexpr int NV = D + 1;
+    const uint32_t fb = (flags >> (8 * I)) & 0xffu;
+    const uint32_t kind = (fb >> 2) & 3u;
+    if (kind >= FK_EXTERIOR) return;
+    const int j = (int)(fb & 3u);
+    const int64_t Kp = nb[I];
+    const unsigned loc0 = (unsigned)(Kp - st.c0);
+    const bool in_block = loc0 < st.nvalid;
+    const unsigned loc = in_block ? loc0 : 0u;
+    const lds_double* xl = st.x + loc * NV;
+    const lds_double* kl = st.k + loc * NV;
+    double xf[D], knf[D], xap;
+    xap = xl[in_block ? j : 0];
+#pragma unroll
+    for (int mm = 0; mm < D; ++mm) {
+        const int o = mm + ((in_block && mm >= j) ? 1 : 0);
+        xf[mm] = xl[o];
+        knf[mm] = kl[o];
+    }
+    if (!in_block) {
+        static_assert(D == 3, "classed kernels are 3D only");
+        const double* px = x + Kp * NV;
+        const double* pk = kappa + Kp * NV;
+        const double2 q0 = *reinterpret_cast<const double2*>(px), q1 = *reinterpret_cast<const double2*>(px + 2);
+        const double2 r0 = *reinterpret_cast<const double2*>(pk), r1 = *reinterpret_cast<const double2*>(pk + 2);
+        xf[0] = (j == 0) ? q0.y : q0.x;  knf[0] = (j == 0) ? r0.y : r0.x;
+        xf[1] = (j <= 1) ? q1.x : q0.y;  knf[1] = (j <= 1) ? r1.x : r0.y;
+        xf[2] = (j <= 2) ? q1.y : q1.x;  knf[2] = (j <= 2) ? r1.y : r1.x;
+        xap = (j & 2) ? ((j & 1) ? q1.y : q1.x) : ((j & 1) ? q0.y : q0.x);
+    }
+    double du[D], sdu = 0.0;
+#pragma unroll
+    for (int mm = 0; mm < D; ++mm) {
+        du[mm] = xv[mm + (mm >= I)] - xf[mm];
+        sdu += du[mm];
+    }
+    const double DV = (double)D * K.vol;
+    const double sqG = st.lrec[11 + 6 * I + 4];
+    if (kind == FK_MEMBRANE) {
+        const double w = C_phi * sqG * DV * FacetConst<D>::mass;
+#pragma unroll
+        for (int mm = 0; mm < D; ++mm) y[mm + (mm >= I)] = fma(w, sdu + du[mm], y[mm + (mm >= I)]);
+        return;
+    }
+    double L[NV];
+#pragma unroll
+    for (int a = 0; a < NV; ++a) L[a] = st.lrec[11 + 6 * I + a];
+    const double gr = K.G[I][I] * fast_rcp(L[I]);
+    double s_own = 0.0, s_nb = xap * gr;
+#pragma unroll
+    for (int a = 0; a < NV; ++a) s_own = fma(xv[a], K.G[a][I], s_own);
+#pragma unroll
+    for (int mm = 0; mm < D; ++mm) s_nb = fma(xf[mm], fma(-L[mm + (mm >= I)], gr, K.G[mm + (mm >= I)][I]), s_nb);
+    double kf[D], sk = 0.0, skn = 0.0, q = 0.0;
+#pragma unroll
+    for (int mm = 0; mm < D; ++mm) {
+        kf[mm] = kv[mm + (mm >= I)];
+        sk += kf[mm];
+        skn += knf[mm];
+        q = fma(kf[mm], sdu + du[mm], q);
+    }
+    const double hm = 0.5 * DV * FacetConst<D>::mass;
+    q *= hm;
+#pragma unroll
+    for (int a = 0; a < NV; ++a) y[a] = fma(K.G[a][I], q, y[a]);
+    const double pw = tau * st.lrec[11 + 6 * I + 5] * sqG * DV * FacetConst<D>::trip;
+    double kb[D], skb = 0.0, skd = 0.0;
+#pragma unroll
+    for (int mm = 0; mm < D; ++mm) {
+        kb[mm] = 0.5 * (kf[mm] + knf[mm]);
+        skb += kb[mm];
+        skd = fma(kb[mm], du[mm], skd);
+    }
+    const double base = fma(skb, sdu, skd);
+#pragma unroll
+    for (int mm = 0; mm < D; ++mm) {
+        const double t1 = hm * fma(s_own, sk + kf[mm], s_nb * (skn + knf[mm]));
+        const double t3 = pw * (base + fma(kb[mm], sdu, du[mm] * fma(2.0, kb[mm], skb)));
+        y[mm + (mm >= I)] += t1 + t3;
+    }
+}
+
 template <int D, int MODE>
 __device__ __forceinline__ void emi_cell(const MeshDev& m, const CellGeom<D>& K, const int* nb, uint32_t flags,
                                          const double* xv, const double* kv, double hK,
@@ -307,7 +396,23 @@ __global__ __launch_bounds__(BLK) void k_emi_apply_cls_staged(MeshDev m, const d
     }
     StageView<D> st{TO_LDS(s_x), TO_LDS(s_k), nullptr, nullptr, c0,
                     (unsigned)((m.nc_owned - c0 < BLK) ? (m.nc_owned - c0) : BLK), nullptr, rec};
-    emi_cell<D, 4>(m, K, nb, flags, xv, kv, 0.0, x, kappa, C_phi, tau, st, yv);
+    {
+        double kbar = 0.0;
+#pragma unroll
+        for (int a = 0; a < NV; ++a) kbar += kv[a];
+        kbar *= K.vol / (double)NV;
+#pragma unroll
+        for (int a = 0; a < NV; ++a) {
+            double sa = 0.0;
+#pragma unroll
+            for (int b = 0; b < NV; ++b) sa = fma(K.G[a][b], xv[b], sa);
+            yv[a] = kbar * sa;
+        }
+    }
+    emi_facet_cls<D, 0>(m, K, nb, flags, xv, kv, x, kappa, C_phi, tau, st, yv);
+    emi_facet_cls<D, 1>(m, K, nb, flags, xv, kv, x, kappa, C_phi, tau, st, yv);
+    emi_facet_cls<D, 2>(m, K, nb, flags, xv, kv, x, kappa, C_phi, tau, st, yv);
+    emi_facet_cls<D, 3>(m, K, nb, flags, xv, kv, x, kappa, C_phi, tau, st, yv);
     store_nodal<D>(y, c, yv);
 }
 
@@ -766,6 +871,14 @@ int launch_emi_apply(knp_ctx* c, const double* x, const double* kappa, double* y
             if (variant == 6) {
                 const int64_t nblk = (((c->m.nc_owned + 383) / 384 + 7) / 8) * 8;
                 hipLaunchKernelGGL((k_emi_apply_cls_staged<3, 384>), dim3((unsigned)nblk), dim3(384), 0, c->stream, c->m, x, kappa, y,
+                                   c->p.C_phi, c->p.tau_emi);
+            } else if (variant == 7) {
+                const int64_t nblk = (((c->m.nc_owned + 511) / 512 + 7) / 8) * 8;
+                hipLaunchKernelGGL((k_emi_apply_cls_staged<3, 512>), dim3((unsigned)nblk), dim3(512), 0, c->stream, c->m, x, kappa, y,
+                                   c->p.C_phi, c->p.tau_emi);
+            } else if (variant == 8) {
+                const int64_t nblk = (((c->m.nc_owned + 127) / 128 + 7) / 8) * 8;
+                hipLaunchKernelGGL((k_emi_apply_cls_staged<3, 128>), dim3((unsigned)nblk), dim3(128), 0, c->stream, c->m, x, kappa, y,
                                    c->p.C_phi, c->p.tau_emi);
             } else {
                 hipLaunchKernelGGL((k_emi_apply_cls_staged<3, 256>), dim3((unsigned)grid8(c->m.nc_owned)), dim3(256), 0, c->stream,
