@@ -1,0 +1,138 @@
+"""Edge cases and error behaviour of the device path (failure detection; section 8b: errors)."""
+import numpy as np
+import pytest
+
+import knpemi_oracle as ko
+from common import synthetic_state, device_for, push_state, relerr, small_3d
+
+pytestmark = pytest.mark.gpu
+
+
+def test_no_membrane_facets(hip_lib):
+    """A mesh without any membrane tag: pure-Neumann EMI (still singular), KNP decoupled; no ODE nodes."""
+    from knpemidg import _abi as A
+    from knpemidg.mesh import BoxMesh, MeshFunction
+    m = BoxMesh((0, 0, 0), (4e-6, 0.3e-6, 0.3e-6), 4, 3, 3)
+    s = MeshFunction(m, 3, 0)
+    f = MeshFunction(m, 2, 0)
+    f.array()[m.exterior_facets()] = 5
+    pb = ko.build_idealized(m, s.array(), f.array(), membrane_tags=(1,))
+    assert len(pb.mem) == 0
+    x = synthetic_state(pb)
+    dev = device_for(pb)
+    push_state(dev, pb)
+    dev.update_kappa(); dev.update_dnphi()
+    Aemi, b, _ = ko.assemble_emi(pb, want_B=False)
+    dev.upload(A.F_X, x[0]); dev.emi_apply(A.F_X, A.F_Y)
+    assert relerr(dev.download(A.F_Y, 0, pb.ndof), Aemi @ x[0].ravel()) < 1e-11
+    dev.emi_rhs(); dev.knp_rhs()
+    assert relerr(dev.download(A.F_B_EMI), b) < 1e-11
+    dev.step_updates()                                   # no membrane facets: must be a no-op for facet fields
+    assert np.all(dev.download(A.F_PHI_M) == pb.phi_M)
+    dev.close()
+
+
+def test_two_cell_mesh_and_single_species(hip_lib):
+    """Smallest possible meshes / species counts (ragged: nc far below one workgroup)."""
+    from knpemidg import _abi as A
+    from knpemidg.mesh import Mesh, MeshFunction
+    coords = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1], [1, 1, 1.0]]) * 1e-6
+    m = Mesh(coords, np.array([[0, 1, 2, 3], [1, 2, 3, 4]]))
+    s = MeshFunction(m, 3, np.array([0, 1]))
+    f = MeshFunction(m, 2, 0)
+    f.array()[m.interior_facets()] = 1
+    for n_ions in (2, 3):
+        P = ko.idealized_params()
+        ions = [dict(name=n, z=P["z"][n], D=np.full(2, P["D"][n])) for n in ("K", "Cl", "Na")][3 - n_ions:]
+        pb = ko.Problem(m, s.array(), f.array(), 1, ions, P, membrane_tags=(1,))
+        rng = np.random.default_rng(5)
+        pb.c = 50 + 10 * rng.uniform(size=pb.c.shape); pb.c_prev_n = pb.c.copy()
+        pb.c_elim = 60 + 10 * rng.uniform(size=pb.c_elim.shape)
+        pb.phi = 0.05 * rng.uniform(-1, 1, size=pb.phi.shape)
+        pb.phi_M[pb.mem] = -0.07
+        dev = device_for(pb)
+        push_state(dev, pb)
+        dev.update_kappa(); dev.update_dnphi()
+        x = rng.uniform(-1, 1, size=(pb.N_ions, 2, 4))
+        Aemi, b, _ = ko.assemble_emi(pb, want_B=False)
+        dev.upload(A.F_X, np.concatenate([x[0].ravel(), np.zeros((pb.N_ions - 1) * 8)])); dev.emi_apply(A.F_X, A.F_Y)
+        assert relerr(dev.download(A.F_Y, 0, 8), Aemi @ x[0].ravel()) < 1e-11
+        dev.upload(A.F_X, x); dev.knp_apply(A.F_X, A.F_Y)
+        y = dev.download(A.F_Y).reshape(pb.N_ions, -1)
+        for k in range(pb.N_ions):
+            assert relerr(y[k], ko.assemble_knp(pb, k) @ x[k].ravel()) < 1e-11
+        dev.knp_rhs()
+        bk = dev.download(A.F_B_KNP).reshape(pb.N_ions, -1)
+        for k in range(pb.N_ions):
+            assert relerr(bk[k], ko.knp_rhs(pb, k)) < 1e-11
+        dev.close()
+
+
+def test_nonconvergence_raises(hip_lib):
+    """maxit too small -> status -3 -> KnpError (ksp_error_if_not_converged, solver.py:428)."""
+    from knpemidg import _abi as A
+    m, s, f = small_3d()
+    pb = ko.build_idealized(m, s.array(), f.array(), membrane_tags=(1,))
+    synthetic_state(pb)
+    dev = device_for(pb)
+    push_state(dev, pb)
+    dev.update_kappa(); dev.emi_rhs()
+    dev.upload(A.F_PHI, np.zeros(pb.ndof))
+    with pytest.raises(A.KnpError, match="did not converge"):
+        dev.emi_solve(1e-12, maxit=3, check_every=1)
+    dev.update_dnphi(); dev.knp_rhs()
+    with pytest.raises(A.KnpError, match="did not converge"):
+        dev.knp_solve(1e-14, maxit=6, min_it=5, check_every=1)
+    dev.close()
+
+
+def test_bad_arguments_are_rejected(hip_lib):
+    from knpemidg import _abi as A
+    from knpemidg.mesh import make_mesh_2D
+    m, s, f = make_mesh_2D(1)
+    pb = ko.build_idealized(m, s.array(), f.array(), membrane_tags=(1,))
+    dev = device_for(pb)
+    with pytest.raises(A.KnpError):
+        dev.upload(A.F_PHI_M, np.zeros(dev.nf + 1))                 # out of bounds
+    with pytest.raises(A.KnpError):
+        dev.emi_apply(A.F_X, A.F_X)                                 # in-place apply
+    with pytest.raises(A.KnpError):
+        dev.emi_apply(A.F_PHI_M, A.F_Y)                             # facet field is not a nodal vector
+    with pytest.raises(A.KnpError):
+        dev.set_params(0.02, 0.0, 96485, 8.314, 300, 200, 40, 40, [1, -1, 1], np.ones((3, dev.nc)))     # dt = 0
+    with pytest.raises(A.KnpError):
+        dev.set_params(0.02, 1e-4, 96485, 8.314, 300, 200, 40, 40, [1, 0, 1], np.ones((3, dev.nc)))     # z = 0
+    dev.close()
+    bad = m.facet_cells.copy()
+    bad[0, 0] = m.num_cells() + 7
+
+    class Fake:
+        pass
+    fm = Fake()
+    fm.coords, fm.cells, fm.gdim, fm.facet_cells, fm.facet_local = m.coords, m.cells, 2, bad, m.facet_local
+    fm.cell_midpoints = m.cell_midpoints
+    fm.cell_facets = m.cell_facets
+    with pytest.raises((A.KnpError, IndexError)):
+        A.Device(fm, s.array(), f.array(), [1], 3, reorder=False)
+
+
+def test_results_are_bitwise_reproducible(hip_lib):
+    """Atomics-free applies and fixed-order reductions: two identical solves give identical bits
+    (race detection by deterministic double run)."""
+    from knpemidg import _abi as A
+    m, s, f = small_3d()
+    pb = ko.build_idealized(m, s.array(), f.array(), membrane_tags=(1,))
+    synthetic_state(pb)
+    outs = []
+    for _ in range(2):
+        dev = device_for(pb)
+        push_state(dev, pb)
+        dev.update_kappa(); dev.emi_rhs()
+        dev.upload(A.F_PHI, np.zeros(pb.ndof))
+        n1, _ = dev.emi_solve(1e-9, maxit=20000)
+        dev.update_dnphi(); dev.knp_rhs()
+        n2, _ = dev.knp_solve(1e-10, maxit=2000)
+        outs.append((dev.download(A.F_PHI), dev.download(A.F_C), n1, tuple(n2)))
+        dev.close()
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    assert outs[0][2:] == outs[1][2:]
