@@ -64,7 +64,8 @@ const char* knp_last_error(knp_ctx* ctx);
 
 /* Physical parameters (Solver.setup_parameters, solver.py:124-154; tau: solver.py:109-111).
  *  z[n_ions], D[n_ions][nc] (make_global, solver.py:1244-1258), rho[nc], fsrc[n_sys][nc] or NULL
- *  (ion['f_source'] on dx(0), solver.py:599), splitting: solver.py:332-337, 614-622. */
+ *  (ion['f_source'] on dx(0), solver.py:599), splitting: 1 = splitting scheme, 0 = original Robin
+ *  data (solver.py:332-337, 614-622), 2 = manufactured-solution mode (knp_set_mms). */
 int knp_set_params(knp_ctx* ctx, double C_M, double dt, double F, double R, double T, double C_phi,
                    double tau_emi, double tau_knp, const double* z, const double* D, const double* rho,
                    const double* fsrc, int splitting);
@@ -73,6 +74,12 @@ int knp_set_params(knp_ctx* ctx, double C_M, double dt, double F, double R, doub
  * positions share one 36-double record {vol, G upper triangle (10), per facet: L[4], sqrt(G_ii), 2/(h+h')}; the
  * operator applies then read no coordinates at all.  ncls = 0 switches back to the coordinate path. */
 int knp_set_geometry_classes(knp_ctx* ctx, int ncls, const uint16_t* cls, const double* table);
+
+/* Manufactured-solution mode (Solver(mms=...), solver.py:349-374, 632-657): splitting = 2 in knp_set_params selects
+ * it.  C[n_sys][nc] are the DG0 coupling coefficients ion['C']; extra_emi[nc*nd] / extra_knp[n_sys][nc*nd] are the
+ * solution-independent data terms (volume sources, Robin and flux-continuity data, Neumann data) integrated on the
+ * host and added to L_emi / L_knp; the solution-dependent term -jump(phi) jump(C v) is evaluated on the device. */
+int knp_set_mms(knp_ctx* ctx, const double* C, const double* extra_emi, const double* extra_knp);
 
 int64_t knp_field_size(knp_ctx* ctx, int field);
 int knp_upload(knp_ctx* ctx, int field, const double* src, int64_t offset, int64_t count);

@@ -206,7 +206,7 @@ void knp_ctx_destroy(knp_ctx* c) {
         g_fields.erase(c);
     }
     hipFree(c->m.cls); hipFree(c->m.cls_table); hipFree(c->m.coords); hipFree(c->m.h); hipFree(c->m.cells); hipFree(c->m.nbr); hipFree(c->m.fflag); hipFree(c->m.cfacet); hipFree(c->m.mf);
-    hipFree(c->D); hipFree(c->rho); hipFree(c->fsrc); hipFree(c->partial); hipFree(c->scal); hipFree(c->status);
+    hipFree(c->D); hipFree(c->rho); hipFree(c->fsrc); hipFree(c->mms_C); hipFree(c->extra_emi); hipFree(c->extra_knp); hipFree(c->partial); hipFree(c->scal); hipFree(c->status);
     hipFree(c->halo_send_idx); hipFree(c->halo_sendbuf);
     if (c->pinned) hipHostFree(c->pinned);
     if (c->ev0) hipEventDestroy(c->ev0);
@@ -223,6 +223,7 @@ int knp_set_params(knp_ctx* c, double C_M, double dt, double Fc, double R, doubl
     Params& p = c->p;
     p.C_M = C_M; p.dt = dt; p.F = Fc; p.R = R; p.T = T; p.C_phi = C_phi; p.psi = Fc / (R * T);
     p.tau_emi = tau_emi; p.tau_knp = tau_knp; p.splitting = splitting;
+    if (splitting == 2 && !c->mms_C) { c->err = "MMS mode needs knp_set_mms first"; return -1; }
     for (int i = 0; i < p.n_ions; ++i) {
         p.z[i] = z[i];
         if (z[i] == 0.0) { c->err = "ion valence z must be non-zero"; return -1; }
@@ -260,6 +261,26 @@ int knp_set_geometry_classes(knp_ctx* c, int ncls, const uint16_t* cls, const do
     HIPCHK(c, hipMalloc((void**)&c->m.cls_table, sizeof(double) * (size_t)ncls * KNP_CLS_STRIDE));
     HIPCHK(c, hipMemcpy(c->m.cls_table, table, sizeof(double) * (size_t)ncls * KNP_CLS_STRIDE, hipMemcpyHostToDevice));
     c->m.ncls = ncls;
+    return 0;
+}
+
+int knp_set_mms(knp_ctx* c, const double* C, const double* extra_emi, const double* extra_knp) {
+    if (!c) return -1;
+    const int64_t ndof = c->m.nc * c->nd, ns = c->p.n_sys;
+    hipFree(c->mms_C); hipFree(c->extra_emi); hipFree(c->extra_knp);
+    c->mms_C = c->extra_emi = c->extra_knp = nullptr;
+    if (C) {
+        HIPCHK(c, hipMalloc((void**)&c->mms_C, sizeof(double) * ns * c->m.nc));
+        HIPCHK(c, hipMemcpy(c->mms_C, C, sizeof(double) * ns * c->m.nc, hipMemcpyHostToDevice));
+    }
+    if (extra_emi) {
+        HIPCHK(c, hipMalloc((void**)&c->extra_emi, sizeof(double) * ndof));
+        HIPCHK(c, hipMemcpy(c->extra_emi, extra_emi, sizeof(double) * ndof, hipMemcpyHostToDevice));
+    }
+    if (extra_knp) {
+        HIPCHK(c, hipMalloc((void**)&c->extra_knp, sizeof(double) * ns * ndof));
+        HIPCHK(c, hipMemcpy(c->extra_knp, extra_knp, sizeof(double) * ns * ndof, hipMemcpyHostToDevice));
+    }
     return 0;
 }
 

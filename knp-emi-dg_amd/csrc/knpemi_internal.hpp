@@ -59,6 +59,10 @@ struct knp_ctx {
     double* D = nullptr;           // [n_ions][nc]
     double* rho = nullptr;         // [nc]
     double* fsrc = nullptr;        // [n_sys][nc] DG0 source on ECS cells, or null
+    // manufactured-solution mode (splitting == 2): constant coupling coefficients + host-integrated data terms
+    double* mms_C = nullptr;       // [n_sys][nc]
+    double* extra_emi = nullptr;   // [nc*nd]
+    double* extra_knp = nullptr;   // [n_sys][nc*nd]
     std::map<int, double*> vecs;   // handle -> device pointer
     std::map<int, int64_t> vlen;
     int next_handle = 1;

@@ -90,6 +90,7 @@ __device__ __forceinline__ void emi_rhs_facet(const MeshDev& m, const CellGeom<D
     const int64_t Kp = nb[I];
     if (kind == FK_MEMBRANE) {
         const int64_t f = m.cfacet[c * NV + I];
+        if (splitting == 2) return;                                 // MMS: Robin data arrives as host-integrated extra RHS
         double g = phiM[f];
         if (!splitting) {
             double It = 0.0;
@@ -135,7 +136,7 @@ __global__ __launch_bounds__(KNP_BLOCK) void k_emi_rhs(MeshDev m, const double* 
                                                        const double* __restrict__ celim, const double* __restrict__ Dall,
                                                        const double* __restrict__ phiM, const double* __restrict__ Ich,
                                                        double* __restrict__ bout, IonArgs ia, double F, double C_phi,
-                                                       int splitting) {
+                                                       int splitting, const double* __restrict__ extra) {
     constexpr int NV = D + 1;
     const int64_t c = (int64_t)blockIdx.x * KNP_BLOCK + threadIdx.x;
     if (c >= m.nc_owned) return;
@@ -165,6 +166,12 @@ __global__ __launch_bounds__(KNP_BLOCK) void k_emi_rhs(MeshDev m, const double* 
     emi_rhs_facet<D, 1>(m, K, c, nb, flags, cc, celim, Dall, phiM, Ich, ia, F, C_phi, splitting, b);
     emi_rhs_facet<D, 2>(m, K, c, nb, flags, cc, celim, Dall, phiM, Ich, ia, F, C_phi, splitting, b);
     if (D == 3) emi_rhs_facet<D, (D == 3 ? 3 : 0)>(m, K, c, nb, flags, cc, celim, Dall, phiM, Ich, ia, F, C_phi, splitting, b);
+    if (extra) {
+        double ev[NV];
+        load_nodal<D>(extra, c, ev);
+#pragma unroll
+        for (int a = 0; a < NV; ++a) b[a] += ev[a];
+    }
     store_nodal<D>(bout, c, b);
 }
 
@@ -174,6 +181,8 @@ __global__ __launch_bounds__(KNP_BLOCK) void k_emi_rhs(MeshDev m, const double* 
 struct KnpRhsArgs {
     double F, C_M, dt;
     int splitting;
+    const double* mms_C;      // [n_sys][nc] in MMS mode
+    const double* extra;      // [n_sys][nc*nd] or null
 };
 
 template <int D, int I>
@@ -207,6 +216,17 @@ __device__ __forceinline__ void knp_rhs_facet(const MeshDev& m, const CellGeom<D
         pnf[mm] = pick_facet<D>(pn, mm, j);
     }
     const double sgn = is_e ? -1.0 : 1.0;
+    if (ra.splitting == 2) {
+        // MMS (solver.py:649-650): -(phi_i - phi_e)(C_i v_i - C_e v_e) with DG0 C; P1 phi -> exact facet mass matrix
+        const double Cown = ra.mms_C[(int64_t)k * m.nc + c];
+        double dph[D], sd = 0.0;
+#pragma unroll
+        for (int mm = 0; mm < D; ++mm) { dph[mm] = is_e ? (pnf[mm] - pf[mm]) : (pf[mm] - pnf[mm]); sd += dph[mm]; }
+        const double w = -sgn * Cown * area * ((D == 3) ? 1.0 / 12.0 : 1.0 / 6.0);
+#pragma unroll
+        for (int mm = 0; mm < D; ++mm) b[mm + (mm >= I)] += w * (sd + dph[mm]);
+        return;
+    }
     using Rule = FacetRule<D, 5>;
 #pragma unroll
     for (int q = 0; q < Rule::nq; ++q) {
@@ -278,6 +298,12 @@ __global__ __launch_bounds__(KNP_BLOCK) void k_knp_rhs(MeshDev m, const double* 
         knp_rhs_facet<D, 1>(m, K, c, nb, flags, k, zk, Dk, ck, asum, pv, phi, phiM, Ich, ia, ra, b);
         knp_rhs_facet<D, 2>(m, K, c, nb, flags, k, zk, Dk, ck, asum, pv, phi, phiM, Ich, ia, ra, b);
         if (D == 3) knp_rhs_facet<D, (D == 3 ? 3 : 0)>(m, K, c, nb, flags, k, zk, Dk, ck, asum, pv, phi, phiM, Ich, ia, ra, b);
+    }
+    if (ra.extra) {
+        double ev[NV];
+        load_nodal<D>(ra.extra + (int64_t)k * m.nc * NV, c, ev);
+#pragma unroll
+        for (int a = 0; a < NV; ++a) b[a] += ev[a];
     }
     store_nodal<D>(bout + (int64_t)k * m.nc * NV, c, b);
 }
@@ -400,13 +426,13 @@ int launch_kappa(knp_ctx* c, const double* cc, const double* celim, double* kapp
 
 int launch_emi_rhs(knp_ctx* c, const double* cc, const double* celim, const double* phiM, const double* Ich, double* b) {
     DISPATCH_DIM(c, k_emi_rhs, dim3((unsigned)grid_for(c->m.nc_owned)), c->m, cc, celim, c->D, phiM, Ich, b,
-                 ion_args(c), c->p.F, c->p.C_phi, c->p.splitting);
+                 ion_args(c), c->p.F, c->p.C_phi, c->p.splitting, (const double*)c->extra_emi);
     return 0;
 }
 
 int launch_knp_rhs(knp_ctx* c, const double* cc, const double* cprev, const double* celim, const double* phi,
                    const double* phiM, const double* Ich, double* b) {
-    KnpRhsArgs ra{c->p.F, c->p.C_M, c->p.dt, c->p.splitting};
+    KnpRhsArgs ra{c->p.F, c->p.C_M, c->p.dt, c->p.splitting, (const double*)c->mms_C, (const double*)c->extra_knp};
     DISPATCH_DIM(c, k_knp_rhs, dim3((unsigned)grid_for(c->m.nc_owned), (unsigned)c->p.n_sys), c->m, cc, cprev, celim, phi,
                  c->D, phiM, Ich, (const double*)c->fsrc, b, ion_args(c), ra);
     return 0;

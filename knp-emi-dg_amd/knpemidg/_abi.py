@@ -30,6 +30,7 @@ SIGNATURES = {
     "knp_last_error": (C.c_char_p, [_ctxp]),
     "knp_set_params": (C.c_int, [_ctxp] + [C.c_double] * 8 + [_f64p, _f64p, _f64p, _f64p, C.c_int]),
     "knp_set_geometry_classes": (C.c_int, [_ctxp, C.c_int, C.POINTER(C.c_uint16), _f64p]),
+    "knp_set_mms": (C.c_int, [_ctxp, _f64p, _f64p, _f64p]),
     "knp_field_size": (C.c_int64, [_ctxp, C.c_int]),
     "knp_upload": (C.c_int, [_ctxp, C.c_int, _f64p, C.c_int64, C.c_int64]),
     "knp_download": (C.c_int, [_ctxp, C.c_int, _f64p, C.c_int64, C.c_int64]),
@@ -260,7 +261,15 @@ class Device:
         rho = None if rho is None else np.ascontiguousarray(np.asarray(rho, dtype=np.float64)[o])
         fsrc = None if fsrc is None else np.ascontiguousarray(np.asarray(fsrc, dtype=np.float64)[:, o])
         self._chk(self.lib.knp_set_params(self.ctx, C_M, dt, F, R, T, C_phi, tau_emi, tau_knp, _p(z, _f64p), _p(D, _f64p),
-                                          _p(rho, _f64p), _p(fsrc, _f64p), int(bool(splitting))), "knp_set_params")
+                                          _p(rho, _f64p), _p(fsrc, _f64p), int(splitting)), "knp_set_params")
+
+    def set_mms(self, C, extra_emi, extra_knp):
+        """Manufactured-solution data (caller cell order): C [n_sys, nc], extra_emi [nc, nd], extra_knp [n_sys, nc, nd]."""
+        o = self.cell_order
+        C_ = np.ascontiguousarray(np.asarray(C, dtype=np.float64)[:, o])
+        ee = np.ascontiguousarray(np.asarray(extra_emi, dtype=np.float64).reshape(self.nc, self.nd)[o])
+        ek = np.ascontiguousarray(np.asarray(extra_knp, dtype=np.float64).reshape(self.n_sys, self.nc, self.nd)[:, o])
+        self._chk(self.lib.knp_set_mms(self.ctx, _p(C_, _f64p), _p(ee, _f64p), _p(ek, _f64p)), "knp_set_mms")
 
     def size(self, field):
         return int(self.lib.knp_field_size(self.ctx, field))

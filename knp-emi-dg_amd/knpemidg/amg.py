@@ -194,7 +194,13 @@ def build_hierarchy(A, theta=0.08, max_coarse=1000, max_levels=12, cheb_degree=2
         A = (lv.R @ A @ P).tocsr()
         A.sort_indices()
     last = levels[-1]
-    last.pinv = np.linalg.pinv(last.A.toarray(), hermitian=True, rcond=1e-12)
+    # dense pseudo-inverse through the eigen-decomposition: the constant mode of the singular EMI operator reaches
+    # the coarsest level as a tiny but non-zero eigenvalue (smoothed prolongators do not reproduce constants to
+    # rounding); inverting it would put a huge indefinite component into the V-cycle, so everything below 1e-9 of
+    # the largest eigenvalue counts as null space
+    w, V = np.linalg.eigh(0.5 * (last.A.toarray() + last.A.toarray().T))
+    keep = w > 1e-9 * w.max()
+    last.pinv = (V[:, keep] / w[keep]) @ V[:, keep].T
     return levels
 
 

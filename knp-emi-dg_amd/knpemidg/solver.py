@@ -199,10 +199,8 @@ class Solver:
     def _ensure_device(self, membrane_tags=None):
         if self.dev is not None:
             return
-        if self.mms is not None:
-            raise NotImplementedError("MMS source terms are not on the device path yet (SURVEY.md section 8f-4)")
         if membrane_tags is None:
-            membrane_tags = [m['ode'].tag for m in self.mem_models]
+            membrane_tags = list(self.lm_tags) if self.mms is not None else [m['ode'].tag for m in self.mem_models]
         self.membrane_tags = list(membrane_tags)
         nc = self.mesh.num_cells()
         self.dev = _abi.Device(self.mesh, self.subdomains.array(), self.surfaces.array(), self.membrane_tags,
@@ -240,7 +238,14 @@ class Solver:
     def setup_varform_emi(self):
         """The bilinear / linear forms are fixed kernels; only the splitting flag is data."""
         self._ensure_device()
-        self._push_params(self.splitting_scheme)
+        if self.mms is not None:
+            # manufactured solution (solver.py:349-374, 632-657): data terms integrated once on the host
+            from knpemidg.mms_terms import extra_rhs
+            Cdev, e_emi, e_knp = extra_rhs(self)
+            self.dev.set_mms(Cdev, e_emi, e_knp)
+            self._push_params(2)
+        else:
+            self._push_params(self.splitting_scheme)
         self.I_ch = [None] * len(self.mem_models)
         return
 
@@ -249,7 +254,10 @@ class Solver:
 
     def setup_solver_emi(self):
         self._read_solver_params()
-        if self.use_amg:
+        # direct_emi (MUMPS in the reference, solver.py:412-422) is emulated by a tightly converged PCG with the plain
+        # block-Jacobi preconditioner: it stays SPD to rounding for any coefficient contrast (the MMS problem couples
+        # the membrane with C_phi = 1e10), which a V-cycle does not
+        if self.use_amg and not self.direct_emi:
             self._setup_amg_emi()
         return
 
@@ -284,7 +292,7 @@ class Solver:
             print(" AMG(EMI) levels:", [lv.A.shape[0] for lv in levels], "setup %.2f s" % self.amg_setup_timer)
 
     def setup_solver_knp(self):
-        if self.use_amg:
+        if self.use_amg and not self.direct_knp:
             self._setup_amg_knp()
         return
 
@@ -330,9 +338,9 @@ class Solver:
         self.max_it_knp = int(getattr(sp, "max_it_knp", self.max_it_knp))
         # direct solvers (MUMPS, solver.py:412-422, 671-681) have no device counterpart: emulate with a tight
         # iterative tolerance
-        self._rtol_emi = 1e-12 if self.direct_emi else float(self.rtol_emi)
+        self._rtol_emi = float(getattr(sp, "rtol_direct", 1e-10)) if self.direct_emi else float(self.rtol_emi)
         self._atol_emi = 1e-40 if self.direct_emi else float(self.atol_emi)
-        self._rtol_knp = 1e-12 if self.direct_knp else float(self.rtol_knp)
+        self._rtol_knp = float(getattr(sp, "rtol_direct", 1e-10)) if self.direct_knp else float(self.rtol_knp)
         self._atol_knp = 1e-40 if self.direct_knp else float(self.atol_knp)
 
     def _sync_membrane_to_device(self):
