@@ -145,8 +145,8 @@ def geometry_classes(mesh, order, max_classes=4096, tol=1.0e-9):
     _, first, inv = np.unique(np.stack([h1, h2], axis=1), axis=0, return_index=True, return_inverse=True)
     inv = inv.ravel()
     ncls = len(first)
-    if ncls > max_classes:
-        return None
+    if ncls > max_classes or ncls > max(64, nc // 8):
+        return None          # not (block-)structured: the coordinate-path kernels are the right tool
     if not np.array_equal(q[first][inv], q):               # hash collision (astronomically unlikely): give up
         return None
     # records of the representatives

@@ -196,3 +196,44 @@ def test_partitioned_kernels_on_one_gpu(hip_lib, world):
         assert relerr(dev.download(A.F_E).reshape(3, -1)[:, lmem], Eg[:, pos]) < 1e-12
         assert relerr(dev.download(A.F_C_ELIM).reshape(-1, pbl.nd), q.c_elim[cg]) < 1e-14
         dev.close()
+
+
+def test_unstructured_geometry_uses_coordinate_kernels(hip_lib):
+    """Randomly jittered vertices destroy the translation invariance of the BoxMesh: no geometry classes can be
+    formed, so the general coordinate-path kernels (geometry recomputed from vertex coordinates in registers) run.
+    Also exercises non-uniform h, varying facet areas and cell volumes."""
+    from knpemidg import _abi as A
+    from common import small_3d
+    m, s, f = small_3d((10, 4, 4))
+    rng = np.random.default_rng(11)
+    interior_v = np.ones(m.num_vertices(), dtype=bool)
+    interior_v[np.unique(m.facets[m.exterior_facets()])] = False
+    jit = rng.uniform(-1, 1, size=m.coords.shape) * np.array([0.2e-6, 0.02e-6, 0.02e-6])
+    m.coords[interior_v] += jit[interior_v]
+    pb = ko.build_idealized(m, s.array(), f.array(), membrane_tags=(1,))
+    x = synthetic_state(pb)
+    dev = device_for(pb)
+    assert dev.n_geometry_classes == 0
+    push_state(dev, pb)
+    dev.update_kappa(); dev.update_dnphi()
+    Aemi, b, _ = ko.assemble_emi(pb, want_B=False)
+    dev.upload(A.F_X, x[0]); dev.emi_apply(A.F_X, A.F_Y)
+    assert relerr(dev.download(A.F_Y, 0, pb.ndof), Aemi @ x[0].ravel()) < TOL
+    dev.upload(A.F_X, x); dev.knp_apply(A.F_X, A.F_Y)
+    y = dev.download(A.F_Y).reshape(pb.N_ions, -1)
+    for k in range(pb.N_ions):
+        assert relerr(y[k], ko.assemble_knp(pb, k) @ x[k].ravel()) < TOL
+    dev.emi_rhs(); dev.knp_rhs()
+    assert relerr(dev.download(A.F_B_EMI), b) < TOL
+    for k in range(pb.N_ions):
+        assert relerr(dev.download(A.F_B_KNP).reshape(pb.N_ions, -1)[k], ko.knp_rhs(pb, k)) < TOL
+    # a converged solve on the unstructured mesh (AMG built from the same conforming operator)
+    from knpemidg import amg
+    cs = amg.ConformingSpace(m, f.array(), (1,))
+    dev.amg_upload(0, cs.dof, amg.build_hierarchy(cs.stiffness(pb.kappa(), membrane=(pb.mem, pb.C_phi))))
+    dev.upload(A.F_PHI, np.zeros(pb.ndof))
+    n, _ = dev.emi_solve(1e-10, maxit=5000)
+    from common import mean_free
+    ref = ko.solve_emi(pb, direct=True)
+    assert relerr(mean_free(dev.download(A.F_PHI), pb.geom.vol), mean_free(ref, pb.geom.vol)) < 1e-6
+    dev.close()
