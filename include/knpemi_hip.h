@@ -129,6 +129,10 @@ int knp_amg_clear(knp_ctx* ctx, int which);
  * C_PREV <- C ; PHI_M <- facet-avg(phi_i - phi_e) ; C_ELIM <- -(sum z_k c_k + rho)/z_N ; E <- Nernst. */
 int knp_step_updates(knp_ctx* ctx);
 int knp_nernst(knp_ctx* ctx);              /* E only, from the current C / C_ELIM (solver.py:299-300) */
+/* Picard variant (solve_for_time_step_picard, solver.py:850-927): per Picard level C_ELIM and E from the current C;
+ * knp_max_abs_diff = inf-norm of the difference of two nodal fields (the eps of solver.py:879-880). */
+int knp_picard_updates(knp_ctx* ctx);
+int knp_max_abs_diff(knp_ctx* ctx, int field_a, int field_b, double* out);
 /* FACET_TMP <- facet average of the plus (side 0, ECS-like) or minus (side 1) trace of a nodal field;
  * species indexes into [n_sys] fields (update_ode hook, examples/idealized-geometries/run_3D.py:39-51). */
 int knp_facet_trace(knp_ctx* ctx, int field, int species, int side);

@@ -394,6 +394,20 @@ int knp_step_updates(knp_ctx* c) {
 
 
 
+// Picard level update (solver.py:882-910): C_ELIM and E from the current C; phi_M and C_PREV are left alone
+int knp_picard_updates(knp_ctx* c) {
+    if (!c) return -1;
+    Fields* f = F(c);
+    return launch_step_updates(c, f->f[KNP_F_C], f->f[KNP_F_C_ELIM], nullptr, nullptr, f->f[KNP_F_E]);
+}
+
+int knp_max_abs_diff(knp_ctx* c, int fa, int fb, double* out) {
+    if (chk_field(c, fa) || chk_field(c, fb) || !out) return -1;
+    const int64_t ndof = c->m.nc * c->nd;
+    if (F(c)->n[fa] != F(c)->n[fb] || F(c)->n[fa] % ndof) { c->err = "max_abs_diff: nodal fields of equal size expected"; return -1; }
+    return max_abs_diff(c, F(c)->f[fa], F(c)->f[fb], (int)(F(c)->n[fa] / ndof), out);
+}
+
 int knp_nernst(knp_ctx* c) {
     if (!c) return -1;
     Fields* f = F(c);

@@ -34,6 +34,16 @@ int allreduce_red(knp_ctx* c, double* red, int count) {
     return 0;
 }
 
+int allreduce_max(knp_ctx* c, double* host_value) {
+    if (!c->comm) { c->err = "allreduce without communicator"; return -6; }
+    double* d = c->scal + KNP_MAX_SYS * 12;            // reduction scratch (krylov.hpp: KS_N = 12)
+    HIPCHK(c, hipMemcpyAsync(d, host_value, sizeof(double), hipMemcpyHostToDevice, c->stream));
+    NCCLCHK(c, ncclAllReduce(d, d, 1, ncclDouble, ncclMax, (ncclComm_t)c->comm, c->stream));
+    HIPCHK(c, hipMemcpyAsync(host_value, d, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
 // out layout for one peer: [field][cell][nv]
 __global__ void k_halo_pack(const double* __restrict__ v, const int32_t* __restrict__ idx, int64_t cnt, int nfields,
                             int64_t field_stride, int nv, double* __restrict__ out) {

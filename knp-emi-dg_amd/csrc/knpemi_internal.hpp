@@ -119,3 +119,5 @@ int64_t grid_for(int64_t n);
 int launch_nernst_only(knp_ctx* c, const double* cc, const double* celim, double* E);
 void comm_destroy(knp_ctx* c);
 int allreduce_red(knp_ctx* c, double* red, int count);
+int allreduce_max(knp_ctx* c, double* host_value);
+int max_abs_diff(knp_ctx* c, const double* a, const double* b, int nsys, double* out);

@@ -417,6 +417,42 @@ __global__ __launch_bounds__(KNP_BLOCK) void k_bi_x(VecDims d, const double* __r
     write_partials<2>(partial, d.nsys, acc);
 }
 
+// inf-norm of a - b over the owned part of an [nsys][nc*NV] field (Picard stopping test, solver.py:879-880)
+__global__ __launch_bounds__(KNP_BLOCK) void k_max_abs_diff(int64_t n_owned, int64_t stride, int nsys, const double* __restrict__ a,
+                                                            const double* __restrict__ b, double* __restrict__ partial) {
+    __shared__ double lds[KNP_BLOCK / 64];
+    double v = 0.0;
+    for (int s = 0; s < nsys; ++s)
+        for (int64_t i = (int64_t)blockIdx.x * KNP_BLOCK + threadIdx.x; i < n_owned; i += (int64_t)gridDim.x * KNP_BLOCK)
+            v = fmax(v, fabs(a[s * stride + i] - b[s * stride + i]));
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_down(v, off, 64));
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < KNP_BLOCK / 64; ++w) v = fmax(v, lds[w]);
+        partial[blockIdx.x] = v;
+    }
+}
+
+int max_abs_diff(knp_ctx* c, const double* a, const double* b, int nsys, double* out) {
+    const int nb = 256;
+    const int64_t n_owned = c->m.nc_owned * c->nd, stride = c->m.nc * c->nd;
+    hipLaunchKernelGGL(k_max_abs_diff, dim3(nb), dim3(KNP_BLOCK), 0, c->stream, n_owned, stride, nsys, a, b, c->partial);
+    HIPCHK(c, hipGetLastError());
+    std::vector<double> h(nb);
+    HIPCHK(c, hipMemcpyAsync(h.data(), c->partial, sizeof(double) * nb, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    double m = 0.0;
+    for (double v : h) m = v > m ? v : m;
+    if (c->nranks > 1) {
+        int rc = allreduce_max(c, &m);
+        if (rc) return rc;
+    }
+    *out = m;
+    return 0;
+}
+
 // ---- host drivers ---------------------------------------------------------------------------------
 
 

@@ -45,6 +45,8 @@ SIGNATURES = {
     "knp_knp_solve": (C.c_int, [_ctxp, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), _f64p]),
     "knp_step_updates": (C.c_int, [_ctxp]),
     "knp_nernst": (C.c_int, [_ctxp]),
+    "knp_picard_updates": (C.c_int, [_ctxp]),
+    "knp_max_abs_diff": (C.c_int, [_ctxp, C.c_int, C.c_int, _f64p]),
     "knp_facet_trace": (C.c_int, [_ctxp, C.c_int, C.c_int, C.c_int]),
     "knp_sync": (C.c_int, [_ctxp]),
     "knp_timer_begin": (C.c_int, [_ctxp]),
@@ -338,6 +340,14 @@ class Device:
 
     def step_updates(self):
         self._chk(self.lib.knp_step_updates(self.ctx), "knp_step_updates")
+
+    def picard_updates(self):
+        self._chk(self.lib.knp_picard_updates(self.ctx), "knp_picard_updates")
+
+    def max_abs_diff(self, fa, fb):
+        out = np.zeros(1)
+        self._chk(self.lib.knp_max_abs_diff(self.ctx, fa, fb, _p(out, _f64p)), "knp_max_abs_diff")
+        return float(out[0])
 
     def nernst(self):
         self._chk(self.lib.knp_nernst(self.ctx), "knp_nernst")

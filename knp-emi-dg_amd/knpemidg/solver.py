@@ -429,6 +429,31 @@ class Solver:
         t.assign(float(t + self.dt))
         return
 
+    # ------------------------------------------------------------------ Picard variant (solver.py:850-927)
+    def solve_for_time_step_picard(self, k, t):
+        """One global step with inner Picard iterations on the two PDE solves (tolerance 1e-4 on the inf-norm of the
+        concentration update, at most 25 iterations, then sys.exit(2) -- reference semantics)."""
+        if self.verbose:
+            print(f"{bcolors.WARNING} t = {float(t)}  k = {k} (Picard) {bcolors.ENDC}")
+        t.assign(float(t + self.dt))
+        tol, eps, max_iter, it = 1.0e-4, 2.0, 25, 0
+        A = _abi
+        while eps > tol:
+            it += 1
+            self.dev.copy_field(A.F_X, A.F_C)               # c_prev_k of this Picard level
+            self.solve_emi()
+            self.solve_knp()
+            eps = self.dev.max_abs_diff(A.F_X, A.F_C)
+            self.dev.picard_updates()                       # c_prev_k <- c (same field), E_k, c_elim for the next level
+            if it > max_iter:
+                print("Picard solver diverged")
+                sys.exit(2)
+        self.dev.step_updates()                             # c_prev_n <- c_prev_k, phi_M, (E_k, c_elim unchanged)
+        self.picard_iters = getattr(self, "picard_iters", []) + [it]
+        if self.verbose:
+            print(f" Summary Picard: eps = {eps}, #iters = {it}")
+        return
+
     def _unpack_solver_params(self, solver_params):
         self.solver_params = solver_params
         self.direct_emi = solver_params.direct_emi

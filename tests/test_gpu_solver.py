@@ -224,3 +224,27 @@ def test_mms_space_convergence_on_device(hip_lib):
     ref = omms.l2_errors(pb)
     for key in ("a", "b", "c", "phi"):
         assert abs(errs[-1][key] - ref[key]) < 2e-3 * ref[key], (key, errs[-1][key], ref[key])
+
+
+def test_picard_variant(hip_lib):
+    """solve_for_time_step_picard (solver.py:850-927): converges in a few Picard levels and lands close to the plain
+    splitting step for a small time step (both are consistent discretisations of the same coupled step)."""
+    from common_examples import make_solver, solver_parameters, Constant
+    res = []
+    for picard in (False, True):
+        S = make_solver(dim=3, resolution=0, n_axons=1, mesh_tuple=small_3d())
+        S._unpack_solver_params(solver_parameters(3, 0)._replace(rtol_emi=1e-9, rtol_knp=1e-11))
+        S.save_fields = S.save_solver_stats = False
+        S.splitting_scheme = True
+        S.setup_varform_emi(); S.setup_varform_knp(); S.setup_solver_emi(); S.setup_solver_knp()
+        t = Constant(0.0)
+        for k in range(2):
+            S.step_membrane_models(k)
+            (S.solve_for_time_step_picard if picard else S.solve_for_time_step)(k, t)
+        res.append((S.c.array(), S.phi_M_prev_PDE.array(), getattr(S, "picard_iters", None)))
+        assert abs(float(t) - 2e-4) < 1e-12
+        S.dev.close()
+    assert all(1 <= n <= 25 for n in res[1][2])
+    assert relerr(res[1][0], res[0][0]) < 1e-3
+    mem = np.nonzero(res[0][1])[0]
+    assert relerr(res[1][1][mem], res[0][1][mem]) < 1e-2
