@@ -1,0 +1,74 @@
+#!/usr/bin/python3
+"""Time-convergence test with a manufactured solution on the HIP path (reference: tests/run_MMS_time.py:16-289):
+fixed 2^r x 2^r mesh, dt = 1e-2 / 2^i, end time 2e-2; the scheme (backward Euler + splitting, data at the old time
+level) is first order in time."""
+import os
+import sys
+from collections import namedtuple
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(HERE)), "knp-emi-dg_amd"))
+sys.path.insert(0, HERE)
+
+from knpemidg import Solver, Constant, make_mesh_MMS            # noqa: E402
+from knpemidg.quadrature import simplex_rule                     # noqa: E402
+from mms_time import setup_mms                                   # noqa: E402
+
+
+def run(i, resolution=6, dt_0=1.0e-2, verbose=False):
+    dt = dt_0 / 2 ** i
+    Tstop = dt_0 * 2
+    names = ('D_a1', 'D_a2', 'D_b1', 'D_b2', 'D_c1', 'D_c2', 'C_a1', 'C_a2', 'C_b1', 'C_b2', 'C_c1', 'C_c2', 'C_phi',
+             'z_a', 'z_b', 'z_c', 'dt', 'F', 'C_M', 'phi_M_init', 'R', 'temperature', 'phi_M_init_type', 'rho_sub')
+    C_M = 1.0
+    vals = (6, 5, 3, 4, 1, 2, 1, 2, 2, 4, 3, 2, C_M / dt, 1.0, -1.0, 1.0, dt, 1.0, C_M, None, 1.0, 1.0, 'expression',
+            {0: 0.0, 1: 0.0, 2: 0.0})                                                      # run_MMS_time.py:49-70
+    params = namedtuple('params', names)(*vals)
+    mesh, subdomains, surfaces = make_mesh_MMS(resolution)
+    t = Constant(0.0)
+    mms = setup_mms(params, t)
+    sol, rhs = mms.solution, mms.rhs
+
+    def ion(s, name):
+        return {'D_sub': {1: getattr(params, 'D_%s1' % s), 0: getattr(params, 'D_%s2' % s)}, 'z': getattr(params, 'z_' + s),
+                'c_init_sub': {1: sol['c_%s1_init' % s], 0: sol['c_%s2_init' % s]}, 'c_init_sub_type': 'expression',
+                'f1': rhs['volume_c_%s1' % s], 'f2': rhs['volume_c_%s2' % s],
+                'g_robin_1': rhs['bdry']['u_%s1' % s], 'g_robin_2': rhs['bdry']['u_%s2' % s],
+                'bdry': rhs['bdry']['neumann_' + s], 'C_sub': {1: getattr(params, 'C_%s1' % s), 0: getattr(params, 'C_%s2' % s)},
+                'name': name, 'f_source': 0.0}
+    ion_list = [ion('a', 'Na'), ion('b', 'K'), ion('c', 'Cl')]
+    S = Solver(params=params, ion_list=ion_list, degree_emi=1, degree_knp=1, mms=mms)
+    S.verbose = verbose
+    S.setup_domain(mesh, subdomains, surfaces)
+    S.setup_parameters()
+    S.setup_FEM_spaces()
+    sp = namedtuple('solver_params', ('direct_emi', 'direct_knp', 'resolution', 'rtol_emi', 'rtol_knp', 'atol_emi',
+                                      'atol_knp', 'threshold_emi', 'threshold_knp'))(True, True, resolution, 1e-6, 1e-7,
+                                                                                     1e-40, 1e-40, 0.9, 7.5)
+    uh, uh_cc = S.solve_system_passive(Tstop, t, sp, None)
+    fields = {'a': uh[0].array(), 'b': uh[1].array(), 'c': uh_cc.array(), 'phi': uh[2].array()}
+    bary, w = simplex_rule(2, 5)
+    x = mesh.coords[mesh.cells]
+    X = np.einsum("ql,cld->cqd", bary, x)
+    J = (x[:, 1:, :] - x[:, :1, :]).transpose(0, 2, 1)
+    wq = w[None, :] * (np.abs(np.linalg.det(J)) / 2.0)[:, None]
+    ics = (subdomains.array() == 1)[:, None]
+    err = {}
+    for s in "abc":                                         # exact fields at the final time (t has been advanced)
+        ex = np.where(ics, sol['c_%s1' % s](X), sol['c_%s2' % s](X))
+        e = ex - np.einsum("ql,cl->cq", bary, fields[s])
+        err[s] = float(np.sqrt((wq * e * e).sum()))
+    S.dev.close()
+    return err, float(t)
+
+
+if __name__ == '__main__':
+    prev = None
+    for i in range(1, int(next((a.split("=")[1] for a in sys.argv if a.startswith("--imax=")), 5)) + 1):
+        e, tend = run(i)
+        rates = {k: np.log(prev[k] / e[k]) / np.log(2) for k in e} if prev else {}
+        print("dt=%.3e t_end=%.3e  " % (1e-2 / 2 ** i, tend) +
+              "  ".join("|%s-%sh|_0 = %.4E [%s]" % (k, k, v, ("%.2f" % rates[k]) if rates else "nan") for k, v in e.items()), flush=True)
+        prev = e

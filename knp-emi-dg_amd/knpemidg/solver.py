@@ -423,6 +423,9 @@ class Solver:
             print(f"{bcolors.WARNING} t = {float(t)} {bcolors.ENDC}")
             print(f"{bcolors.WARNING} k = {k} {bcolors.ENDC}")
             print("------------------------------------------------")
+        if self.mms is not None and getattr(self.mms, "time_dependent", False):
+            from knpemidg.mms_terms import extra_rhs       # data terms at the current t (solver.py:845 advances t last)
+            self.dev.set_mms(*extra_rhs(self))
         self.solve_emi()                    # step I
         self.solve_knp()                    # step II
         self.dev.step_updates()             # step III: c_prev <- c, phi_M, E_k, c_elim

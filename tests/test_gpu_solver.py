@@ -248,3 +248,19 @@ def test_picard_variant(hip_lib):
     assert relerr(res[1][0], res[0][0]) < 1e-3
     mem = np.nonzero(res[0][1])[0]
     assert relerr(res[1][1][mem], res[0][1][mem]) < 1e-2
+
+
+def test_mms_time_convergence_on_device(hip_lib):
+    """The reference's second verification test (tests/run_MMS_time.py) on the HIP path: halving dt halves the
+    concentration errors (first order: backward Euler + splitting with data at the old time level)."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "mms"))
+    import run_MMS_time as R
+    errs = []
+    for i in (1, 2, 3):
+        e, tend = R.run(i, resolution=4)
+        assert abs(tend - 2e-2) < 1e-12
+        errs.append(e)
+    for key in ("a", "b", "c"):
+        r1 = np.log(errs[0][key] / errs[1][key]) / np.log(2)
+        r2 = np.log(errs[1][key] / errs[2][key]) / np.log(2)
+        assert 0.8 < r2 < 1.3 and 0.7 < r1 < 1.4, (key, r1, r2, errs)
