@@ -102,8 +102,10 @@ class MembraneModel:
         self.dof_locations = V.tabulate_dof_coordinates()[self.indices]
         nodes = len(self.indices)
         self.nodes = nodes
-        self._states = np.array([ode.init_state_values() for _ in range(nodes)], dtype=np.float64).reshape(nodes, -1)
-        self._parameters = np.array([ode.init_parameter_values() for _ in range(nodes)], dtype=np.float64).reshape(nodes, -1)
+        s0 = np.asarray(ode.init_state_values(), dtype=np.float64)
+        p0 = np.asarray(ode.init_parameter_values(), dtype=np.float64)
+        self._states = np.tile(s0, (nodes, 1))               # [nodes, n_states]; well-formed for nodes == 0 too
+        self._parameters = np.tile(p0, (nodes, 1))           # (a rank / tag without membrane facets)
         self.tag = tag
         self.ode = ode
         self.prefix = getattr(ode, "__name__", "ode")

@@ -136,3 +136,31 @@ def test_results_are_bitwise_reproducible(hip_lib):
         dev.close()
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
     assert outs[0][2:] == outs[1][2:]
+
+
+def test_membrane_tag_without_facets(hip_lib):
+    """A membrane model whose tag marks no facet on this rank (e.g. an x-slab in front of the axons): zero ODE nodes,
+    every PDE<->ODE exchange and the ODE step must be no-ops and the time loop must still run."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "idealized_geometries"))
+    from idealized_common import SolverIdealized, physical_setup, solver_parameters, Constant
+    from knpemidg.models import mm_hh, mm_hh_no_stim
+    mesh, sub, surf = small_3d()
+    params, ion_list, stim = physical_setup()
+    S = SolverIdealized(params, ion_list)
+    S.verbose = False
+    S.setup_domain(mesh, sub, surf)
+    S.setup_parameters(); S.setup_FEM_spaces()
+    S.setup_membrane_model(stim, {1: mm_hh, 2: mm_hh_no_stim})          # tag 2 does not occur in this mesh
+    assert S.mem_models[1]['ode'].nodes == 0 and S.mem_models[1]['ode'].on_device
+    assert S.mem_models[1]['ode'].states.shape == (0, 4)
+    S._unpack_solver_params(solver_parameters(3, 0))
+    S.save_fields = S.save_solver_stats = False
+    S.splitting_scheme = True
+    S.setup_varform_emi(); S.setup_varform_knp(); S.setup_solver_emi(); S.setup_solver_knp()
+    t = Constant(0.0)
+    for k in range(2):
+        S.step_membrane_models(k)
+        S.solve_for_time_step(k, t)
+    assert np.isfinite(S.phi.array()).all() and np.isfinite(S.c.array()).all()
+    S.dev.close()
