@@ -264,3 +264,54 @@ def test_mms_time_convergence_on_device(hip_lib):
         r1 = np.log(errs[0][key] / errs[1][key]) / np.log(2)
         r2 = np.log(errs[1][key] / errs[2][key]) / np.log(2)
         assert 0.8 < r2 < 1.3 and 0.7 < r1 < 1.4, (key, r1, r2, errs)
+
+
+def test_baseline_config1_2d_neuron_one_step(hip_lib):
+    """BASELINE configs[0]: 2D idealized single neuron + ECS (make_mesh_2D r=2: 3 968 triangles, 35 712 DoFs), HH
+    membrane with stimulus, P1, ONE splitting step: HIP path vs the oracle's assembled-CSR direct solves."""
+    from common_examples import make_solver, solver_parameters, Constant
+    from knpemidg.mesh import make_mesh_2D
+    mt = make_mesh_2D(2)
+    assert mt[0].num_cells() == 3968
+    S = make_solver(dim=2, resolution=2, mesh_tuple=mt)
+    S._unpack_solver_params(solver_parameters(2, 2)._replace(rtol_emi=1e-10, rtol_knp=1e-12))
+    S.save_fields = S.save_solver_stats = False
+    S.splitting_scheme = True
+    S.setup_varform_emi(); S.setup_varform_knp(); S.setup_solver_emi(); S.setup_solver_knp()
+    pb = ko.build_idealized(mt[0], mt[1].array(), mt[2].array(), membrane_tags=(1,))
+    pb.phi_M[:] = 0.0
+    t = Constant(0.0)
+    S.step_membrane_models(0)
+    pb.phi_M = S.phi_M_prev_PDE.array().copy()
+    for ion in pb.ions:
+        pb.I_ch[ion["name"]] = S.mem_models[0]['I_ch_k'][ion["name"]].array().copy()
+    S.solve_for_time_step(0, t)
+    E = ko.solve_for_time_step(pb, direct=True)
+    vol = pb.geom.vol
+    assert relerr(mean_free(S.phi.array(), vol), mean_free(pb.phi, vol)) < 1e-6
+    assert relerr(S.c.array(), pb.c) < 1e-8
+    assert relerr(S.phi_M_prev_PDE.array()[pb.mem], pb.phi_M[pb.mem]) < 1e-6
+    for ion in S.ion_list:
+        assert relerr(ion['E'].array()[pb.mem], E[ion['name']]) < 1e-7
+    S.dev.close()
+
+
+def test_baseline_config2_3d_single_cell_r1_apply(hip_lib):
+    """BASELINE configs[1] at r=1: 3D idealized single cell (124 416 tets), P1, Na/K/Cl + potential, synthetic seeded
+    inputs: matrix-free applies vs the assembled reference operator."""
+    from knpemidg import _abi as A
+    from knpemidg.mesh import make_mesh_3D
+    m, s, f = make_mesh_3D(1, n_axons=1)
+    pb = ko.build_idealized(m, s.array(), f.array(), membrane_tags=(1,))
+    x = synthetic_state(pb)
+    dev = device_for(pb)
+    push_state(dev, pb)
+    dev.update_kappa(); dev.update_dnphi()
+    Aemi, _, _ = ko.assemble_emi(pb, want_B=False)
+    dev.upload(A.F_X, x[0]); dev.emi_apply(A.F_X, A.F_Y)
+    assert relerr(dev.download(A.F_Y, 0, pb.ndof), Aemi @ x[0].ravel()) < 1e-11
+    dev.upload(A.F_X, x); dev.knp_apply(A.F_X, A.F_Y)
+    y = dev.download(A.F_Y).reshape(pb.N_ions, -1)
+    for k in range(pb.N_ions):
+        assert relerr(y[k], ko.assemble_knp(pb, k) @ x[k].ravel()) < 1e-11
+    dev.close()
