@@ -237,3 +237,58 @@ def test_unstructured_geometry_uses_coordinate_kernels(hip_lib):
     ref = ko.solve_emi(pb, direct=True)
     assert relerr(mean_free(dev.download(A.F_PHI), pb.geom.vol), mean_free(ref, pb.geom.vol)) < 1e-6
     dev.close()
+
+
+def test_full_size_properties_r2(hip_lib):
+    """BASELINE configs[3] mesh (r=2: 995 328 tets, 11.9 M DoFs) is too large for the oracle, so the operators are
+    checked through size-independent properties: EMI annihilates constants and is symmetric, both operators are
+    linear, the KNP operator without drift conserves mass (1^T A_k 1 = |Omega| / dt), and one splitting step keeps
+    electroneutrality and the rest state."""
+    sys_path_examples()
+    from idealized_common import make_solver, solver_parameters, Constant
+    from knpemidg import _abi as A
+    S = make_solver(dim=3, resolution=2)
+    dev = S.dev
+    assert dev.nc == 995328 and dev.n_geometry_classes > 0
+    ndof = dev.nc * 4
+    rng = np.random.default_rng(3)
+    dev.update_kappa()
+    x = rng.uniform(-1, 1, size=(2, ndof))
+    pad = np.zeros(ndof)
+
+    def emi(v):
+        dev.upload(A.F_X, np.concatenate([v, pad])); dev.emi_apply(A.F_X, A.F_Y)
+        return dev.download(A.F_Y, 0, ndof)
+    y0, y1 = emi(x[0]), emi(x[1])
+    assert np.abs(emi(np.ones(ndof))).max() < 1e-9 * np.abs(y0).max()                     # constants in the null space
+    assert abs(x[1] @ y0 - x[0] @ y1) < 1e-10 * abs(x[1] @ y0)                             # symmetry
+    assert relerr(emi(2.0 * x[0] - 0.5 * x[1]), 2.0 * y0 - 0.5 * y1) < 1e-12              # linearity
+    dev.upload(A.F_PHI, np.zeros(ndof)); dev.update_dnphi()                                # no drift
+    dev.upload(A.F_X, np.ones(2 * ndof)); dev.knp_apply(A.F_X, A.F_Y)
+    yk = dev.download(A.F_Y).reshape(2, -1)
+    vol_total = 32e-6 * 0.9e-6 * 0.9e-6
+    for k in range(2):
+        assert abs(yk[k].sum() - vol_total / 1e-4) < 1e-9 * vol_total / 1e-4                # 1^T (M/dt + K_sipg) 1
+    # one unstimulated splitting step from the calibrated rest state (run_3D.py:80-86)
+    S.stimulus = {}
+    S._unpack_solver_params(solver_parameters(3, 2))
+    S.save_fields = S.save_solver_stats = False
+    S.splitting_scheme = True
+    S.setup_varform_emi(); S.setup_varform_knp(); S.setup_solver_emi(); S.setup_solver_knp()
+    c0 = S.c.array()
+    t = Constant(0.0)
+    S.step_membrane_models(0); S.solve_for_time_step(0, t)
+    c1, ce = S.c.array(), S.ion_list[-1]['c'].array()
+    assert relerr(c1, c0) < 1e-6                                                            # rest state stays at rest
+    assert np.abs(c1[0] - c1[1] + ce).max() < 1e-9 * np.abs(ce).max()                       # z = (+1, -1, +1): electroneutral
+    pm = S.phi_M_prev_PDE.array()
+    mem = np.nonzero(pm)[0]
+    assert len(mem) == 23552 and np.abs(pm[mem] + 0.07438609374462003).max() < 1e-5
+    dev.close()
+
+
+def sys_path_examples():
+    import os, sys
+    p = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "idealized_geometries")
+    if p not in sys.path:
+        sys.path.insert(0, p)
