@@ -153,7 +153,7 @@ class Level:
     pass
 
 
-def build_hierarchy(A, theta=0.08, max_coarse=1000, max_levels=12, cheb_degree=2, cheb_lower=0.3):
+def build_hierarchy(A, theta=0.08, max_coarse=1000, max_levels=12, cheb_degree=2, cheb_lower=0.3, psmooth=2):
     """Smoothed-aggregation hierarchy for an SPD (possibly singular, constants) matrix.
     Each level: A (csr), dinv, rho = spectral radius estimate of D^-1 A, P (csr, to the next level).
     Last level: dense pseudo-inverse."""
@@ -162,6 +162,7 @@ def build_hierarchy(A, theta=0.08, max_coarse=1000, max_levels=12, cheb_degree=2
     cheb_degree = int(os.environ.get("KNP_AMG_DEGREE", cheb_degree))
     cheb_lower = float(os.environ.get("KNP_AMG_LOWER", cheb_lower))
     max_coarse = int(os.environ.get("KNP_AMG_MAXCOARSE", max_coarse))
+    psmooth = int(os.environ.get("KNP_AMG_PSMOOTH", psmooth))
     levels = []
     A = A.tocsr().astype(np.float64)
     while True:
@@ -185,8 +186,13 @@ def build_hierarchy(A, theta=0.08, max_coarse=1000, max_levels=12, cheb_degree=2
             break
         cnt = np.bincount(agg, minlength=nagg).astype(np.float64)
         T = sp.csr_matrix((1.0 / np.sqrt(cnt[agg]), (np.arange(n), agg)), shape=(n, nagg))
+        # prolongator smoothing: `psmooth` damped-Jacobi steps on the tentative prolongator.  Two steps instead of the
+        # textbook one cut the V-cycle's convergence factor on the anisotropic conforming operator from ~0.63 to
+        # ~0.25 (CG on Ac: 39 -> 13 iterations at r=1) for 1.8x the operator complexity
         omega = (4.0 / 3.0) / lv.rho
-        P = (T - sp.diags(omega * lv.dinv) @ (A @ T)).tocsr()
+        P = T
+        for _ in range(psmooth):
+            P = (P - sp.diags(omega * lv.dinv) @ (A @ P)).tocsr()
         P.sort_indices()
         lv.P = P
         lv.R = P.T.tocsr()

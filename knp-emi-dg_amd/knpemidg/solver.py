@@ -285,7 +285,7 @@ class Solver:
         ft = gsurf.array()
         mem = np.nonzero((gmesh.facet_cells[:, 1] >= 0) & np.isin(ft, self.membrane_tags))[0]
         Ac = self._cspace.stiffness(kappa, membrane=(mem, _f(self.C_phi)))
-        levels = amg.build_hierarchy(Ac)
+        levels = amg.build_hierarchy(Ac, psmooth=2)          # EMI: 68 -> 22 PCG iterations at r=2 vs one smoothing step
         dev.amg_upload(0, self._local_dg2cg(), levels)
         self.amg_setup_timer = time.perf_counter() - ts
         if self.verbose:
@@ -326,7 +326,7 @@ class Solver:
         nc = gmesh.num_cells()
         for k, ion in enumerate(self.ion_list[:-1]):
             Ac = self._cspace.stiffness(self._by_tag(ion['D_sub'], gsub), mass_coef=np.full(nc, 1.0 / _f(self.dt)))
-            levels = amg.build_hierarchy(Ac)
+            levels = amg.build_hierarchy(Ac, psmooth=1)      # mass-dominated: the cheaper hierarchy already gives ~9 its
             self.dev.amg_upload(1 + k, self._local_dg2cg(), levels)
             if self.verbose:
                 print(" AMG(KNP %s) levels:" % ion['name'], [lv.A.shape[0] for lv in levels])
