@@ -28,19 +28,45 @@ int up_csr(knp_ctx* c, CsrDev& M, int64_t nrows, int64_t ncols, const int32_t* r
 
 void free_csr(CsrDev& M) { hipFree(M.rowptr); hipFree(M.col); hipFree(M.val); M = CsrDev(); }
 
+// partial dot product of CSR row `row` with x over this lane's entries (lane, lane+G, ...). The loop is unrolled so
+// that up to 4 (col, val, x[col]) chains are in flight per lane: these kernels are latency-bound (a row has 15..100
+// entries), not bandwidth-bound, and a rolled loop serialises one memory round trip per iteration.
+template <int G>
+__device__ __forceinline__ double row_dot(const CsrDev& A, int64_t row, int lane, const double* __restrict__ x) {
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    if (row < A.nrows) {
+        const int e = A.rowptr[row + 1];
+        int k = A.rowptr[row] + lane;
+        for (; k + 3 * G < e; k += 4 * G) {
+            const int c0 = A.col[k], c1 = A.col[k + G], c2 = A.col[k + 2 * G], c3 = A.col[k + 3 * G];
+            const double v0 = A.val[k], v1 = A.val[k + G], v2 = A.val[k + 2 * G], v3 = A.val[k + 3 * G];
+            s0 = fma(v0, x[c0], s0);
+            s1 = fma(v1, x[c1], s1);
+            s2 = fma(v2, x[c2], s2);
+            s3 = fma(v3, x[c3], s3);
+        }
+        if (k + G < e) {
+            const int c0 = A.col[k], c1 = A.col[k + G];
+            const double v0 = A.val[k], v1 = A.val[k + G];
+            s0 = fma(v0, x[c0], s0);
+            s1 = fma(v1, x[c1], s1);
+            k += 2 * G;
+        }
+        if (k < e) s2 = fma(A.val[k], x[A.col[k]], s2);
+    }
+    double s = (s0 + s1) + (s2 + s3);
+#pragma unroll
+    for (int off = G / 2; off > 0; off >>= 1) s += __shfl_down(s, off, G);
+    return s;
+}
+
 // y = A x (MODE 0) | y = b - A x (MODE 1) | y += A x (MODE 2); G lanes cooperate on one row
 template <int MODE, int G>
 __global__ __launch_bounds__(256) void k_csr(CsrDev A, const double* __restrict__ x, const double* __restrict__ b,
                                              double* __restrict__ y) {
     const int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) / G;
     const int lane = threadIdx.x % G;
-    double s = 0.0;
-    if (row < A.nrows) {
-        const int e = A.rowptr[row + 1];
-        for (int k = A.rowptr[row] + lane; k < e; k += G) s = fma(A.val[k], x[A.col[k]], s);
-    }
-#pragma unroll
-    for (int off = G / 2; off > 0; off >>= 1) s += __shfl_down(s, off, G);
+    const double s = row_dot<G>(A, row, lane, x);
     if (row < A.nrows && lane == 0) {
         if (MODE == 0) y[row] = s;
         else if (MODE == 1) y[row] = b[row] - s;
@@ -79,13 +105,7 @@ __global__ __launch_bounds__(256) void k_cheb_first_res(CsrDev A, const double* 
                                                         double* __restrict__ d, double* __restrict__ xout) {
     const int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) / G;
     const int lane = threadIdx.x % G;
-    double s = 0.0;
-    if (row < A.nrows) {
-        const int e = A.rowptr[row + 1];
-        for (int k = A.rowptr[row] + lane; k < e; k += G) s = fma(A.val[k], x[A.col[k]], s);
-    }
-#pragma unroll
-    for (int off = G / 2; off > 0; off >>= 1) s += __shfl_down(s, off, G);
+    const double s = row_dot<G>(A, row, lane, x);
     if (row < A.nrows && lane == 0) {
         const double rn = b[row] - s;
         const double v = dinv[row] * rn * inv_theta;
@@ -102,13 +122,7 @@ __global__ __launch_bounds__(256) void k_cheb_step(CsrDev A, const double* __res
                                                    double* __restrict__ x) {
     const int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) / G;
     const int lane = threadIdx.x % G;
-    double s = 0.0;
-    if (row < A.nrows) {
-        const int e = A.rowptr[row + 1];
-        for (int k = A.rowptr[row] + lane; k < e; k += G) s = fma(A.val[k], din[A.col[k]], s);
-    }
-#pragma unroll
-    for (int off = G / 2; off > 0; off >>= 1) s += __shfl_down(s, off, G);
+    const double s = row_dot<G>(A, row, lane, din);
     if (row < A.nrows && lane == 0) {
         const double rn = r[row] - s;
         const double dn = fma(c1, din[row], c2 * dinv[row] * rn);
@@ -129,16 +143,30 @@ void launch_cheb_step(knp_ctx* c, const CsrDev& A, const double* dinv, const dou
         hipLaunchKernelGGL((k_cheb_step<64>), dim3((unsigned)((A.nrows * 64 + 255) / 256)), dim3(256), 0, c->stream, A, dinv, din, c1, c2, r, dout, x);
 }
 
-// dense y = M b on the coarsest level (n <= ~512): one wavefront per row
-__global__ void k_dense_mv(int n, const double* __restrict__ M, const double* __restrict__ b, double* __restrict__ y) {
-    const int row = blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (row >= n) return;
-    double s = 0.0;
-    for (int k = lane; k < n; k += 64) s = fma(M[(int64_t)row * n + k], b[k], s);
+// dense y = M b on the coarsest level (n up to a few thousand): one workgroup per row, 4 independent loads in flight per
+// lane; M is the pseudo-inverse stored in fp32 (preconditioner data: half the bytes, still an exactly symmetric
+// operator because symmetric entries round identically), accumulation in fp64, fixed reduction tree.
+__global__ __launch_bounds__(256) void k_dense_mv(int n, const float* __restrict__ M, const double* __restrict__ b,
+                                                  double* __restrict__ y) {
+    __shared__ double part[4];
+    const int row = blockIdx.x;
+    const float* __restrict__ Mr = M + (int64_t)row * n;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int k = threadIdx.x;
+    for (; k + 768 < n; k += 1024) {
+        const float m0 = Mr[k], m1 = Mr[k + 256], m2 = Mr[k + 512], m3 = Mr[k + 768];
+        s0 = fma((double)m0, b[k], s0);
+        s1 = fma((double)m1, b[k + 256], s1);
+        s2 = fma((double)m2, b[k + 512], s2);
+        s3 = fma((double)m3, b[k + 768], s3);
+    }
+    for (; k < n; k += 256) s0 = fma((double)Mr[k], b[k], s0);
+    double s = (s0 + s1) + (s2 + s3);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-    if (lane == 0) y[row] = s;
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) y[row] = (part[0] + part[1]) + (part[2] + part[3]);
 }
 
 // rc[v] = sum over the DG dofs mapped to conforming dof v (CSR list, fixed order -> deterministic)
@@ -199,7 +227,7 @@ static int amg_vcycle_eager(knp_ctx* c, AmgHierarchy& H) {
         launch_csr<0>(c, L.R, L.r, nullptr, H.levels[l + 1].b);      // b_{l+1} = R r
     }
     AmgLevel& C = H.levels[nl - 1];
-    hipLaunchKernelGGL(k_dense_mv, dim3((unsigned)((C.n + 3) / 4)), dim3(256), 0, c->stream, (int)C.n, H.pinv, C.b, C.x);
+    hipLaunchKernelGGL(k_dense_mv, dim3((unsigned)C.n), dim3(256), 0, c->stream, (int)C.n, (const float*)H.pinv, C.b, C.x);
     for (int l = nl - 2; l >= 0; --l) {
         AmgLevel& L = H.levels[l];
         launch_csr<2>(c, L.P, H.levels[l + 1].x, nullptr, L.x);      // x += P x_{l+1}
@@ -317,7 +345,9 @@ int knp_amg_finish(knp_ctx* c, int which, int64_t n, const double* pinv) {
     if (!H || H->levels.empty() || H->levels.back().n != n || H->levels.back().ncoarse != 0) {
         c->err = "amg: finish does not match the last level"; return -1;
     }
-    int rc = up(c, &H->pinv, pinv, (size_t)n * n);
+    std::vector<float> p32((size_t)n * n);
+    for (size_t i = 0; i < p32.size(); ++i) p32[i] = (float)pinv[i];
+    int rc = up(c, &H->pinv, p32.data(), p32.size());
     H->ready = (rc == 0);
     return rc;
 }

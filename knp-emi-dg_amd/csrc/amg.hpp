@@ -26,7 +26,7 @@ struct AmgHierarchy {
     int32_t* dg2cg = nullptr;       // [nc*nd] conforming dof of every DG dof
     int32_t *cg_ptr = nullptr, *cg_idx = nullptr;   // CSR list: conforming dof -> DG dofs (owned cells only)
     std::vector<AmgLevel> levels;
-    double* pinv = nullptr;         // dense pseudo-inverse of the coarsest level
+    float* pinv = nullptr;          // dense pseudo-inverse of the coarsest level (fp32 storage)
     void* graph_exec = nullptr;     // hipGraphExec_t of one V-cycle (fixed kernel sequence on fixed buffers)
     bool graph_tried = false;
 };

