@@ -81,6 +81,28 @@ int knp_set_geometry_classes(knp_ctx* ctx, int ncls, const uint16_t* cls, const 
  * host and added to L_emi / L_knp; the solution-dependent term -jump(phi) jump(C v) is evaluated on the device. */
 int knp_set_mms(knp_ctx* ctx, const double* C, const double* extra_emi, const double* extra_knp);
 
+/* DG-p path (degree 2): reference-basis tabulation of one integral class.  The quadratic forms are integrated by
+ * numerical quadrature once per time step into dense cell blocks (the device analogue of assemble(), solver.py:477-479,
+ * 730-731); the rules and the basis tabulated at their points come from the host (knpemidg/dgtab.py).
+ *  w[nq] weights summing to 1;  B[nloc][nq][nd] basis values;  dB[nloc][nq][nd][dim+1] derivatives with respect to
+ *  the barycentric coordinates;  nloc = 1 for cell rules, dim+1 for facet rules (one tabulation per local facet, all
+ *  with the same facet points: facet vertex m <-> cell vertex m + (m >= local facet index)).
+ * Local dof order of a P2 cell: the dim+1 vertices, then the edge midpoints (a,b), a<b, lexicographic. */
+enum knp_tab_slot {
+    KNP_TAB_CELL_STIFF = 0,     /* dx of a_emi / a_knp                  degree max(2, 3p-2, 2p)  solver.py:318, 550-556 */
+    KNP_TAB_CELL_RHS_EMI = 1,   /* dx of L_emi                          degree max(1, 2p-2)      solver.py:309-310 */
+    KNP_TAB_CELL_MASS = 2,      /* dx of L_knp                          degree 2p                solver.py:597-599 */
+    KNP_TAB_FACET_EMI = 3,      /* dS(0) of a_emi                       degree 3p                solver.py:321-328 */
+    KNP_TAB_FACET_MEM = 4,      /* dS(membrane) of a_emi                degree 2p                solver.py:344 */
+    KNP_TAB_FACET_KNP = 5,      /* dS(0) of a_knp                       degree max(2, 3p-1)      solver.py:586-594 */
+    KNP_TAB_FACET_RHS_EMI = 6,  /* dS(0) of L_emi                       degree max(1, 2p-1)      solver.py:330 */
+    KNP_TAB_FACET_MEM_LIN = 7,  /* dS(membrane) of L_emi                degree max(1, 2p-1)      solver.py:332-344 */
+    KNP_TAB_FACET_MEM_KNP = 8,  /* dS(membrane) of L_knp                degree 5p                solver.py:603-629 */
+    KNP_TAB_FACET_AVG = 9,      /* facet averages (phi_M, traces)       degree max(1, p)         utils.py:100-124 */
+    KNP_TAB_FACET_NERNST = 10   /* ln(c_e/c_i)                          degree 2p+2              solver.py:827-828 */
+};
+int knp_set_tabulation(knp_ctx* ctx, int slot, int nloc, int nq, const double* w, const double* B, const double* dB);
+
 int64_t knp_field_size(knp_ctx* ctx, int field);
 int knp_upload(knp_ctx* ctx, int field, const double* src, int64_t offset, int64_t count);
 int knp_download(knp_ctx* ctx, int field, double* dst, int64_t offset, int64_t count);

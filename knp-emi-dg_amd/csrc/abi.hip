@@ -60,7 +60,7 @@ int knp_ctx_create(knp_ctx** out, int device, int dim, int degree, int n_ions, i
     if (!out) return -1;
     *out = nullptr;
     if (dim != 2 && dim != 3) { g_err = "dim must be 2 or 3"; return -1; }
-    if (degree != 1) { g_err = "only degree 1 is implemented on the device path"; return -1; }
+    if (degree != 1 && degree != 2) { g_err = "degree must be 1 or 2"; return -1; }
     if (n_ions < 2 || n_ions > KNP_MAX_IONS) { g_err = "n_ions out of range"; return -1; }
     if (nc_owned < 0 || nc_owned > nc) { g_err = "nc_owned out of range"; return -1; }
     int ndev = 0;
@@ -70,7 +70,8 @@ int knp_ctx_create(knp_ctx** out, int device, int dim, int degree, int n_ions, i
     c->device = device;
     c->degree = degree;
     const int NV = dim + 1;
-    c->nd = NV;
+    const int ND = degree == 1 ? NV : NV * (NV + 1) / 2;      // P2: vertices, then edges (a,b), a<b, lexicographic
+    c->nd = ND;
     c->p.n_ions = n_ions;
     c->p.n_sys = n_ions - 1;
     c->amg.resize(1 + (size_t)(n_ions - 1));
@@ -163,15 +164,15 @@ int knp_ctx_create(knp_ctx** out, int device, int dim, int degree, int n_ions, i
     if (rc) { g_err = c->err; delete c; return -2; }
 
     Fields* fl = new Fields();
-    const int64_t ndof = nc * NV, ns = c->p.n_sys;
+    const int64_t ndof = nc * ND, ns = c->p.n_sys;
     const int64_t sizes[KNP_F_COUNT] = {ndof, ns * ndof, ns * ndof, ndof, nf, n_ions * nf, n_ions * nf, ndof, ndof,
                                         ndof, ns * ndof, ns * ndof, ns * ndof, nf};
     for (int i = 0; i < KNP_F_COUNT; ++i) {
         fl->n[i] = sizes[i];
         rc |= dev_zeros(c, &fl->f[i], sizes[i]);
     }
-    rc |= dev_zeros(c, &fl->binv_emi, ndof * NV);
-    rc |= dev_zeros(c, &fl->binv_knp, ns * ndof * NV);
+    rc |= dev_zeros(c, &fl->binv_emi, ndof * ND);
+    rc |= dev_zeros(c, &fl->binv_knp, ns * ndof * ND);
     double** wk[] = {&fl->r, &fl->z, &fl->p, &fl->w, &fl->rhat, &fl->v, &fl->y};
     for (auto pp : wk) rc |= dev_zeros(c, pp, ns * ndof);
     rc |= dev_zeros(c, &c->D, (size_t)n_ions * nc);
@@ -197,6 +198,7 @@ void knp_ctx_destroy(knp_ctx* c) {
     for (auto ev : c->aux_events) hipEventDestroy(ev);
     if (c->fork_event) hipEventDestroy(c->fork_event);
     ode_destroy_all(c);
+    tab_free(c);
     Fields* fl = g_fields[c];
     if (fl) {
         for (int i = 0; i < KNP_F_COUNT; ++i) hipFree(fl->f[i]);

@@ -864,7 +864,7 @@ int64_t grid_for(int64_t n) { return (n + KNP_BLOCK - 1) / KNP_BLOCK; }
 static inline int64_t grid8(int64_t n) { return ((grid_for(n) + 7) / 8) * 8; }
 
 int launch_emi_apply(knp_ctx* c, const double* x, const double* kappa, double* y) {
-    if (c->degree != 1) { c->err = "P1 kernels only"; return -1; }
+    if (c->degree != 1) return tab_apply(c, 0, x, y);
     static const int variant = getenv("KNP_EMI_VARIANT") ? atoi(getenv("KNP_EMI_VARIANT")) : 1;
     if (c->m.cls && c->m.dim == 3 && variant != 4) {
         if (c->m.ncls <= CLS_MAX_LDS && variant != 5) {
@@ -945,11 +945,12 @@ template <int D> static int knp_apply_dispatch(knp_ctx* c, const double* x, cons
 }
 
 int launch_knp_apply(knp_ctx* c, const double* x, const double* gphi, double* y) {
-    if (c->degree != 1) { c->err = "P1 kernels only"; return -1; }
+    if (c->degree != 1) return tab_apply(c, 1, x, y);
     return c->m.dim == 3 ? knp_apply_dispatch<3>(c, x, gphi, y) : knp_apply_dispatch<2>(c, x, gphi, y);
 }
 
 int launch_emi_blockjacobi(knp_ctx* c, const double* kappa, double* binv) {
+    if (c->degree != 1) return tab_block_inverse(c, 0, binv);
     const dim3 g((unsigned)grid_for(c->m.nc_owned)), b(KNP_BLOCK);
     const double shift = 0.0;
     if (c->m.dim == 3)
@@ -961,6 +962,7 @@ int launch_emi_blockjacobi(knp_ctx* c, const double* kappa, double* binv) {
 }
 
 int launch_knp_blockjacobi(knp_ctx* c, const double* gphi, double* binv) {
+    if (c->degree != 1) return tab_block_inverse(c, 1, binv);
     const dim3 g((unsigned)grid_for(c->m.nc_owned), (unsigned)c->p.n_sys), b(KNP_BLOCK);
     const KnpArgs ka = make_knp_args(c);
     if (c->m.dim == 3)
@@ -972,6 +974,7 @@ int launch_knp_blockjacobi(knp_ctx* c, const double* gphi, double* binv) {
 }
 
 int launch_dnphi(knp_ctx* c, const double* phi, double* gphi) {
+    if (c->degree != 1) return tab_assemble_knp(c, phi);     // P2: the drift enters the assembled blocks
     const dim3 g((unsigned)grid_for(c->m.nc)), b(KNP_BLOCK);
     if (c->m.dim == 3)
         hipLaunchKernelGGL(k_gphi<3>, g, b, 0, c->stream, c->m, phi, gphi);

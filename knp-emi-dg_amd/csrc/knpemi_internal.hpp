@@ -44,6 +44,15 @@ struct Params {
     int splitting = 1;
 };
 
+// one quadrature rule with the reference basis tabulated at its points (DG-p path, tab_dg.hip); device pointers
+struct TabRule {
+    int nq = 0;
+    const double* w = nullptr;     // [nq], sums to 1
+    const double* B = nullptr;     // [nloc][nq][nd]        nloc = 1 (cell rule) or dim+1 (one per local facet)
+    const double* dB = nullptr;    // [nloc][nq][nd][dim+1] derivatives with respect to the barycentric coordinates
+};
+#define KNP_TAB_COUNT 11
+
 struct KernelArgsIons {            // small by-value structs for kernels
     int n;
     double z[KNP_MAX_IONS];
@@ -63,6 +72,11 @@ struct knp_ctx {
     double* mms_C = nullptr;       // [n_sys][nc]
     double* extra_emi = nullptr;   // [nc*nd]
     double* extra_knp = nullptr;   // [n_sys][nc*nd]
+    // DG-p (p >= 2) path: tabulated rules + assembled cell blocks [nc][dim+2][nd][nd] (tab_dg.hip)
+    TabRule tab[KNP_TAB_COUNT];
+    double* tab_mem[KNP_TAB_COUNT] = {nullptr};
+    double* blk_emi = nullptr;
+    double* blk_knp = nullptr;     // [n_sys] x the same
     std::map<int, double*> vecs;   // handle -> device pointer
     std::map<int, int64_t> vlen;
     int next_handle = 1;
@@ -112,6 +126,18 @@ int launch_knp_rhs(knp_ctx* c, const double* cc, const double* cprev, const doub
 int launch_step_updates(knp_ctx* c, const double* cc, double* celim, const double* phi,
                         double* phiM, double* E);
 int launch_facet_trace(knp_ctx* c, const double* nodal, int side, double* out);
+
+// DG-p path (tab_dg.hip)
+int tab_kappa(knp_ctx* c, const double* cc, const double* celim, double* kappa);
+int tab_assemble_knp(knp_ctx* c, const double* phi);
+int tab_apply(knp_ctx* c, int which, const double* x, double* y);
+int tab_block_inverse(knp_ctx* c, int which, double* binv);
+int tab_emi_rhs(knp_ctx* c, const double* cc, const double* celim, const double* phiM, const double* Ich, double* b);
+int tab_knp_rhs(knp_ctx* c, const double* cc, const double* cprev, const double* celim, const double* phi, const double* phiM,
+                const double* Ich, double* b);
+int tab_step_updates(knp_ctx* c, const double* cc, double* celim, const double* phi, double* phiM, double* E, bool do_celim);
+int tab_facet_trace(knp_ctx* c, const double* nodal, int side, double* out);
+void tab_free(knp_ctx* c);
 
 int halo_exchange(knp_ctx* c, double* v, int nfields);
 

@@ -46,8 +46,46 @@ template <int NR> __device__ __forceinline__ void write_partials(double* partial
     }
 }
 
-template <int NV> __device__ __forceinline__ void ldv(const double* p, int64_t c, double* v) { load_nodal<NV - 1>(p, c, v); }
-template <int NV> __device__ __forceinline__ void stv(double* p, int64_t c, const double* v) { store_nodal<NV - 1>(p, c, v); }
+// NV = dofs per cell: 3 / 4 (P1 triangles / tets), 6 / 10 (P2)
+template <int NV> __device__ __forceinline__ void ldv(const double* p, int64_t c, double* v) {
+    if constexpr (NV <= 4) {
+        load_nodal<NV - 1>(p, c, v);
+    } else {
+        static_assert(NV % 2 == 0, "P2 cell vectors are read as double2");
+        const double2* q = reinterpret_cast<const double2*>(p + (int64_t)NV * c);
+#pragma unroll
+        for (int k = 0; k < NV / 2; ++k) { const double2 t = q[k]; v[2 * k] = t.x; v[2 * k + 1] = t.y; }
+    }
+}
+template <int NV> __device__ __forceinline__ void stv(double* p, int64_t c, const double* v) {
+    if constexpr (NV <= 4) {
+        store_nodal<NV - 1>(p, c, v);
+    } else {
+        double2* q = reinterpret_cast<double2*>(p + (int64_t)NV * c);
+#pragma unroll
+        for (int k = 0; k < NV / 2; ++k) q[k] = make_double2(v[2 * k], v[2 * k + 1]);
+    }
+}
+
+// value of the conforming-P1 correction e at DG dof a of cell c.  dg2cg holds the conforming dof of every cell VERTEX
+// ([nc][dim+1]); P1: injection.  P2 (NV = 6 / 10): vertex dofs first, then the edge midpoints (a0,a1), a0 < a1 in
+// lexicographic order, where a P1 function takes the mean of the two vertex values.
+template <int NV> __device__ __forceinline__ void prolong_cell(const int32_t* __restrict__ dg2cg, const double* __restrict__ e,
+                                                                int64_t c, double* add) {
+    constexpr int NVT = (NV == 3 || NV == 6) ? 3 : 4;
+    double ev[NVT];
+#pragma unroll
+    for (int a = 0; a < NVT; ++a) ev[a] = e[dg2cg[c * NVT + a]];
+#pragma unroll
+    for (int a = 0; a < NVT; ++a) add[a] = ev[a];
+    if constexpr (NV > NVT) {
+        int k = NVT;
+#pragma unroll
+        for (int a0 = 0; a0 < NVT; ++a0)
+#pragma unroll
+            for (int a1 = a0 + 1; a1 < NVT; ++a1) add[k++] = 0.5 * (ev[a0] + ev[a1]);
+    }
+}
 
 template <int NV> __device__ __forceinline__ void block_matvec(const double* __restrict__ binv, int64_t c, const double* r, double* z) {
     const double* B = binv + c * NV * NV;
@@ -258,9 +296,11 @@ __global__ __launch_bounds__(KNP_BLOCK) void k_prolong_dot(VecDims d, const int*
         double rv[NV], zv[NV];
         ldv<NV>(r, c, rv);
         ldv<NV>(z, c, zv);
+        double ad[NV];
+        prolong_cell<NV>(dg2cg, e, c, ad);
 #pragma unroll
         for (int a = 0; a < NV; ++a) {
-            zv[a] += e[dg2cg[c * NV + a]];
+            zv[a] += ad[a];
             acc[0] += rv[a] * zv[a];
             acc[1] += zv[a] * zv[a];
         }
@@ -268,9 +308,10 @@ __global__ __launch_bounds__(KNP_BLOCK) void k_prolong_dot(VecDims d, const int*
         if (NR == 3) {
             double bv[NV];
             ldv<NV>(z2, c, bv);
+            prolong_cell<NV>(dg2cg, e2, c, ad);
 #pragma unroll
             for (int a = 0; a < NV; ++a) {
-                bv[a] += e2[dg2cg[c * NV + a]];
+                bv[a] += ad[a];
                 acc[NR - 1] += bv[a] * bv[a];
             }
         }
@@ -288,8 +329,10 @@ __global__ __launch_bounds__(KNP_BLOCK) void k_prolong_add(VecDims d, const int*
     if (c >= d.nc_owned) return;
     double yv[NV];
     ldv<NV>(y, c, yv);
+    double ad[NV];
+    prolong_cell<NV>(dg2cg, e, c, ad);
 #pragma unroll
-    for (int a = 0; a < NV; ++a) yv[a] += e[dg2cg[c * NV + a]];
+    for (int a = 0; a < NV; ++a) yv[a] += ad[a];
     stv<NV>(y, c, yv);
 }
 
@@ -536,8 +579,14 @@ static int pcg_impl(knp_ctx* c, KrylovVecs& kv, double rtol, double atol, int ma
 
 int pcg_solve(knp_ctx* c, KrylovVecs& kv, double rtol, double atol, int maxit, int check_every, int* niter, double* res) {
     if (check_every < 1) check_every = 1;
-    return c->m.dim == 3 ? pcg_impl<4>(c, kv, rtol, atol, maxit, check_every, niter, res)
-                         : pcg_impl<3>(c, kv, rtol, atol, maxit, check_every, niter, res);
+    switch (c->nd) {
+        case 3: return pcg_impl<3>(c, kv, rtol, atol, maxit, check_every, niter, res);
+        case 4: return pcg_impl<4>(c, kv, rtol, atol, maxit, check_every, niter, res);
+        case 6: return pcg_impl<6>(c, kv, rtol, atol, maxit, check_every, niter, res);
+        case 10: return pcg_impl<10>(c, kv, rtol, atol, maxit, check_every, niter, res);
+    }
+    c->err = "pcg: unsupported dofs per cell";
+    return -1;
 }
 
 // out_s += P_s V_s(P_s^T in_s) for every species s with an armed hierarchy (slot 1 + s).  The species' V-cycles are
@@ -643,6 +692,12 @@ static int bicgstab_impl(knp_ctx* c, KrylovVecs& kv, double rtol, double atol, i
 int bicgstab_solve(knp_ctx* c, KrylovVecs& kv, double rtol, double atol, int maxit, int min_it, int check_every, int* niter,
                    double* res) {
     if (check_every < 1) check_every = 1;
-    return c->m.dim == 3 ? bicgstab_impl<4>(c, kv, rtol, atol, maxit, min_it, check_every, niter, res)
-                         : bicgstab_impl<3>(c, kv, rtol, atol, maxit, min_it, check_every, niter, res);
+    switch (c->nd) {
+        case 3: return bicgstab_impl<3>(c, kv, rtol, atol, maxit, min_it, check_every, niter, res);
+        case 4: return bicgstab_impl<4>(c, kv, rtol, atol, maxit, min_it, check_every, niter, res);
+        case 6: return bicgstab_impl<6>(c, kv, rtol, atol, maxit, min_it, check_every, niter, res);
+        case 10: return bicgstab_impl<10>(c, kv, rtol, atol, maxit, min_it, check_every, niter, res);
+    }
+    c->err = "bicgstab: unsupported dofs per cell";
+    return -1;
 }

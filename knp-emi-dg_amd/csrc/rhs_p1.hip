@@ -420,11 +420,13 @@ static IonArgs ion_args(knp_ctx* c) {
     } while (0)
 
 int launch_kappa(knp_ctx* c, const double* cc, const double* celim, double* kappa) {
+    if (c->degree != 1) return tab_kappa(c, cc, celim, kappa);
     DISPATCH_DIM(c, k_kappa, dim3((unsigned)grid_for(c->m.nc)), c->m, cc, celim, c->D, kappa, ion_args(c), c->p.F, c->p.psi);
     return 0;
 }
 
 int launch_emi_rhs(knp_ctx* c, const double* cc, const double* celim, const double* phiM, const double* Ich, double* b) {
+    if (c->degree != 1) return tab_emi_rhs(c, cc, celim, phiM, Ich, b);
     DISPATCH_DIM(c, k_emi_rhs, dim3((unsigned)grid_for(c->m.nc_owned)), c->m, cc, celim, c->D, phiM, Ich, b,
                  ion_args(c), c->p.F, c->p.C_phi, c->p.splitting, (const double*)c->extra_emi);
     return 0;
@@ -432,6 +434,7 @@ int launch_emi_rhs(knp_ctx* c, const double* cc, const double* celim, const doub
 
 int launch_knp_rhs(knp_ctx* c, const double* cc, const double* cprev, const double* celim, const double* phi,
                    const double* phiM, const double* Ich, double* b) {
+    if (c->degree != 1) return tab_knp_rhs(c, cc, cprev, celim, phi, phiM, Ich, b);
     KnpRhsArgs ra{c->p.F, c->p.C_M, c->p.dt, c->p.splitting, (const double*)c->mms_C, (const double*)c->extra_knp};
     DISPATCH_DIM(c, k_knp_rhs, dim3((unsigned)grid_for(c->m.nc_owned), (unsigned)c->p.n_sys), c->m, cc, cprev, celim, phi,
                  c->D, phiM, Ich, (const double*)c->fsrc, b, ion_args(c), ra);
@@ -439,6 +442,7 @@ int launch_knp_rhs(knp_ctx* c, const double* cc, const double* cprev, const doub
 }
 
 int launch_step_updates(knp_ctx* c, const double* cc, double* celim, const double* phi, double* phiM, double* E) {
+    if (c->degree != 1) return tab_step_updates(c, cc, celim, phi, phiM, E, true);
     DISPATCH_DIM(c, k_celim, dim3((unsigned)grid_for(c->m.nc)), c->m, cc, c->rho, celim, ion_args(c));
     if (c->m.nmf > 0)
         DISPATCH_DIM(c, k_facet_updates, dim3((unsigned)grid_for(c->m.nmf)), c->m, cc, (const double*)celim, phi, phiM, E,
@@ -447,12 +451,14 @@ int launch_step_updates(knp_ctx* c, const double* cc, double* celim, const doubl
 }
 
 int launch_facet_trace(knp_ctx* c, const double* nodal, int side, double* out) {
+    if (c->degree != 1) return tab_facet_trace(c, nodal, side, out);
     if (c->m.nmf > 0)
         DISPATCH_DIM(c, k_facet_trace, dim3((unsigned)grid_for(c->m.nmf)), c->m, nodal, side, out);
     return 0;
 }
 
 int launch_nernst_only(knp_ctx* c, const double* cc, const double* celim, double* E) {
+    if (c->degree != 1) return tab_step_updates(c, cc, const_cast<double*>(celim), nullptr, nullptr, E, false);
     if (c->m.nmf > 0)
         DISPATCH_DIM(c, k_facet_updates, dim3((unsigned)grid_for(c->m.nmf)), c->m, cc, celim, (const double*)nullptr,
                      (double*)nullptr, E, ion_args(c), c->p.R * c->p.T / c->p.F);

@@ -30,6 +30,7 @@ SIGNATURES = {
     "knp_last_error": (C.c_char_p, [_ctxp]),
     "knp_set_params": (C.c_int, [_ctxp] + [C.c_double] * 8 + [_f64p, _f64p, _f64p, _f64p, C.c_int]),
     "knp_set_geometry_classes": (C.c_int, [_ctxp, C.c_int, C.POINTER(C.c_uint16), _f64p]),
+    "knp_set_tabulation": (C.c_int, [_ctxp, C.c_int, C.c_int, C.c_int, _f64p, _f64p, _f64p]),
     "knp_set_mms": (C.c_int, [_ctxp, _f64p, _f64p, _f64p]),
     "knp_field_size": (C.c_int64, [_ctxp, C.c_int]),
     "knp_upload": (C.c_int, [_ctxp, C.c_int, _f64p, C.c_int64, C.c_int64]),
@@ -229,7 +230,14 @@ class Device:
             self.ctx = None
             raise KnpError("knp_ctx_create failed (%d): %s" % (rc, msg.decode() if msg else "?"))
         self.n_geometry_classes = 0
-        if os.environ.get("KNP_NO_CLASSES", "0") != "1":
+        self.degree = int(degree)
+        if degree != 1:
+            # DG-p path: the device integrates the forms with host-tabulated rules (csrc/tab_dg.hip)
+            from knpemidg import dgtab
+            for slot, (nloc, nq, w, B, dB) in dgtab.tables(self.dim, degree).items():
+                self._chk(self.lib.knp_set_tabulation(self.ctx, slot, nloc, nq, _p(w, _f64p), _p(B, _f64p), _p(dB, _f64p)),
+                          "knp_set_tabulation")
+        if degree == 1 and os.environ.get("KNP_NO_CLASSES", "0") != "1":
             gc = geometry_classes(mesh, order)
             if gc is not None:
                 cls, table = gc
@@ -411,14 +419,28 @@ class Device:
 
     # -- auxiliary-space AMG (knpemidg/amg.py builds, csrc/amg.hip applies) ------------------
     def amg_upload(self, which, dg2cg, levels):
-        """dg2cg [nc, nd] in the caller's cell order; levels from amg.build_hierarchy."""
-        nd = self.nd
-        d2c = np.ascontiguousarray(np.asarray(dg2cg)[self.cell_order].ravel(), dtype=np.int32)
+        """dg2cg [nc, dim+1]: conforming dof of every cell vertex, caller's cell order; levels from amg.build_hierarchy."""
+        nd, nv = self.nd, self.dim + 1
+        vmap = np.asarray(dg2cg)[self.cell_order].reshape(self.nc, nv)
+        d2c = np.ascontiguousarray(vmap.ravel(), dtype=np.int32)
         ncg = levels[0].A.shape[0]
-        own = d2c[:self.nc_owned * nd]
-        idx = np.argsort(own, kind="stable").astype(np.int32)
+        # restriction lists: for every conforming dof the DG dofs it receives from (owned cells).  P1: the vertex dofs.
+        # P2: also the edge-midpoint dofs of the edges ending in that vertex (weight 1/2, applied by the kernel).
+        vo = vmap[:self.nc_owned]
+        cell = np.arange(self.nc_owned, dtype=np.int64)[:, None]
+        tgt = [vo.ravel()]
+        src = [(cell * nd + np.arange(nv)[None, :]).ravel()]
+        if nd > nv:
+            for e, (a, b) in enumerate([(a, b) for a in range(nv) for b in range(a + 1, nv)]):
+                for end in (a, b):
+                    tgt.append(vo[:, end])
+                    src.append(cell[:, 0] * nd + nv + e)
+        tgt = np.concatenate(tgt)
+        src = np.concatenate(src)
+        order = np.lexsort((src, tgt))
+        idx = np.ascontiguousarray(src[order], dtype=np.int32)
         ptr = np.zeros(ncg + 1, dtype=np.int32)
-        np.cumsum(np.bincount(own, minlength=ncg), out=ptr[1:])
+        np.cumsum(np.bincount(tgt, minlength=ncg), out=ptr[1:])
         self._chk(self.lib.knp_amg_begin(self.ctx, which, ncg, _p(d2c, _i32p), _p(ptr, _i32p), _p(idx, _i32p)), "knp_amg_begin")
 
         def csr(M):

@@ -271,7 +271,7 @@ class Solver:
         gmesh, gsub, gsurf = self._amg_global()
         if gmesh is self.mesh:
             dev.update_kappa()
-            kappa = dev.download(_abi.F_KAPPA).reshape(self.mesh.num_cells(), self.nd)
+            kappa = dev.download(_abi.F_KAPPA).reshape(self.mesh.num_cells(), self.nd)[:, :self.gdim + 1]   # vertex values (P2: coefficient of the P1 auxiliary space)
         else:
             # distributed: every rank builds the SAME global hierarchy from the tag-wise initial state (no
             # communication; the preconditioner is lagged anyway)

@@ -20,10 +20,16 @@ def _problems():
     out["3D_4axon_r0"] = ko.build_idealized(m, s.array(), f.array())
     m, s, f = make_mesh_3D(0, n_axons=1)
     out["3D_1axon_r0"] = ko.build_idealized(m, s.array(), f.array())
+    # DG-P2 (BASELINE configs[2] degree): assembled cell-block path (csrc/tab_dg.hip)
+    m, s, f = make_mesh_2D(1)
+    out["2D_neuron_r1_P2"] = ko.build_idealized(m, s.array(), f.array(), p=2, membrane_tags=(1,))
+    from common import small_3d
+    m, s, f = small_3d((8, 4, 4))
+    out["3D_box_P2"] = ko.build_idealized(m, s.array(), f.array(), p=2, membrane_tags=(1,))
     return out
 
 
-@pytest.fixture(scope="module", params=["2D_neuron_r0", "3D_1axon_r0", "3D_4axon_r0"])
+@pytest.fixture(scope="module", params=["2D_neuron_r0", "3D_1axon_r0", "3D_4axon_r0", "2D_neuron_r1_P2", "3D_box_P2"])
 def case(request, hip_lib):
     from knpemidg import _abi as A
     pb = _problems()[request.param]
@@ -102,10 +108,10 @@ def test_step_updates(case):
     assert relerr(dev.download(A.F_C_PREV), pb.c) < 1e-16
     # traces used by the update_ode hook (run_3D.py:44-49)
     K_e = dev.facet_trace(A.F_C, 0, 0)
-    ref = ko.facet_average(pb, pb.mem, lambda plus, minus: plus(pb.c[0]), 1)
+    ref = ko.facet_average(pb, pb.mem, lambda plus, minus: plus(pb.c[0]), pb.p)
     assert relerr(K_e[pb.mem], ref) < 1e-14
     Na_i = dev.facet_trace(A.F_C_ELIM, 0, 1)
-    ref = ko.facet_average(pb, pb.mem, lambda plus, minus: minus(pb.c_elim), 1)
+    ref = ko.facet_average(pb, pb.mem, lambda plus, minus: minus(pb.c_elim), pb.p)
     assert relerr(Na_i[pb.mem], ref) < 1e-14
 
 

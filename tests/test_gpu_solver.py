@@ -21,10 +21,14 @@ def _small_problems():
     out["2D"] = ko.build_idealized(m, s.array(), f.array(), membrane_tags=(1,))
     m, s, f = small_3d()
     out["3D"] = ko.build_idealized(m, s.array(), f.array(), membrane_tags=(1,))
+    m, s, f = make_mesh_2D(0)
+    out["2D_P2"] = ko.build_idealized(m, s.array(), f.array(), p=2, membrane_tags=(1,))
+    m, s, f = small_3d((6, 3, 3))
+    out["3D_P2"] = ko.build_idealized(m, s.array(), f.array(), p=2, membrane_tags=(1,))
     return out
 
 
-@pytest.fixture(scope="module", params=["2D", "3D"])
+@pytest.fixture(scope="module", params=["2D", "3D", "2D_P2", "3D_P2"])
 def case(request, hip_lib):
     from knpemidg import _abi as A
     pb = _small_problems()[request.param]
@@ -64,21 +68,22 @@ def test_knp_solve(case):
     assert all(n >= 5 for n in niter)          # ksp_min_it 5 (solver.py:686)
 
 
-@pytest.mark.parametrize("dim", [2, 3])
-def test_active_time_loop(hip_lib, dim):
+@pytest.mark.parametrize("dim,degree", [(2, 1), (3, 1), (2, 2), (3, 2)])
+def test_active_time_loop(hip_lib, dim, degree):
     """Three splitting steps with HH membranes + stimulus: GPU Solver vs oracle stepping fed with the
-    same ODE outputs (the ODE step is adjacent to the hot path)."""
+    same ODE outputs (the ODE step is adjacent to the hot path).  degree 2 is the
+    `Solver(degree_emi=2, degree_knp=2)` path of BASELINE configs[2]."""
     from common_examples import make_solver, solver_parameters, Constant
     from knpemidg.mesh import make_mesh_2D
-    mt = make_mesh_2D(0) if dim == 2 else small_3d()
-    S = make_solver(dim=dim, resolution=0, n_axons=1, mesh_tuple=mt)
+    mt = make_mesh_2D(0) if dim == 2 else small_3d((8, 4, 4) if degree == 1 else (6, 3, 3))
+    S = make_solver(dim=dim, resolution=0, n_axons=1, mesh_tuple=mt, degree=degree)
     sp = solver_parameters(dim, 0, max_it_emi=50000)
     sp = sp._replace(rtol_emi=1e-10, rtol_knp=1e-12)
     S._unpack_solver_params(sp)
     S.save_fields = S.save_solver_stats = False
     S.splitting_scheme = True
     S.setup_varform_emi(); S.setup_varform_knp(); S.setup_solver_emi(); S.setup_solver_knp()
-    pb = ko.build_idealized(mt[0], mt[1].array(), mt[2].array(), membrane_tags=(1,))
+    pb = ko.build_idealized(mt[0], mt[1].array(), mt[2].array(), p=degree, membrane_tags=(1,))
     pb.phi_M[:] = 0.0
     t = Constant(0.0)
     for k in range(3):
