@@ -74,6 +74,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--resolution", type=int, default=2)
+    ap.add_argument("--degree", type=int, default=1, help="DG degree: 1 = headline config (configs[3] mesh), 2 = configs[2] (use --resolution 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -101,7 +102,7 @@ def main():
         from knpemidg.partition import make_distributed_solver
         S = make_distributed_solver(dim=3, resolution=r, rank=rank, world=world, local_rank=local_rank, dist=dist)
     else:
-        S = make_solver(dim=3, resolution=r, verbose=False)
+        S = make_solver(dim=3, resolution=r, verbose=False, degree=args.degree)
     sp = solver_parameters(3, r)
     S._unpack_solver_params(sp)
     S.save_fields = S.save_solver_stats = False
@@ -139,12 +140,18 @@ def main():
     S.dev.update_kappa(); S.dev.update_dnphi()
     emi_ms = S.dev.bench_apply(0, 200)
     knp_ms = S.dev.bench_apply(1, 200)
-    emi_gbs = EMI_BYTES_PER_CELL * nc_local / (emi_ms * 1e-3) / 1e9
-    knp_gbs = KNP_BYTES_PER_CELL * nc_local / (knp_ms * 1e-3) / 1e9
+    # algorithmic bytes per cell: P1 137 / 217, P2 281 / 457
+    emi_bpc = EMI_BYTES_PER_CELL if args.degree == 1 else 281.0
+    knp_bpc = KNP_BYTES_PER_CELL if args.degree == 1 else 457.0
+    emi_gbs = emi_bpc * nc_local / (emi_ms * 1e-3) / 1e9
+    knp_gbs = knp_bpc * nc_local / (knp_ms * 1e-3) / 1e9
 
     # HBM-side traffic of the same kernel on the same workload, from the committed rocprofv3 --pmc passes
     # (counters cannot be read from inside this process); null when the workload differs
     emi_name = "k_emi_apply_cls_staged<3,256>" if S.dev.n_geometry_classes else "k_emi_apply<3,3>"
+    knp_name = "k_knp_apply_cls_staged<3,2,256>" if S.dev.n_geometry_classes else "k_knp_apply<3,2>"
+    if args.degree != 1:
+        emi_name = knp_name = "k_tab_apply<3,10>"
     traffic = None
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
@@ -158,8 +165,8 @@ def main():
             "metric": "DoF-updates/sec per PDE timestep", "value": dofs * args.steps / elapsed, "unit": "DoF/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "3D idealized 4-axon mesh r=%d (%d tets, %d P1-DG DoFs: phi + K,Cl solved, Na eliminated), "
-                                   "HH membranes + stimulus, full splitting step" % (r, nc_global, dofs),
+            "config": {"workload": "3D idealized 4-axon mesh r=%d (%d tets, %d P%d-DG DoFs: phi + K,Cl solved, Na eliminated), "
+                                   "HH membranes + stimulus, full splitting step" % (r, nc_global, dofs, args.degree),
                        "parallelism": "slab%d" % world,
                        "preconditioner": "cell-block-Jacobi + conforming-P1 smoothed-aggregation AMG V-cycle" if S.use_amg
                        else "cell-block-Jacobi",
@@ -167,11 +174,11 @@ def main():
                        "knp_iters_per_step": float(np.mean([max(n) for n in S.knp_niter[-args.steps:]])),
                        "emi_solve_s": S.emi_solve_timer, "knp_solve_s": S.knp_solve_timer,
                        "assemble_s": S.emi_ass_timer + S.knp_ass_timer, "ode_s": S.ode_solve_timer},
-            "roofline": {"bound": "hbm", "kernel": "k_emi_apply_cls_staged<3,256>" if S.dev.n_geometry_classes else "k_emi_apply<3,3>", "achieved": emi_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": emi_name, "achieved": emi_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": emi_gbs / HBM_PEAK_GBS, "traffic": traffic, "avg_kernel_us": emi_ms * 1e3,
-                         "algorithmic_bytes_per_cell": EMI_BYTES_PER_CELL, "cells_per_launch": nc_local,
-                         "knp_apply": {"kernel": "k_knp_apply_cls_staged<3,2,256>" if S.dev.n_geometry_classes else "k_knp_apply<3,2>", "achieved": knp_gbs, "frac": knp_gbs / HBM_PEAK_GBS,
-                                       "avg_kernel_us": knp_ms * 1e3, "algorithmic_bytes_per_cell": KNP_BYTES_PER_CELL}},
+                         "algorithmic_bytes_per_cell": emi_bpc, "cells_per_launch": nc_local,
+                         "knp_apply": {"kernel": knp_name, "achieved": knp_gbs, "frac": knp_gbs / HBM_PEAK_GBS,
+                                       "avg_kernel_us": knp_ms * 1e3, "algorithmic_bytes_per_cell": knp_bpc}},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()

@@ -169,25 +169,16 @@ __global__ __launch_bounds__(256) void k_dense_mv(int n, const float* __restrict
     if (threadIdx.x == 0) y[row] = (part[0] + part[1]) + (part[2] + part[3]);
 }
 
-// rc[v] = sum over the DG dofs mapped to conforming dof v (CSR list, fixed order -> deterministic).  P2: the list also
-// holds the edge-midpoint dofs of the edges ending in v, which carry weight 1/2 (a P1 function at an edge midpoint is
-// the mean of the end values); local dof index >= nvtx marks them.
+// rc[v] = sum over the DG dofs mapped to conforming dof v (CSR list, fixed order -> deterministic)
 __global__ __launch_bounds__(256) void k_dg_restrict(int64_t ncg, const int32_t* __restrict__ ptr, const int32_t* __restrict__ idx,
-                                                     const double* __restrict__ r, double* __restrict__ rc, int nd, int nvtx) {
+                                                     const double* __restrict__ r, double* __restrict__ rc) {
     // 8 lanes per conforming dof (a vertex is shared by ~24 tets); fixed summation tree -> deterministic
     const int64_t v = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 3;
     const int lane = threadIdx.x & 7;
     double s = 0.0;
     if (v < ncg) {
         const int e = ptr[v + 1];
-        if (nd == nvtx) {
-            for (int k = ptr[v] + lane; k < e; k += 8) s += r[idx[k]];
-        } else {
-            for (int k = ptr[v] + lane; k < e; k += 8) {
-                const int i = idx[k];
-                s += ((i % nd) < nvtx ? 1.0 : 0.5) * r[i];
-            }
-        }
+        for (int k = ptr[v] + lane; k < e; k += 8) s += r[idx[k]];
     }
     s += __shfl_down(s, 4, 8);
     s += __shfl_down(s, 2, 8);
@@ -275,7 +266,7 @@ int amg_vcycle(knp_ctx* c, AmgHierarchy& H, hipStream_t on_stream) {
 
 int amg_restrict_from_dg(knp_ctx* c, AmgHierarchy& H, const double* r_dg) {
     hipLaunchKernelGGL(k_dg_restrict, dim3((unsigned)((H.ncg * 8 + 255) / 256)), dim3(256), 0, c->stream, H.ncg, H.cg_ptr, H.cg_idx,
-                       r_dg, H.levels[0].b, c->nd, c->m.dim + 1);
+                       r_dg, H.levels[0].b);
     // multi-GPU: the conforming hierarchy is replicated on every rank; the restricted residual is the sum of the
     // ranks' owned-cell contributions (one all-reduce of ncg doubles), after which every rank runs the same V-cycle
     if (c->nranks > 1) return allreduce_red(c, H.levels[0].b, (int)H.ncg);
@@ -306,10 +297,10 @@ int knp_amg_begin(knp_ctx* c, int which, int64_t ncg, const int32_t* dg2cg, cons
     if (!H) { c->err = "amg: bad slot"; return -1; }
     amg_free(*H);
     const int64_t ndof = c->m.nc * c->nd;
-    const int64_t nmap = c->m.nc * (c->m.dim + 1);          // dg2cg: conforming dof of every cell vertex
+    const int64_t nmap = ndof;                              // dg2cg: conforming dof of every DG dof (injection)
     for (int64_t i = 0; i < nmap; ++i)
         if (dg2cg[i] < 0 || dg2cg[i] >= ncg) { c->err = "amg: dg2cg out of range"; return -1; }
-    if (cg_ptr[ncg] > 2 * ndof) { c->err = "amg: cg_ptr inconsistent"; return -1; }     // P2 edge dofs appear under both end vertices
+    if (cg_ptr[ncg] > ndof) { c->err = "amg: cg_ptr inconsistent"; return -1; }
     for (int64_t k = 0; k < cg_ptr[ncg]; ++k)
         if (cg_idx[k] < 0 || cg_idx[k] >= ndof) { c->err = "amg: cg_idx out of range"; return -1; }
     H->ncg = ncg;

@@ -67,24 +67,12 @@ template <int NV> __device__ __forceinline__ void stv(double* p, int64_t c, cons
     }
 }
 
-// value of the conforming-P1 correction e at DG dof a of cell c.  dg2cg holds the conforming dof of every cell VERTEX
-// ([nc][dim+1]); P1: injection.  P2 (NV = 6 / 10): vertex dofs first, then the edge midpoints (a0,a1), a0 < a1 in
-// lexicographic order, where a P1 function takes the mean of the two vertex values.
+// conforming-space correction e gathered into the DG dofs of cell c: dg2cg[c][a] is the conforming dof of DG dof (c, a)
+// (P1: membrane-broken vertex dofs; P2: vertex + edge dofs of the conforming P2 space) -- pure injection
 template <int NV> __device__ __forceinline__ void prolong_cell(const int32_t* __restrict__ dg2cg, const double* __restrict__ e,
                                                                 int64_t c, double* add) {
-    constexpr int NVT = (NV == 3 || NV == 6) ? 3 : 4;
-    double ev[NVT];
 #pragma unroll
-    for (int a = 0; a < NVT; ++a) ev[a] = e[dg2cg[c * NVT + a]];
-#pragma unroll
-    for (int a = 0; a < NVT; ++a) add[a] = ev[a];
-    if constexpr (NV > NVT) {
-        int k = NVT;
-#pragma unroll
-        for (int a0 = 0; a0 < NVT; ++a0)
-#pragma unroll
-            for (int a1 = a0 + 1; a1 < NVT; ++a1) add[k++] = 0.5 * (ev[a0] + ev[a1]);
-    }
+    for (int a = 0; a < NV; ++a) add[a] = e[dg2cg[c * NV + a]];
 }
 
 template <int NV> __device__ __forceinline__ void block_matvec(const double* __restrict__ binv, int64_t c, const double* r, double* z) {

@@ -419,28 +419,15 @@ class Device:
 
     # -- auxiliary-space AMG (knpemidg/amg.py builds, csrc/amg.hip applies) ------------------
     def amg_upload(self, which, dg2cg, levels):
-        """dg2cg [nc, dim+1]: conforming dof of every cell vertex, caller's cell order; levels from amg.build_hierarchy."""
-        nd, nv = self.nd, self.dim + 1
-        vmap = np.asarray(dg2cg)[self.cell_order].reshape(self.nc, nv)
-        d2c = np.ascontiguousarray(vmap.ravel(), dtype=np.int32)
+        """dg2cg [nc, nd]: conforming dof of every DG dof (caller's cell order); levels from amg.build_hierarchy."""
+        nd = self.nd
+        d2c = np.ascontiguousarray(np.asarray(dg2cg)[self.cell_order].ravel(), dtype=np.int32)
+        assert d2c.shape == (self.nc * nd,)
         ncg = levels[0].A.shape[0]
-        # restriction lists: for every conforming dof the DG dofs it receives from (owned cells).  P1: the vertex dofs.
-        # P2: also the edge-midpoint dofs of the edges ending in that vertex (weight 1/2, applied by the kernel).
-        vo = vmap[:self.nc_owned]
-        cell = np.arange(self.nc_owned, dtype=np.int64)[:, None]
-        tgt = [vo.ravel()]
-        src = [(cell * nd + np.arange(nv)[None, :]).ravel()]
-        if nd > nv:
-            for e, (a, b) in enumerate([(a, b) for a in range(nv) for b in range(a + 1, nv)]):
-                for end in (a, b):
-                    tgt.append(vo[:, end])
-                    src.append(cell[:, 0] * nd + nv + e)
-        tgt = np.concatenate(tgt)
-        src = np.concatenate(src)
-        order = np.lexsort((src, tgt))
-        idx = np.ascontiguousarray(src[order], dtype=np.int32)
+        own = d2c[:self.nc_owned * nd]
+        idx = np.argsort(own, kind="stable").astype(np.int32)
         ptr = np.zeros(ncg + 1, dtype=np.int32)
-        np.cumsum(np.bincount(tgt, minlength=ncg), out=ptr[1:])
+        np.cumsum(np.bincount(own, minlength=ncg), out=ptr[1:])
         self._chk(self.lib.knp_amg_begin(self.ctx, which, ncg, _p(d2c, _i32p), _p(ptr, _i32p), _p(idx, _i32p)), "knp_amg_begin")
 
         def csr(M):

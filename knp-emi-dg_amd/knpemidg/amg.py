@@ -92,6 +92,86 @@ class ConformingSpace:
 
 
 # ----------------------------------------------------------------------------------------------
+# conforming (membrane-broken) P2 space: auxiliary space of the DG-P2 operators
+# ----------------------------------------------------------------------------------------------
+class ConformingSpaceP2:
+    """Conforming P2 on top of a ConformingSpace (P1).  For DG-P2 the cell-block-Jacobi part over-weights every
+    CONTINUOUS quadratic mode by the penalty factor (tau = 20 d p = 120 in 3D), so the auxiliary space must contain
+    them: vertex dofs = the P1 space's dofs, edge dofs keyed by the pair of (already membrane-broken) vertex dofs.
+    Local order per cell as on the device: vertices, then edges (a, b), a < b, lexicographic.
+    The P1 space enters the hierarchy as the first coarse level through `interp` (vertex: identity, edge: mean)."""
+
+    def __init__(self, cs):
+        self.cs = cs
+        mesh = cs.mesh
+        nv = mesh.cells.shape[1]
+        self.edges = [(a, b) for a in range(nv) for b in range(a + 1, nv)]
+        v = cs.dof.astype(np.int64)
+        lo = np.stack([np.minimum(v[:, a], v[:, b]) for a, b in self.edges], axis=1)
+        hi = np.stack([np.maximum(v[:, a], v[:, b]) for a, b in self.edges], axis=1)
+        uniq, inv = np.unique((lo * cs.n + hi).ravel(), return_inverse=True)
+        self.n = cs.n + len(uniq)
+        self.dof = np.concatenate([cs.dof, (cs.n + inv.reshape(lo.shape)).astype(np.int32)], axis=1)   # [nc, nd]
+        ne = len(uniq)
+        rows = np.concatenate([np.arange(cs.n), cs.n + np.arange(ne), cs.n + np.arange(ne)])
+        cols = np.concatenate([np.arange(cs.n), uniq // cs.n, uniq % cs.n])
+        vals = np.concatenate([np.ones(cs.n), np.full(2 * ne, 0.5)])
+        self.interp = sp.csr_matrix((vals, (rows, cols)), shape=(self.n, cs.n))
+
+    def stiffness(self, coef, mass_coef=None, membrane=None):
+        """Conforming-P2 Galerkin operator: sum_cells int coef grad u.grad v (+ mass_coef int u v)
+        (+ C int_F jump jump on membrane facets).  coef: [nc, nd] P2 nodal or [nc] cell-wise constant."""
+        from knpemidg import dgtab
+        from knpemidg.quadrature import simplex_rule
+        mesh = self.cs.mesh
+        d = mesh.gdim
+        x = mesh.coords[mesh.cells]
+        J = (x[:, 1:, :] - x[:, :1, :]).transpose(0, 2, 1)
+        vol = np.abs(np.linalg.det(J)) / {2: 2.0, 3: 6.0}[d]
+        Jinv = np.linalg.inv(J)
+        g = np.empty((x.shape[0], d + 1, d))
+        g[:, 1:, :] = Jinv
+        g[:, 0, :] = -Jinv.sum(axis=1)
+        Gl = np.einsum("cld,cmd->clm", g, g)                                  # grad lambda_l . grad lambda_m
+        nd = self.dof.shape[1]
+        bary, w = simplex_rule(d, 4)
+        B, dB = dgtab.tabulate(2, bary)
+        coef = np.asarray(coef, dtype=np.float64)
+        kq = coef @ B.T if coef.ndim == 2 else np.repeat(coef[:, None], len(w), axis=1)      # [nc, q]
+        # blk[c, a, b] = vol sum_q w kq dB[q,a,l] dB[q,b,m] Gl[c,l,m]
+        T = np.einsum("q,qal,qbm->qablm", w, dB, dB)
+        blk = np.einsum("cq,qablm,clm->cab", kq, T, Gl) * vol[:, None, None]
+        if mass_coef is not None:
+            Mref = np.einsum("q,qa,qb->ab", w, B, B)
+            blk = blk + (np.asarray(mass_coef) * vol)[:, None, None] * Mref[None]
+        rows = np.repeat(self.dof[:, :, None], nd, axis=2).ravel()
+        cols = np.repeat(self.dof[:, None, :], nd, axis=1).ravel()
+        A = sp.coo_matrix((blk.ravel(), (rows, cols)), shape=(self.n, self.n))
+        if membrane is not None:
+            fids, C = membrane
+            fcl = mesh.facet_cells[fids]
+            fl = mesh.facet_local[fids].astype(np.int64)
+            fx = mesh.coords[mesh.facets[fids]]
+            if d == 2:
+                area = np.linalg.norm(fx[:, 1] - fx[:, 0], axis=1)
+            else:
+                area = 0.5 * np.linalg.norm(np.cross(fx[:, 1] - fx[:, 0], fx[:, 2] - fx[:, 0]), axis=1)
+            mu, wf = simplex_rule(d - 1, 4)
+            Bs = np.array([dgtab.tabulate(2, np.insert(mu, i, 0.0, axis=1))[0] for i in range(d + 1)])   # [i, q, nd]
+            B0, B1 = Bs[fl[:, 0]], Bs[fl[:, 1]]                                 # [F, q, nd]
+            Jm = np.concatenate([B0, -B1], axis=2)                              # jump operator on the facet pair
+            full = np.einsum("f,q,fqa,fqb->fab", C * area, wf, Jm, Jm)
+            dofs = np.concatenate([self.dof[fcl[:, 0]], self.dof[fcl[:, 1]]], axis=1)
+            rows = np.repeat(dofs[:, :, None], 2 * nd, axis=2).ravel()
+            cols = np.repeat(dofs[:, None, :], 2 * nd, axis=1).ravel()
+            A = A + sp.coo_matrix((full.ravel(), (rows, cols)), shape=(self.n, self.n))
+        A = A.tocsr()
+        A.sum_duplicates()
+        A.eliminate_zeros()
+        return A
+
+
+# ----------------------------------------------------------------------------------------------
 # smoothed aggregation
 # ----------------------------------------------------------------------------------------------
 def _rowmax(S, vals):
@@ -153,10 +233,12 @@ class Level:
     pass
 
 
-def build_hierarchy(A, theta=0.08, max_coarse=4000, max_levels=12, cheb_degree=2, cheb_lower=0.3, psmooth=2, trunc=0.04):
+def build_hierarchy(A, theta=0.08, max_coarse=4000, max_levels=12, cheb_degree=2, cheb_lower=0.3, psmooth=2, trunc=0.04,
+                    top_interp=None):
     """Smoothed-aggregation hierarchy for an SPD (possibly singular, constants) matrix.
     Each level: A (csr), dinv, rho = spectral radius estimate of D^-1 A, P (csr, to the next level).
-    Last level: dense pseudo-inverse."""
+    Last level: dense pseudo-inverse.  top_interp: geometric prolongator of the first level (conforming P1 -> P2,
+    ConformingSpaceP2.interp); aggregation starts below it."""
     import os
     theta = float(os.environ.get("KNP_AMG_THETA", theta))
     cheb_degree = int(os.environ.get("KNP_AMG_DEGREE", cheb_degree))
@@ -175,6 +257,15 @@ def build_hierarchy(A, theta=0.08, max_coarse=4000, max_levels=12, cheb_degree=2
         lv.cheb_degree, lv.cheb_lower = cheb_degree, cheb_lower
         levels.append(lv)
         n = A.shape[0]
+        if top_interp is not None and len(levels) == 1:
+            P = top_interp.tocsr().astype(np.float64)
+            P.sort_indices()
+            lv.P = P
+            lv.R = P.T.tocsr()
+            lv.R.sort_indices()
+            A = (lv.R @ A @ P).tocsr()
+            A.sort_indices()
+            continue
         if n <= max_coarse or len(levels) >= max_levels:
             break
         # symmetric strength of connection

@@ -271,7 +271,7 @@ class Solver:
         gmesh, gsub, gsurf = self._amg_global()
         if gmesh is self.mesh:
             dev.update_kappa()
-            kappa = dev.download(_abi.F_KAPPA).reshape(self.mesh.num_cells(), self.nd)[:, :self.gdim + 1]   # vertex values (P2: coefficient of the P1 auxiliary space)
+            kappa = dev.download(_abi.F_KAPPA).reshape(self.mesh.num_cells(), self.nd)
         else:
             # distributed: every rank builds the SAME global hierarchy from the tag-wise initial state (no
             # communication; the preconditioner is lagged anyway)
@@ -284,8 +284,14 @@ class Solver:
                 kappa += _f(self.F) * float(ion['z']) ** 2 * self.psi * D * c0
         ft = gsurf.array()
         mem = np.nonzero((gmesh.facet_cells[:, 1] >= 0) & np.isin(ft, self.membrane_tags))[0]
-        Ac = self._cspace.stiffness(kappa, membrane=(mem, _f(self.C_phi)))
-        levels = amg.build_hierarchy(Ac, psmooth=2)          # EMI: 68 -> 22 PCG iterations at r=2 vs one smoothing step
+        if self.degree_knp == 1:
+            Ac = self._cspace.stiffness(kappa, membrane=(mem, _f(self.C_phi)))
+            levels = amg.build_hierarchy(Ac, psmooth=2)      # EMI: 68 -> 22 PCG iterations at r=2 vs one smoothing step
+        else:
+            # DG-P2: auxiliary space = conforming P2 (block-Jacobi over-weights continuous quadratics by the penalty
+            # factor); the conforming P1 space is its first coarse level, aggregation starts below
+            Ac = self._cspace2.stiffness(kappa, membrane=(mem, _f(self.C_phi)))
+            levels = amg.build_hierarchy(Ac, psmooth=2, top_interp=self._cspace2.interp)
         dev.amg_upload(0, self._local_dg2cg(), levels)
         self.amg_setup_timer = time.perf_counter() - ts
         if self.verbose:
@@ -303,11 +309,14 @@ class Solver:
         g = getattr(self, "global_mesh_tuple", None) or (self.mesh, self.subdomains, self.surfaces)
         if not hasattr(self, "_cspace"):
             self._cspace = amg.ConformingSpace(g[0], g[2].array(), self.membrane_tags)
+            if self.degree_knp != 1:
+                self._cspace2 = amg.ConformingSpaceP2(self._cspace)
         return g
 
     def _local_dg2cg(self):
         loc = getattr(self, "local_mesh", None)
-        return self._cspace.dof if loc is None else self._cspace.dof[loc.cells_global]
+        dof = self._cspace.dof if self.degree_knp == 1 else self._cspace2.dof
+        return dof if loc is None else dof[loc.cells_global]
 
     @staticmethod
     def _by_tag(d, subdomains):
@@ -325,8 +334,12 @@ class Solver:
         gmesh, gsub, gsurf = self._amg_global()
         nc = gmesh.num_cells()
         for k, ion in enumerate(self.ion_list[:-1]):
-            Ac = self._cspace.stiffness(self._by_tag(ion['D_sub'], gsub), mass_coef=np.full(nc, 1.0 / _f(self.dt)))
-            levels = amg.build_hierarchy(Ac, psmooth=2)      # 10 -> 8 BiCGStab iterations once P is truncated
+            if self.degree_knp == 1:
+                Ac = self._cspace.stiffness(self._by_tag(ion['D_sub'], gsub), mass_coef=np.full(nc, 1.0 / _f(self.dt)))
+                levels = amg.build_hierarchy(Ac, psmooth=2)  # 10 -> 8 BiCGStab iterations once P is truncated
+            else:
+                Ac = self._cspace2.stiffness(self._by_tag(ion['D_sub'], gsub), mass_coef=np.full(nc, 1.0 / _f(self.dt)))
+                levels = amg.build_hierarchy(Ac, psmooth=2, top_interp=self._cspace2.interp)
             self.dev.amg_upload(1 + k, self._local_dg2cg(), levels)
             if self.verbose:
                 print(" AMG(KNP %s) levels:" % ion['name'], [lv.A.shape[0] for lv in levels])
