@@ -87,6 +87,7 @@ struct knp_ctx {
     int* status = nullptr;         // device: [0]=converged flag, [1]=iterations
     void* pinned = nullptr;        // host pinned mirror for status/scalars
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int last_it_emi = 0, last_it_knp = 0;   // iteration counts of the previous solves (chunking of the status polls)
     // auxiliary-space AMG hierarchies: [0] EMI, [1 + k] KNP species k
     std::vector<AmgHierarchy> amg;
     std::vector<hipStream_t> aux_streams;   // one per extra KNP species: their V-cycles run concurrently

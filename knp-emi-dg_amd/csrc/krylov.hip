@@ -507,6 +507,19 @@ static int poll_status(knp_ctx* c, int nsys, int* host_status) {
     return 0;
 }
 
+// How many iterations to enqueue before the next look at the device's convergence flag.  Kernels of iterations past
+// convergence are no-ops only for the vector updates -- operator applies and V-cycles still run -- so a fixed chunk of
+// 25 wastes up to a whole solve's worth of work (17 useful + 8 wasted iterations at r=2).  Iteration counts are stable
+// from one time step to the next: enqueue (previous count - 1) iterations without looking, then look every 2.
+static inline int next_chunk(int it, int maxit, int check_every, int predicted) {
+    int chunk = check_every;
+    if (predicted > 0) {
+        const int ahead = predicted - 1 - it;
+        chunk = ahead > 0 ? (ahead < 4 * check_every ? ahead : 4 * check_every) : 2;
+    }
+    return (maxit - it < chunk) ? (maxit - it) : chunk;
+}
+
 template <int NV>
 static int pcg_impl(knp_ctx* c, KrylovVecs& kv, double rtol, double atol, int maxit, int check_every, int* niter, double* res) {
     VecDims d{c->m.nc_owned, c->m.nc, 1};
@@ -533,7 +546,7 @@ static int pcg_impl(knp_ctx* c, KrylovVecs& kv, double rtol, double atol, int ma
     int it = 0;
     if ((rc = poll_status(c, 1, hs))) return rc;
     while (!hs[0] && it < maxit) {
-        const int chunk = (maxit - it < check_every) ? (maxit - it) : check_every;
+        const int chunk = next_chunk(it, maxit, check_every, c->last_it_emi);
         for (int k = 0; k < chunk; ++k) {
             if (c->nranks > 1 && (rc = halo_exchange(c, kv.p, 1))) return rc;
             if ((rc = launch_emi_apply(c, kv.p, kv.coef, kv.w))) return rc;
@@ -557,6 +570,7 @@ static int pcg_impl(knp_ctx* c, KrylovVecs& kv, double rtol, double atol, int ma
     double hscal[KS_N];
     HIPCHK(c, hipMemcpy(hscal, c->scal, sizeof(double) * KS_N, hipMemcpyDeviceToHost));
     *niter = hs[1];
+    c->last_it_emi = hs[1];
     res[0] = hscal[KS_RES0];
     res[1] = hscal[KS_RES];
     res[2] = hscal[KS_BNORM];
@@ -641,7 +655,7 @@ static int bicgstab_impl(knp_ctx* c, KrylovVecs& kv, double rtol, double atol, i
     if ((rc = poll_status(c, ns, hs))) return rc;
     int it = 0;
     while (!all_done() && it < maxit) {
-        const int chunk = (maxit - it < check_every) ? (maxit - it) : check_every;
+        const int chunk = next_chunk(it, maxit, check_every, c->last_it_knp);
         for (int k = 0; k < chunk; ++k) {
             hipLaunchKernelGGL(k_bi_p<NV>, g, b, 0, c->stream, d, c->scal, c->status, kv.r, kv.v, kv.binv, kv.p, kv.y);
             if ((rc = knp_coarse_correction<NV>(c, d, kv.p, kv.y))) return rc;
@@ -668,6 +682,7 @@ static int bicgstab_impl(knp_ctx* c, KrylovVecs& kv, double rtol, double atol, i
     int bad = 0;
     for (int s = 0; s < ns; ++s) {
         niter[s] = hs[2 * s + 1];
+        if (s == 0 || niter[s] > c->last_it_knp) c->last_it_knp = niter[s];
         res[3 * s + 0] = hscal[s * KS_N + KS_RES0];
         res[3 * s + 1] = hscal[s * KS_N + KS_RES];
         res[3 * s + 2] = hscal[s * KS_N + KS_BNORM];
