@@ -89,7 +89,9 @@ def main():
         raise SystemExit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    # KNP_FORCE_COMM=1 takes the distributed code path (process group, slab partition, RCCL communicator) with one rank
+    force_dist = os.environ.get("KNP_FORCE_COMM", "0") == "1" and "RANK" in os.environ
+    if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -98,7 +100,7 @@ def main():
     from knpemidg import _abi as A
 
     r = args.resolution
-    if world > 1:
+    if world > 1 or force_dist:
         from knpemidg.partition import make_distributed_solver
         S = make_distributed_solver(dim=3, resolution=r, rank=rank, world=world, local_rank=local_rank, dist=dist)
     else:

@@ -334,7 +334,7 @@ int knp_emi_apply(knp_ctx* c, int fx, int fy) {
     if (!c) return -1;
     if (chk_vec(c, fx, fy, c->m.nc * c->nd)) return -1;
     Fields* f = F(c);
-    if (c->nranks > 1) { int rc = halo_exchange(c, f->f[fx], 1); if (rc) return rc; }
+    if (c->dist) { int rc = halo_exchange(c, f->f[fx], 1); if (rc) return rc; }
     return launch_emi_apply(c, f->f[fx], f->f[KNP_F_KAPPA], f->f[fy]);
 }
 
@@ -342,7 +342,7 @@ int knp_knp_apply(knp_ctx* c, int fx, int fy) {
     if (!c) return -1;
     if (chk_vec(c, fx, fy, (int64_t)c->p.n_sys * c->m.nc * c->nd)) return -1;
     Fields* f = F(c);
-    if (c->nranks > 1) { int rc = halo_exchange(c, f->f[fx], c->p.n_sys); if (rc) return rc; }
+    if (c->dist) { int rc = halo_exchange(c, f->f[fx], c->p.n_sys); if (rc) return rc; }
     return launch_knp_apply(c, f->f[fx], f->f[KNP_F_DNPHI], f->f[fy]);
 }
 
@@ -369,7 +369,7 @@ int knp_emi_solve(knp_ctx* c, double rtol, double atol, int maxit, int check_eve
     kv.r = f->r; kv.z = f->z; kv.p = f->p; kv.w = f->w; kv.rhat = f->rhat; kv.v = f->v; kv.y = f->y;
     rc = pcg_solve(c, kv, rtol, atol, maxit, check_every, niter, res);
     if (rc) return rc;
-    if (c->nranks > 1) return halo_exchange(c, kv.x, 1);     // ghostUpdate (solver.py:529)
+    if (c->dist) return halo_exchange(c, kv.x, 1);     // ghostUpdate (solver.py:529)
     return 0;
 }
 
@@ -383,7 +383,7 @@ int knp_knp_solve(knp_ctx* c, double rtol, double atol, int maxit, int min_it, i
     kv.r = f->r; kv.z = f->z; kv.p = f->p; kv.w = f->w; kv.rhat = f->rhat; kv.v = f->v; kv.y = f->y;
     rc = bicgstab_solve(c, kv, rtol, atol, maxit, min_it, check_every, niter, res);
     if (rc) return rc;
-    if (c->nranks > 1) return halo_exchange(c, kv.x, c->p.n_sys);   // ghostUpdate (solver.py:789)
+    if (c->dist) return halo_exchange(c, kv.x, c->p.n_sys);   // ghostUpdate (solver.py:789)
     return 0;
 }
 
@@ -469,7 +469,7 @@ int knp_halo_exchange(knp_ctx* c, int field) {
     if (chk_field(c, field)) return -1;
     const int64_t ndof = c->m.nc * c->nd;
     if (F(c)->n[field] % ndof) { c->err = "halo_exchange: not a nodal field"; return -1; }
-    if (c->nranks <= 1) return 0;
+    if (!c->dist) return 0;
     return halo_exchange(c, F(c)->f[field], (int)(F(c)->n[field] / ndof));
 }
 

@@ -269,7 +269,7 @@ int amg_restrict_from_dg(knp_ctx* c, AmgHierarchy& H, const double* r_dg) {
                        r_dg, H.levels[0].b);
     // multi-GPU: the conforming hierarchy is replicated on every rank; the restricted residual is the sum of the
     // ranks' owned-cell contributions (one all-reduce of ncg doubles), after which every rank runs the same V-cycle
-    if (c->nranks > 1) return allreduce_red(c, H.levels[0].b, (int)H.ncg);
+    if (c->dist) return allreduce_red(c, H.levels[0].b, (int)H.ncg);
     return 0;
 }
 

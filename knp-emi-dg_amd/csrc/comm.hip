@@ -9,6 +9,7 @@
 #include "knpemi_internal.hpp"
 #include <rccl/rccl.h>
 #include <cstring>
+#include <cstdlib>
 
 #define NCCLCHK(ctx, call)                                                         \
     do {                                                                           \
@@ -56,7 +57,7 @@ __global__ void k_halo_pack(const double* __restrict__ v, const int32_t* __restr
 }
 
 int halo_exchange(knp_ctx* c, double* v, int nfields) {
-    if (c->nranks <= 1 || c->halo_peer.empty()) return 0;
+    if (!c->dist || c->halo_peer.empty()) return 0;
     if (!c->comm) { c->err = "halo exchange without communicator"; return -6; }
     if (nfields > KNP_MAX_SYS) { c->err = "halo exchange: too many fields"; return -1; }
     const int NV = c->nd;
@@ -102,13 +103,16 @@ int knp_comm_init(knp_ctx* c, int rank, int nranks, const char* id128) {
     if (!c || !id128 || nranks < 1 || rank < 0 || rank >= nranks) return -1;
     c->rank = rank;
     c->nranks = nranks;
-    if (nranks == 1) return 0;
+    // KNP_FORCE_COMM=1: build the communicator and take every collective code path even with one rank (a 1-GPU box can
+    // then exercise ncclCommInitRank / ncclAllReduce on the solver's stream; RCCL refuses two ranks on one device)
+    if (nranks == 1 && !getenv("KNP_FORCE_COMM")) return 0;
     ncclUniqueId id;
     memcpy(&id, id128, sizeof(id));
     HIPCHK(c, hipSetDevice(c->device));
     ncclComm_t comm;
     NCCLCHK(c, ncclCommInitRank(&comm, nranks, id, rank));
     c->comm = comm;
+    c->dist = true;
     return 0;
 }
 

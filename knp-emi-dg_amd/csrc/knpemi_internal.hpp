@@ -96,6 +96,7 @@ struct knp_ctx {
     // distributed
     void* comm = nullptr;          // ncclComm_t
     int rank = 0, nranks = 1;
+    bool dist = false;             // communicator active: halo exchanges + all-reduced reductions
     std::vector<int> halo_peer;
     std::vector<int64_t> halo_send_off, halo_send_cnt, halo_recv_off, halo_recv_cnt;
     int32_t* halo_send_idx = nullptr;   // device: owned cell ids to pack, grouped by peer

@@ -476,7 +476,7 @@ int max_abs_diff(knp_ctx* c, const double* a, const double* b, int nsys, double*
     HIPCHK(c, hipStreamSynchronize(c->stream));
     double m = 0.0;
     for (double v : h) m = v > m ? v : m;
-    if (c->nranks > 1) {
+    if (c->dist) {
         int rc = allreduce_max(c, &m);
         if (rc) return rc;
     }
@@ -491,7 +491,7 @@ static int finalize(knp_ctx* c, int op, int nsys, int nred, double rtol, double 
     const int64_t nb = grid_for(c->m.nc_owned);
     double* red = c->scal + KNP_MAX_SYS * KS_N;
     hipLaunchKernelGGL(k_reduce, dim3(nsys), dim3(KNP_BLOCK), 0, c->stream, c->partial, nb, nsys, nred, red);
-    if (c->nranks > 1) {
+    if (c->dist) {
         int rc = allreduce_red(c, red, nsys * KNP_MAX_RED);
         if (rc) return rc;
     }
@@ -525,7 +525,7 @@ static int pcg_impl(knp_ctx* c, KrylovVecs& kv, double rtol, double atol, int ma
     VecDims d{c->m.nc_owned, c->m.nc, 1};
     const dim3 g((unsigned)grid_for(c->m.nc_owned)), b(KNP_BLOCK);
     int rc;
-    if (c->nranks > 1 && (rc = halo_exchange(c, kv.x, 1))) return rc;
+    if (c->dist && (rc = halo_exchange(c, kv.x, 1))) return rc;
     if ((rc = launch_emi_apply(c, kv.x, kv.coef, kv.w))) return rc;
     AmgHierarchy* H = (c->amg.size() && c->amg[0].ready) ? &c->amg[0] : nullptr;
     hipLaunchKernelGGL(k_cg_init<NV>, g, b, 0, c->stream, d, kv.b, kv.w, kv.binv, kv.r, kv.z, kv.p, c->partial);
@@ -548,7 +548,7 @@ static int pcg_impl(knp_ctx* c, KrylovVecs& kv, double rtol, double atol, int ma
     while (!hs[0] && it < maxit) {
         const int chunk = next_chunk(it, maxit, check_every, c->last_it_emi);
         for (int k = 0; k < chunk; ++k) {
-            if (c->nranks > 1 && (rc = halo_exchange(c, kv.p, 1))) return rc;
+            if (c->dist && (rc = halo_exchange(c, kv.p, 1))) return rc;
             if ((rc = launch_emi_apply(c, kv.p, kv.coef, kv.w))) return rc;
             hipLaunchKernelGGL(k_dot2<NV>, dim3(g.x, 1), b, 0, c->stream, d, kv.p, kv.w, (const double*)nullptr,
                                (const double*)nullptr, c->partial, c->status);
@@ -646,7 +646,7 @@ static int bicgstab_impl(knp_ctx* c, KrylovVecs& kv, double rtol, double atol, i
     VecDims d{c->m.nc_owned, c->m.nc, ns};
     const dim3 g((unsigned)grid_for(c->m.nc_owned), (unsigned)ns), b(KNP_BLOCK);
     int rc;
-    if (c->nranks > 1 && (rc = halo_exchange(c, kv.x, ns))) return rc;
+    if (c->dist && (rc = halo_exchange(c, kv.x, ns))) return rc;
     if ((rc = launch_knp_apply(c, kv.x, kv.coef, kv.w))) return rc;
     hipLaunchKernelGGL(k_bi_init<NV>, g, b, 0, c->stream, d, kv.b, kv.w, kv.r, kv.rhat, kv.p, kv.v, c->partial);
     if ((rc = finalize(c, OP_BI_INIT, ns, 2, rtol, atol, min_it))) return rc;
@@ -659,14 +659,14 @@ static int bicgstab_impl(knp_ctx* c, KrylovVecs& kv, double rtol, double atol, i
         for (int k = 0; k < chunk; ++k) {
             hipLaunchKernelGGL(k_bi_p<NV>, g, b, 0, c->stream, d, c->scal, c->status, kv.r, kv.v, kv.binv, kv.p, kv.y);
             if ((rc = knp_coarse_correction<NV>(c, d, kv.p, kv.y))) return rc;
-            if (c->nranks > 1 && (rc = halo_exchange(c, kv.y, ns))) return rc;
+            if (c->dist && (rc = halo_exchange(c, kv.y, ns))) return rc;
             if ((rc = launch_knp_apply(c, kv.y, kv.coef, kv.v))) return rc;
             hipLaunchKernelGGL(k_dot2<NV>, g, b, 0, c->stream, d, kv.rhat, kv.v, (const double*)nullptr, (const double*)nullptr,
                                c->partial, c->status);
             if ((rc = finalize(c, OP_BI_ALPHA, ns, 1, rtol, atol, min_it))) return rc;
             hipLaunchKernelGGL(k_bi_s<NV>, g, b, 0, c->stream, d, c->scal, c->status, kv.v, kv.binv, kv.r, kv.z);
             if ((rc = knp_coarse_correction<NV>(c, d, kv.r, kv.z))) return rc;
-            if (c->nranks > 1 && (rc = halo_exchange(c, kv.z, ns))) return rc;
+            if (c->dist && (rc = halo_exchange(c, kv.z, ns))) return rc;
             if ((rc = launch_knp_apply(c, kv.z, kv.coef, kv.w))) return rc;
             hipLaunchKernelGGL(k_dot2<NV>, g, b, 0, c->stream, d, kv.w, kv.r, kv.w, kv.w, c->partial, c->status);
             if ((rc = finalize(c, OP_BI_OMEGA, ns, 2, rtol, atol, min_it))) return rc;

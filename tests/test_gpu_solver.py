@@ -321,3 +321,25 @@ def test_baseline_config2_3d_single_cell_r1_apply(hip_lib):
     for k in range(pb.N_ions):
         assert relerr(y[k], ko.assemble_knp(pb, k) @ x[k].ravel()) < 1e-11
     dev.close()
+
+
+def test_rccl_code_path_with_one_rank(hip_lib):
+    """RCCL refuses two ranks on one device, so the collective code path is exercised with ONE rank: KNP_FORCE_COMM=1 makes
+    bench.py build the process group, the slab partition and the RCCL communicator, and every reduction / restricted
+    residual goes through ncclAllReduce on the solver's stream.  Must reproduce the single-process iteration counts."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    args = ["bench.py", "--gpus", "1", "--resolution", "0", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+    env = dict(os.environ)
+    plain = subprocess.run([sys.executable] + args, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert plain.returncode == 0, plain.stderr[-2000:]
+    env["KNP_FORCE_COMM"] = "1"
+    forced = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+                             "127.0.0.1", "--master-port", "29517"] + args, cwd=root, env=env, capture_output=True, text=True,
+                            timeout=600)
+    assert forced.returncode == 0, forced.stderr[-2000:]
+    a = json.loads([l for l in plain.stdout.splitlines() if l.startswith("{")][-1])
+    b = json.loads([l for l in forced.stdout.splitlines() if l.startswith("{")][-1])
+    assert a["config"]["emi_iters_per_step"] == b["config"]["emi_iters_per_step"]
+    assert a["config"]["knp_iters_per_step"] == b["config"]["knp_iters_per_step"]
