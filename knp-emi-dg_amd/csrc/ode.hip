@@ -11,7 +11,7 @@
 #define ODE_MAX_PARAMS 20
 
 struct OdeSet {
-    int model = 0;              // 1 = HH with synaptic stimulus, 2 = HH without
+    int model = 0;              // 1 = HH with synaptic stimulus, 2 = HH without, 3 = EMIx HH (cm/ms/mV), 4 = glial
     int ns = 0, np = 0;
     int64_t n = 0;
     int32_t* facet = nullptr;   // [n] facet id of every node
@@ -51,9 +51,58 @@ template <bool STIM> __device__ __forceinline__ void hh_rhs(double t, const doub
     dy[3] = (-i_K - i_Na) / p[6];
 }
 
+// EMIx neuron membrane: the same HH kinetics in cm / ms / mV units with a periodically re-triggered synaptic
+// conductance (reference: examples/emix-simulations/mm_hh.py:118-161); same parameter layout as above.
+__device__ __forceinline__ void hh_emix_rhs(double t, const double* y, double* p, double* dy) {
+    const double m = y[0], h = y[1], n = y[2], V = y[3];
+    const double alpha_m = 0.1 * (V + 40.0) / (1.0 - exp(-(V + 40.0) / 10.0));
+    const double beta_m = 4.0 * exp(-(V + 65.0) / 18.0);
+    const double alpha_h = 0.07 * exp(-(V + 65.0) / 20.0);
+    const double beta_h = 1.0 / (1.0 + exp(-(V + 35.0) / 10.0));
+    const double alpha_n = 0.01 * (V + 55.0) / (1.0 - exp(-(V + 55.0) / 10.0));
+    const double beta_n = 0.125 * exp(-(V + 65.0) / 80.0);
+    dy[0] = (1 - m) * alpha_m - m * beta_m;
+    dy[1] = (1 - h) * alpha_h - h * beta_h;
+    dy[2] = (1 - n) * alpha_n - n * beta_n;
+    const double g_stim = p[7] * exp(-fmod(t, 20.0) / 2.0);
+    const double a = 1 + p[13] / p[11], b = 1 + p[14] / p[12];
+    const double i_pump = p[15] / (a * a * b * b * b);
+    const double i_Na = (p[2] + p[0] * h * m * m * m + g_stim) * (V - p[4]) + 3 * i_pump;
+    const double n2 = n * n;
+    const double i_K = (p[3] + p[1] * n2 * n2) * (V - p[5]) - 2 * i_pump;
+    p[8] = i_Na;
+    p[9] = i_K;
+    p[10] = 0.0;
+    dy[3] = (-i_K - i_Na) / p[6];
+}
+
+// Glial membrane: Kir 4.1 + Na leak + Na/K pump, one state (reference: examples/emix-simulations/mm_glial.py:117-170).
+// parameters 0..15 as above, 16 K_e_init, 17 K_i_init, 18 E_Cl
+__device__ __forceinline__ void glial_rhs(double t, const double* y, double* p, double* dy) {
+    const double V = y[0];
+    const double a = 1 + p[13] / p[11], b = 1 + p[14] / p[12];
+    const double i_pump = p[15] / (a * a * b * b * b);
+    const double E_K_init = 8.314e3 * 300e3 / 96485e3 * log(p[16] / p[17]);
+    const double dphi = V - p[5];
+    const double A = 1 + exp(18.4 / 42.4);
+    const double B = 1 + exp(-(0.1186e3 + E_K_init) / 0.0441e3);
+    const double C = 1 + exp((dphi + 0.0185e3) / 0.0425e3);
+    const double D = 1 + exp(-(0.1186e3 + V) / 0.0441e3);
+    const double g_Kir = sqrt(p[11] / p[16]) * (A * B) / (C * D);
+    const double i_Kir = p[3] * g_Kir * (V - p[5]);
+    const double i_Na = p[2] * (V - p[4]) + 3 * i_pump;
+    const double i_K = i_Kir - 2 * i_pump;
+    p[8] = i_Na;
+    p[9] = i_K;
+    p[10] = 0.0;
+    dy[0] = (-i_K - i_Na) / p[6];
+}
+
 template <int MODEL> __device__ __forceinline__ void model_rhs(double t, const double* y, double* p, double* dy) {
     if (MODEL == 1) hh_rhs<true>(t, y, p, dy);
-    else hh_rhs<false>(t, y, p, dy);
+    else if (MODEL == 2) hh_rhs<false>(t, y, p, dy);
+    else if (MODEL == 3) hh_emix_rhs(t, y, p, dy);
+    else glial_rhs(t, y, p, dy);
 }
 
 template <int MODEL, int NS, int NP>
@@ -163,8 +212,9 @@ extern "C" {
 int knp_ode_create(knp_ctx* c, int model, int64_t n, const int32_t* facets, int ns, int np, const double* states,
                    const double* params) {
     if (!c) return -1;
-    if (model != 1 && model != 2) { c->err = "ode: unknown device model id"; return -1; }
-    if (ns != 4 || np != 17) { c->err = "ode: HH models have 4 states and 17 parameters"; return -1; }
+    if (model < 1 || model > 4) { c->err = "ode: unknown device model id"; return -1; }
+    if (model <= 3 && (ns != 4 || np != 17)) { c->err = "ode: HH models have 4 states and 17 parameters"; return -1; }
+    if (model == 4 && (ns != 1 || np != 19)) { c->err = "ode: the glial model has 1 state and 19 parameters"; return -1; }
     for (int64_t i = 0; i < n; ++i)
         if (facets[i] < 0 || facets[i] >= c->m.nf) { c->err = "ode: facet id out of range"; return -1; }
     OdeSet S;
@@ -223,8 +273,12 @@ int knp_ode_step(knp_ctx* c, int handle, double t0, double dt, double rtol, doub
     const int max_steps = 100000;
     if (S->model == 1)
         hipLaunchKernelGGL((k_ode_step<1, 4, 17>), g, b, 0, c->stream, S->n, t0, t0 + dt, rtol, atol, max_steps, S->states, S->params, S->h, S->fail);
-    else
+    else if (S->model == 2)
         hipLaunchKernelGGL((k_ode_step<2, 4, 17>), g, b, 0, c->stream, S->n, t0, t0 + dt, rtol, atol, max_steps, S->states, S->params, S->h, S->fail);
+    else if (S->model == 3)
+        hipLaunchKernelGGL((k_ode_step<3, 4, 17>), g, b, 0, c->stream, S->n, t0, t0 + dt, rtol, atol, max_steps, S->states, S->params, S->h, S->fail);
+    else
+        hipLaunchKernelGGL((k_ode_step<4, 1, 19>), g, b, 0, c->stream, S->n, t0, t0 + dt, rtol, atol, max_steps, S->states, S->params, S->h, S->fail);
     HIPCHK(c, hipGetLastError());
     int fail = 0;
     HIPCHK(c, hipMemcpyAsync(&fail, S->fail, sizeof(int), hipMemcpyDeviceToHost, c->stream));

@@ -343,3 +343,61 @@ def test_rccl_code_path_with_one_rank(hip_lib):
     b = json.loads([l for l in forced.stdout.splitlines() if l.startswith("{")][-1])
     assert a["config"]["emi_iters_per_step"] == b["config"]["emi_iters_per_step"]
     assert a["config"]["knp_iters_per_step"] == b["config"]["knp_iters_per_step"]
+
+
+@pytest.mark.parametrize("which", ["hh_emix", "glial"])
+def test_emix_device_ode_models_match_host(hip_lib, which):
+    """Device implementations of the EMIx membrane models (cm / ms / mV; reference: examples/emix-simulations/mm_hh.py,
+    mm_glial.py) against the host batch integrator running the vectorised Python right-hand sides."""
+    from knpemidg.mesh import make_mesh_2D
+    from knpemidg.functions import FacetSpace, FacetFunction
+    from knpemidg.membrane import MembraneModel
+    from knpemidg.models import mm_hh_emix, mm_glial
+    ode = mm_hh_emix if which == "hh_emix" else mm_glial
+    m, s, f = make_mesh_2D(1)
+    pb = ko.build_idealized(m, s.array(), f.array(), membrane_tags=(1,))
+    dev = device_for(pb)
+    Q = FacetSpace(m)
+    rng = np.random.default_rng(5)
+    K_e = 3.3 * (1 + 0.05 * rng.uniform(-1, 1, Q.dim()))
+    models = []
+    for on_dev in (False, True):
+        mm = MembraneModel(ode, facet_f=f, tag=1, V=Q)
+        mm.set_parameter_values({'Cm': lambda x: 2.0})
+        if on_dev:
+            assert mm.attach_device(dev)
+        for name, val in (('K_e', K_e), ('Na_i', np.full(Q.dim(), 12.8)), ('E_K', np.full(Q.dim(), -93.6)),
+                          ('E_Na', np.full(Q.dim(), 53.3))):
+            mm.set_parameter(name, FacetFunction(Q, val))
+        models.append(mm)
+    for k in range(5):
+        for mm in models:
+            mm.step_lsoda(dt=0.1, stimulus={'stim_amplitude': 5.0}, stimulus_locator=lambda x: x[0] < 20e-6)
+    sh, sd = models[0].states, models[1].states
+    ph, pd = models[0].parameters, models[1].parameters
+    assert np.abs(sh - sd).max() < 1e-8 * np.abs(sh).max()
+    assert np.abs(ph[:, 8:10] - pd[:, 8:10]).max() < 1e-7 * np.abs(ph[:, 8:10]).max()
+    dev.close()
+
+
+def test_baseline_config5_emix_mesh(hip_lib):
+    """BASELINE configs[4]: the reference's bundled EMIx reconstruction (121 617 tets, unstructured; read with
+    knpemidg.h5lite) with glial + neuronal membranes, three splitting steps on the general (coordinate-path) kernels:
+    the solves converge at the reference tolerances, the bulk stays electroneutral and the resting state persists away from
+    the stimulated region."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "emix_simulations"))
+    from emix_common import make_solver, solver_parameters, Constant
+    S = make_solver()
+    assert S.mesh.num_cells() == 121617 and S.mesh.num_vertices() == 22419
+    assert S.dev.n_geometry_classes == 0
+    assert all(mm['ode'].on_device for mm in S.mem_models)
+    t = Constant(0.0)
+    S.solve_system_active(0.3, t, solver_parameters(), filename=None, save_fields=False)
+    assert len(S.emi_niter) == 3 and max(S.emi_niter) < 100 and max(max(k) for k in S.knp_niter) < 100
+    c = S.c.array().reshape(2, -1)
+    na = S.ion_list[-1]['c'].array().ravel()
+    assert np.abs(c[0] - c[1] + na).max() < 1e-9 * np.abs(c[1]).max()          # z = +1, -1, +1 and rho = 0
+    phiM = S.phi_M_prev_PDE.array()
+    glial = S.mem_models[0]['ode'].indices
+    assert np.abs(phiM[glial] + 83.085).max() < 1.0                             # mV: glial rest potential
+    assert np.isfinite(S.phi.array()).all()
