@@ -152,3 +152,91 @@ def test_no_gpu_means_loud_failure():
     m, s, f = make_mesh_2D(0)
     with pytest.raises(_abi.KnpError):
         _abi.Device(m, s.array(), f.array(), [1], 3)
+
+
+def test_h5lite_reads_the_emix_mesh():
+    """The pure-Python HDF5 subset reader against the reference's bundled EMIx mesh (chunked + deflate datasets; sizes from its
+    XDMF descriptor: 22 419 vertices, 121 617 tets, labels 1..6)."""
+    import os
+    from knpemidg.h5lite import read_xdmf_mesh, H5File
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    d = os.path.join(root, "examples", "emix_simulations", "meshes", "emix_meshes", "volume_ncells_5_size_5000")
+    coords, cells, attrs = read_xdmf_mesh(os.path.join(d, "mesh.xdmf"))
+    assert coords.shape == (22419, 3) and coords.dtype == np.float64
+    assert cells.shape == (121617, 4) and cells.min() == 0 and cells.max() == 22418
+    lab = attrs["label"]
+    assert lab.shape == (121617,) and sorted(np.unique(lab)) == [1, 2, 3, 4, 5, 6]
+    x = coords[cells]
+    vol = np.abs(np.linalg.det(x[:, 1:] - x[:, :1])) / 6.0
+    assert vol.min() > 0 and 0.9 < vol.sum() / np.prod(coords.max(0) - coords.min(0)) <= 1.0
+    assert set(H5File(os.path.join(d, "mesh.h5")).datasets) == {"data0", "data1", "data2"}
+    with pytest.raises(KeyError):
+        H5File(os.path.join(d, "mesh.h5")).read("nope")
+
+
+def test_quadrature_rules_are_exact():
+    """Product quadrature (feeds the device tabulations): every rule integrates all monomials up to its degree exactly
+    (Dirichlet formula int lambda^alpha = d! alpha! / (|alpha| + d)!)."""
+    import itertools
+    from math import factorial
+    from knpemidg.quadrature import simplex_rule
+    for dim in (1, 2, 3):
+        for deg in range(1, 11):
+            bary, w = simplex_rule(dim, deg)
+            assert abs(w.sum() - 1.0) < 1e-13 and (bary.sum(axis=1) - 1 < 1e-13).all()
+            for alpha in itertools.product(range(deg + 1), repeat=dim + 1):
+                if sum(alpha) > deg:
+                    continue
+                exact = factorial(dim) * np.prod([factorial(a) for a in alpha]) / factorial(sum(alpha) + dim)
+                assert abs((w * np.prod(bary ** np.array(alpha), axis=1)).sum() - exact) < 1e-13, (dim, deg, alpha)
+
+
+def test_dg_tabulations():
+    """Tables uploaded by knp_set_tabulation: partition of unity, nodal property, facet tabulations live on the facet."""
+    from knpemidg import dgtab
+    for dim in (2, 3):
+        nd = (dim + 1) * (dim + 2) // 2
+        tabs = dgtab.tables(dim, 2)
+        assert sorted(tabs) == list(range(11))
+        for slot, (nloc, nq, w, B, dB) in tabs.items():
+            assert B.shape == (nloc, nq, nd) and dB.shape == (nloc, nq, nd, dim + 1) and abs(w.sum() - 1) < 1e-13
+            # sum_a phi_a = 1 on the simplex; its barycentric derivative is the same for every l (grad lambda_l sum to zero)
+            assert np.abs(B.sum(axis=2) - 1).max() < 1e-13 and np.ptp(dB.sum(axis=2), axis=-1).max() < 1e-12
+            if nloc > 1:
+                for i in range(nloc):           # vertex i's basis function and every edge function touching i vanish on facet i
+                    assert np.abs(B[i, :, i]).max() < 1e-14
+        nodes = np.concatenate([np.eye(dim + 1)] + [[0.5 * (np.eye(dim + 1)[a] + np.eye(dim + 1)[b])] for a, b in dgtab.edges(dim + 1)])
+        assert np.abs(dgtab.tabulate(2, nodes)[0] - np.eye(nd)).max() < 1e-14
+
+
+def test_conforming_p2_auxiliary_space_is_galerkin():
+    """The conforming-P2 operator assembled by knpemidg.amg equals P^T A P of the oracle's DG-P2 matrix (EMI with membrane
+    coupling; KNP mass + diffusion), and its P1 coarse level is the Galerkin product through the P1->P2 interpolation."""
+    import scipy.sparse as sp
+    from knpemidg import amg
+    from common import small_3d, synthetic_state
+    m, s, f = small_3d((6, 3, 3))
+    pb = ko.build_idealized(m, s.array(), f.array(), p=2, membrane_tags=(1,))
+    synthetic_state(pb)
+    cs = amg.ConformingSpace(m, f.array(), (1,))
+    c2 = amg.ConformingSpaceP2(cs)
+    P = sp.coo_matrix((np.ones(pb.ndof), (np.arange(pb.ndof), c2.dof.ravel())), shape=(pb.ndof, c2.n)).tocsr()
+    A, _, _ = ko.assemble_emi(pb, want_B=False)
+    Ac = c2.stiffness(pb.kappa(), membrane=(pb.mem, pb.C_phi))
+    ref = (P.T @ A @ P).tocsr()
+    assert abs(Ac - ref).max() < 1e-12 * abs(ref).max()
+    pb.phi[:] = 0.0
+    Ak = ko.assemble_knp(pb, 0)
+    Ack = c2.stiffness(pb.ions[0]["D"], mass_coef=np.full(m.num_cells(), 1.0 / pb.dt))
+    refk = (P.T @ Ak @ P).tocsr()
+    assert abs(Ack - refk).max() < 1e-12 * abs(refk).max()
+    H = amg.build_hierarchy(Ac, top_interp=c2.interp, max_coarse=40)
+    assert [lv.A.shape[0] for lv in H][:2] == [c2.n, cs.n]
+    assert abs(H[1].A - c2.interp.T @ Ac @ c2.interp).max() < 1e-12 * abs(H[1].A).max()
+    # P1 functions are reproduced: interpolating a linear field gives its values at the P2 nodes
+    lin = m.coords @ np.array([1.0, -2.0, 0.5])
+    v1 = np.zeros(cs.n); v1[cs.dof.ravel()] = lin[m.cells].ravel()
+    x = m.coords[m.cells]
+    mids = np.stack([0.5 * (x[:, a] + x[:, b]) for a, b in c2.edges], axis=1) @ np.array([1.0, -2.0, 0.5])
+    v2 = c2.interp @ v1
+    assert np.abs(v2[c2.dof[:, 4:]] - mids).max() < 1e-12 * np.abs(lin).max()
