@@ -213,6 +213,7 @@ def test_conforming_p2_auxiliary_space_is_galerkin():
     """The conforming-P2 operator assembled by knpemidg.amg equals P^T A P of the oracle's DG-P2 matrix (EMI with membrane
     coupling; KNP mass + diffusion), and its P1 coarse level is the Galerkin product through the P1->P2 interpolation."""
     import scipy.sparse as sp
+    import knpemi_oracle as ko
     from knpemidg import amg
     from common import small_3d, synthetic_state
     m, s, f = small_3d((6, 3, 3))
