@@ -170,7 +170,7 @@ def main():
             "config": {"workload": "3D idealized 4-axon mesh r=%d (%d tets, %d P%d-DG DoFs: phi + K,Cl solved, Na eliminated), "
                                    "HH membranes + stimulus, full splitting step" % (r, nc_global, dofs, args.degree),
                        "parallelism": "slab%d" % world,
-                       "preconditioner": "cell-block-Jacobi + conforming-P1 smoothed-aggregation AMG V-cycle" if S.use_amg
+                       "preconditioner": ("cell-block-Jacobi + conforming-P%d auxiliary space, smoothed-aggregation AMG V-cycle" % args.degree) if S.use_amg
                        else "cell-block-Jacobi",
                        "emi_iters_per_step": float(np.mean(S.emi_niter[-args.steps:])),
                        "knp_iters_per_step": float(np.mean([max(n) for n in S.knp_niter[-args.steps:]])),
