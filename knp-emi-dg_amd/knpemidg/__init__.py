@@ -10,7 +10,8 @@ from knpemidg.membrane import MembraneModel, get_indices, is_dlt_scalar, get_val
 from knpemidg.utils import (subdomain_marking_foo, interface_normal, plus, minus, pcws_constant_project,
                             CellCenterDistance)
 from knpemidg.solver import Solver
+from knpemidg.solver_emi import SolverEMI
 
-__all__ = ["Solver", "MembraneModel", "subdomain_marking_foo", "interface_normal", "plus", "minus",
+__all__ = ["Solver", "SolverEMI", "MembraneModel", "subdomain_marking_foo", "interface_normal", "plus", "minus",
            "pcws_constant_project", "CellCenterDistance", "Mesh", "MeshFunction", "Constant", "RectangleMesh", "BoxMesh",
            "make_mesh_2D", "make_mesh_3D", "make_mesh_MMS"]

@@ -401,3 +401,41 @@ def test_baseline_config5_emix_mesh(hip_lib):
     glial = S.mem_models[0]['ode'].indices
     assert np.abs(phiM[glial] + 83.085).max() < 1.0                             # mV: glial rest potential
     assert np.isfinite(S.phi.array()).all()
+
+
+def test_solver_emi_variant(hip_lib):
+    """`SolverEMI` (reference: src/knpemidg/solver_emi.py): potential-only stepping with frozen concentrations, HH membrane
+    ODEs in the loop; every step's phi and phi_M against the oracle's EMI solve fed with the same ODE outputs."""
+    from common_examples import physical_setup, solver_parameters, Constant
+    from knpemidg import SolverEMI
+    from knpemidg.mesh import make_mesh_2D
+    from knpemidg.models import mm_hh
+    mesh, sub, surf = make_mesh_2D(0)
+    params, ion_list, stim = physical_setup(1.0e-4)
+    S = SolverEMI(params, ion_list)
+    S.verbose = False
+    S.setup_domain(mesh, sub, surf)
+    S.setup_parameters()
+    S.setup_FEM_spaces()
+    S.setup_membrane_model(stim, {1: mm_hh})
+    sp = solver_parameters(2, 0)._replace(rtol_emi=1e-11)
+    S._unpack_solver_params(sp)
+    S.splitting_scheme = True
+    S.save_fields = S.save_solver_stats = False
+    S.setup_varform_emi(); S.setup_solver_emi()
+    pb = ko.build_idealized(mesh, sub.array(), surf.array(), membrane_tags=(1,))
+    c0 = S.c.array().copy()
+    t = Constant(0.0)
+    for k in range(3):
+        S.step_membrane_models(k)
+        pb.phi_M = S.phi_M_prev_PDE.array().copy()
+        for ion in pb.ions:
+            pb.I_ch[ion["name"]] = S.mem_models[0]['I_ch_k'][ion["name"]].array().copy()
+        S.solve_for_time_step(k, t)
+        ko.solve_emi(pb, direct=True)
+        ko.update_phi_M(pb)
+        vol = pb.geom.vol
+        assert relerr(mean_free(S.phi.array(), vol), mean_free(pb.phi, vol)) < 1e-6
+        assert relerr(S.phi_M_prev_PDE.array()[pb.mem], pb.phi_M[pb.mem]) < 1e-6
+    assert np.array_equal(S.c.array(), c0)                       # concentrations frozen
+    assert abs(float(t) - 3e-4) < 1e-12
