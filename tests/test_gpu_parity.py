@@ -153,16 +153,16 @@ def test_gpu_matches_golden(hip_lib, name):
     dev.close()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_partitioned_kernels_on_one_gpu(hip_lib, world):
+@pytest.mark.parametrize("world,p", [(2, 1), (3, 1), (2, 2)])
+def test_partitioned_kernels_on_one_gpu(hip_lib, world, p):
     """Owned+ghost sub-meshes on the device: every rank's context (all living on this one GPU, ghosts filled
     from the global arrays = what the RCCL halo exchange delivers) must reproduce the owned rows of the
     global oracle results.  Exercises nc_owned < nc in every kernel; RCCL itself needs >= 2 GPUs."""
     from knpemidg import _abi as A
     from knpemidg.partition import Partition
     from common import small_3d
-    m, s, f = small_3d((12, 4, 4))
-    pbg = ko.build_idealized(m, s.array(), f.array(), membrane_tags=(1,))
+    m, s, f = small_3d((12, 4, 4) if p == 1 else (8, 3, 3))
+    pbg = ko.build_idealized(m, s.array(), f.array(), p=p, membrane_tags=(1,))
     x = synthetic_state(pbg)
     Ag, bg, _ = ko.assemble_emi(pbg, want_B=False)
     yg = (Ag @ x[0].ravel()).reshape(-1, pbg.nd)
@@ -176,7 +176,7 @@ def test_partitioned_kernels_on_one_gpu(hip_lib, world):
     for rank in range(world):
         loc = part.local(rank)
         sub_l, surf_l = loc.localize(s, f, (1,))
-        pbl = ko.build_idealized(loc.mesh, sub_l.array(), surf_l.array(), membrane_tags=(1,))
+        pbl = ko.build_idealized(loc.mesh, sub_l.array(), surf_l.array(), p=p, membrane_tags=(1,))
         cg, no = loc.cells_global, loc.nc_owned
         pbl.c, pbl.c_prev_n, pbl.c_elim, pbl.phi = pbg.c[:, cg], pbg.c_prev_n[:, cg], pbg.c_elim[cg], pbg.phi[cg]
         pbl.phi_M = pbg.phi_M[loc.facets_global]
