@@ -264,9 +264,10 @@ int amg_vcycle(knp_ctx* c, AmgHierarchy& H, hipStream_t on_stream) {
     return amg_vcycle_eager(c, H);      // eager fallback always runs on the context's stream
 }
 
-int amg_restrict_from_dg(knp_ctx* c, AmgHierarchy& H, const double* r_dg) {
-    hipLaunchKernelGGL(k_dg_restrict, dim3((unsigned)((H.ncg * 8 + 255) / 256)), dim3(256), 0, c->stream, H.ncg, H.cg_ptr, H.cg_idx,
-                       r_dg, H.levels[0].b);
+int amg_restrict_from_dg(knp_ctx* c, AmgHierarchy& H, const double* r_dg, hipStream_t on_stream) {
+    if (on_stream && c->dist) { c->err = "amg: the all-reduced restriction runs on the context's stream"; return -1; }
+    hipLaunchKernelGGL(k_dg_restrict, dim3((unsigned)((H.ncg * 8 + 255) / 256)), dim3(256), 0, on_stream ? on_stream : c->stream,
+                       H.ncg, H.cg_ptr, H.cg_idx, r_dg, H.levels[0].b);
     // multi-GPU: the conforming hierarchy is replicated on every rank; the restricted residual is the sum of the
     // ranks' owned-cell contributions (one all-reduce of ncg doubles), after which every rank runs the same V-cycle
     if (c->dist) return allreduce_red(c, H.levels[0].b, (int)H.ncg);

@@ -33,5 +33,5 @@ struct AmgHierarchy {
 
 struct knp_ctx;
 int amg_vcycle(knp_ctx* c, AmgHierarchy& H, hipStream_t on_stream = nullptr);
-int amg_restrict_from_dg(knp_ctx* c, AmgHierarchy& H, const double* r_dg);
+int amg_restrict_from_dg(knp_ctx* c, AmgHierarchy& H, const double* r_dg, hipStream_t on_stream = nullptr);
 void amg_free(AmgHierarchy& H);

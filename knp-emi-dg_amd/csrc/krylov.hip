@@ -602,11 +602,17 @@ static int knp_coarse_correction(knp_ctx* c, const VecDims& d, const double* in,
         if ((int)c->amg.size() > 1 + s && c->amg[1 + s].ready) active[na++] = s;
     if (!na) return 0;
     int rc;
-    for (int i = 0; i < na; ++i) {
-        const int s = active[i];
-        if ((rc = amg_restrict_from_dg(c, c->amg[1 + s], in + (int64_t)s * d.nc * NV))) return rc;
-    }
+    // every species is an independent chain  restrict -> V-cycle -> prolong  of short latency-bound kernels writing
+    // disjoint slices: species 0 runs on the context's stream, every further species on its own auxiliary stream
+    // (fork / join with events).  With a communicator the restriction ends in an all-reduce on the context's stream, so
+    // only the V-cycles fork.
     const bool fork = na > 1 && c->amg[1 + active[0]].graph_tried && c->amg[1 + active[0]].graph_exec;
+    const bool fork_all = fork && !c->dist;
+    if (!fork_all)
+        for (int i = 0; i < na; ++i) {
+            const int s = active[i];
+            if ((rc = amg_restrict_from_dg(c, c->amg[1 + s], in + (int64_t)s * d.nc * NV))) return rc;
+        }
     if (fork) {
         while ((int)c->aux_streams.size() < na - 1) {
             hipStream_t st; hipEvent_t ev;
@@ -618,23 +624,29 @@ static int knp_coarse_correction(knp_ctx* c, const VecDims& d, const double* in,
         if (!c->fork_event) HIPCHK(c, hipEventCreateWithFlags(&c->fork_event, hipEventDisableTiming));
         HIPCHK(c, hipEventRecord(c->fork_event, c->stream));
     }
-    for (int i = 0; i < na; ++i) {
-        AmgHierarchy& H = c->amg[1 + active[i]];
+    // aux streams first, so that their chains are already running while the host enqueues species 0
+    for (int i = na - 1; i >= 0; --i) {
+        const int s = active[i];
+        AmgHierarchy& H = c->amg[1 + s];
         hipStream_t st = nullptr;
         if (fork && i > 0 && H.graph_exec) {
             st = c->aux_streams[i - 1];
             HIPCHK(c, hipStreamWaitEvent(st, c->fork_event, 0));
         }
+        if (fork_all && (rc = amg_restrict_from_dg(c, H, in + (int64_t)s * d.nc * NV, st))) return rc;
         if ((rc = amg_vcycle(c, H, st))) return rc;
-        if (st) {
-            HIPCHK(c, hipEventRecord(c->aux_events[i - 1], st));
-            HIPCHK(c, hipStreamWaitEvent(c->stream, c->aux_events[i - 1], 0));
-        }
+        if (fork_all || !st)
+            hipLaunchKernelGGL(k_prolong_add<NV>, g1, b, 0, st ? st : c->stream, d, c->status, s, H.dg2cg, H.levels[0].x,
+                               out + (int64_t)s * d.nc * NV);
+        if (st) HIPCHK(c, hipEventRecord(c->aux_events[i - 1], st));
     }
-    for (int i = 0; i < na; ++i) {
-        const int s = active[i];
-        AmgHierarchy& H = c->amg[1 + s];
-        hipLaunchKernelGGL(k_prolong_add<NV>, g1, b, 0, c->stream, d, c->status, s, H.dg2cg, H.levels[0].x, out + (int64_t)s * d.nc * NV);
+    for (int i = 1; i < na; ++i) {
+        AmgHierarchy& H = c->amg[1 + active[i]];
+        if (!(fork && H.graph_exec)) continue;
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->aux_events[i - 1], 0));
+        if (!fork_all)
+            hipLaunchKernelGGL(k_prolong_add<NV>, g1, b, 0, c->stream, d, c->status, active[i], H.dg2cg, H.levels[0].x,
+                               out + (int64_t)active[i] * d.nc * NV);
     }
     return 0;
 }
