@@ -48,7 +48,9 @@ def run(resolution, degree=1, dt=1.0e-10, nsteps=2, verbose=False):
     uh, uh_cc = S.solve_system_passive(dt * nsteps, t, sp, None)
     fields = {'a': uh[0].array(), 'b': uh[1].array(), 'c': uh_cc.array(), 'phi': uh[2].array()}
     # L2 errors, degree-5 quadrature, phi mean-corrected (run_MMS_space.py:227-260)
+    from knpemidg.dgtab import tabulate
     bary, w = simplex_rule(2, 5)
+    Bq = tabulate(degree, bary)[0]
     x = mesh.coords[mesh.cells]
     X = np.einsum("ql,cld->cqd", bary, x)
     J = (x[:, 1:, :] - x[:, :1, :]).transpose(0, 2, 1)
@@ -57,10 +59,10 @@ def run(resolution, degree=1, dt=1.0e-10, nsteps=2, verbose=False):
     err = {}
     for s in "abc":
         ex = np.where(ics, sol['c_%s1' % s](X), sol['c_%s2' % s](X))
-        e = ex - np.einsum("ql,cl->cq", bary, fields[s])
+        e = ex - np.einsum("ql,cl->cq", Bq, fields[s])
         err[s] = float(np.sqrt((wq * e * e).sum()))
     ex = np.where(ics, sol['phi_1'](X), sol['phi_2'](X))
-    uhq = np.einsum("ql,cl->cq", bary, fields['phi'])
+    uhq = np.einsum("ql,cl->cq", Bq, fields['phi'])
     e = ex - (wq * (ex - uhq)).sum() - uhq
     err['phi'] = float(np.sqrt((wq * e * e).sum()))
     S.dev.close()
@@ -72,7 +74,7 @@ if __name__ == '__main__':
     rmax = int(next((a.split("=")[1] for a in sys.argv if a.startswith("--rmax=")), 6))
     prev, rates = None, {}
     for r in range(2, rmax + 1):
-        e = run(r)
+        e = run(r, degree=int(next((a.split("=")[1] for a in sys.argv if a.startswith("--degree=")), 1)))
         if prev is not None:
             rates = {k: np.log(prev[k] / e[k]) / np.log(2) for k in e}
         print("r=%d  " % r + "  ".join("|%s-%sh|_0 = %.4E [%s]" % (k, k, v, ("%.2f" % rates[k]) if rates else "nan")

@@ -170,19 +170,19 @@ __global__ __launch_bounds__(256) void k_dense_mv(int n, const float* __restrict
 }
 
 // rc[v] = sum over the DG dofs mapped to conforming dof v (CSR list, fixed order -> deterministic)
+// G lanes per conforming dof (a vertex is shared by ~24 tets); fixed summation tree -> deterministic
+template <int G>
 __global__ __launch_bounds__(256) void k_dg_restrict(int64_t ncg, const int32_t* __restrict__ ptr, const int32_t* __restrict__ idx,
                                                      const double* __restrict__ r, double* __restrict__ rc) {
-    // 8 lanes per conforming dof (a vertex is shared by ~24 tets); fixed summation tree -> deterministic
-    const int64_t v = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 3;
-    const int lane = threadIdx.x & 7;
+    const int64_t v = ((int64_t)blockIdx.x * 256 + threadIdx.x) / G;
+    const int lane = threadIdx.x % G;
     double s = 0.0;
     if (v < ncg) {
         const int e = ptr[v + 1];
-        for (int k = ptr[v] + lane; k < e; k += 8) s += r[idx[k]];
+        for (int k = ptr[v] + lane; k < e; k += G) s += r[idx[k]];
     }
-    s += __shfl_down(s, 4, 8);
-    s += __shfl_down(s, 2, 8);
-    s += __shfl_down(s, 1, 8);
+#pragma unroll
+    for (int off = G / 2; off > 0; off >>= 1) s += __shfl_down(s, off, G);
     if (v < ncg && lane == 0) rc[v] = s;
 }
 
@@ -266,8 +266,16 @@ int amg_vcycle(knp_ctx* c, AmgHierarchy& H, hipStream_t on_stream) {
 
 int amg_restrict_from_dg(knp_ctx* c, AmgHierarchy& H, const double* r_dg, hipStream_t on_stream) {
     if (on_stream && c->dist) { c->err = "amg: the all-reduced restriction runs on the context's stream"; return -1; }
-    hipLaunchKernelGGL(k_dg_restrict, dim3((unsigned)((H.ncg * 8 + 255) / 256)), dim3(256), 0, on_stream ? on_stream : c->stream,
-                       H.ncg, H.cg_ptr, H.cg_idx, r_dg, H.levels[0].b);
+    static const int lanes = getenv("KNP_RESTRICT_LANES") ? atoi(getenv("KNP_RESTRICT_LANES")) : 8;
+    hipStream_t st = on_stream ? on_stream : c->stream;
+    if (lanes == 32)
+        hipLaunchKernelGGL(k_dg_restrict<32>, dim3((unsigned)((H.ncg * 32 + 255) / 256)), dim3(256), 0, st, H.ncg, H.cg_ptr, H.cg_idx, r_dg, H.levels[0].b);
+    else if (lanes == 16)
+        hipLaunchKernelGGL(k_dg_restrict<16>, dim3((unsigned)((H.ncg * 16 + 255) / 256)), dim3(256), 0, st, H.ncg, H.cg_ptr, H.cg_idx, r_dg, H.levels[0].b);
+    else if (lanes == 4)
+        hipLaunchKernelGGL(k_dg_restrict<4>, dim3((unsigned)((H.ncg * 4 + 255) / 256)), dim3(256), 0, st, H.ncg, H.cg_ptr, H.cg_idx, r_dg, H.levels[0].b);
+    else
+        hipLaunchKernelGGL(k_dg_restrict<8>, dim3((unsigned)((H.ncg * 8 + 255) / 256)), dim3(256), 0, st, H.ncg, H.cg_ptr, H.cg_idx, r_dg, H.levels[0].b);
     // multi-GPU: the conforming hierarchy is replicated on every rank; the restricted residual is the sum of the
     // ranks' owned-cell contributions (one all-reduce of ncg doubles), after which every rank runs the same V-cycle
     if (c->dist) return allreduce_red(c, H.levels[0].b, (int)H.ncg);

@@ -385,7 +385,8 @@ template <int D, int ND>
 __global__ __launch_bounds__(128) void k_tab_emi_rhs(MeshDev m, TabRule rc, TabRule rf, TabRule rm, const double* __restrict__ cc,
                                                      const double* __restrict__ celim, const double* __restrict__ Dk,
                                                      const double* __restrict__ phiM, const double* __restrict__ Ich, IonZ ia,
-                                                     double F, double C_phi, int splitting, double* __restrict__ out) {
+                                                     double F, double C_phi, int splitting, const double* __restrict__ extra,
+                                                     double* __restrict__ out) {
     constexpr int NV = D + 1;
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= m.nc_owned * ND) return;
@@ -454,7 +455,7 @@ __global__ __launch_bounds__(128) void k_tab_emi_rhs(MeshDev m, TabRule rc, TabR
                 }
                 acc += rf.w[q] * area * 0.5 * flux * Bi[a];
             }
-        } else if (kind == FK_MEMBRANE) {
+        } else if (kind == FK_MEMBRANE && splitting != 2) {    // MMS: Robin data arrives as host-integrated extra RHS
             const int64_t f = m.cfacet[c * NV + i];
             double g = phiM[f];
             if (!splitting) {
@@ -469,13 +470,14 @@ __global__ __launch_bounds__(128) void k_tab_emi_rhs(MeshDev m, TabRule rc, TabR
             acc += sgn * C_phi * g * area * sB;
         }
     }
+    if (extra) acc += extra[t];
     out[t] = acc;
 }
 
 // ------------------------------------------------------------------------------------------------------------
 // L_knp of species s = blockIdx.y
 // ------------------------------------------------------------------------------------------------------------
-struct KnpRhsTab { double F, C_M, dt; int splitting; };
+struct KnpRhsTab { double F, C_M, dt; int splitting; const double* mms_C; const double* extra; };
 
 template <int D, int ND>
 __global__ __launch_bounds__(128) void k_tab_knp_rhs(MeshDev m, TabRule rc, TabRule rm, const double* __restrict__ cc,
@@ -527,6 +529,22 @@ __global__ __launch_bounds__(128) void k_tab_knp_rhs(MeshDev m, TabRule rc, TabR
 #pragma unroll
             for (int b = 0; b < ND; ++b) as[b] = fma(fz, src[c * ND + b], as[b]);
         }
+        if (ra.splitting == 2) {
+            // MMS (solver.py:649-650): -(phi_i - phi_e)(C_i v_i - C_e v_e) with the DG0 coupling coefficient C
+            const double Cown = ra.mms_C[(int64_t)s * m.nc + c];
+            const double area = (double)D * K.vol * sqrt(dotD<D>(K.g[i], K.g[i]));
+            const double sgn = is_e ? -1.0 : 1.0;
+            for (int q = 0; q < rm.nq; ++q) {
+                const double* Bi = rm.B + ((int64_t)i * rm.nq + q) * ND;
+                const double* Bj = rm.B + ((int64_t)j * rm.nq + q) * ND;
+                double pq = 0.0, pq2 = 0.0;
+#pragma unroll
+                for (int b = 0; b < ND; ++b) { pq = fma(Bi[b], po[b], pq); pq2 = fma(Bj[b], pn[b], pq2); }
+                const double jump = is_e ? (pq2 - pq) : (pq - pq2);
+                acc -= rm.w[q] * area * sgn * Cown * jump * Bi[a];
+            }
+            continue;
+        }
         const double I_k = Ich[(int64_t)s * m.nf + f];
         double I_tot = 0.0;
         for (int k = 0; k < ia.n; ++k) I_tot += Ich[(int64_t)k * m.nf + f];
@@ -552,6 +570,7 @@ __global__ __launch_bounds__(128) void k_tab_knp_rhs(MeshDev m, TabRule rc, TabR
             acc += rm.w[q] * area * sgn * C * (g - jump) * Bi[a];
         }
     }
+    if (ra.extra) acc += ra.extra[(int64_t)s * m.nc * ND + t];
     out_all[(int64_t)s * m.nc * ND + t] = acc;
 }
 
@@ -686,19 +705,17 @@ int tab_block_inverse(knp_ctx* c, int which, double* binv) {
 }
 
 int tab_emi_rhs(knp_ctx* c, const double* cc, const double* celim, const double* phiM, const double* Ich, double* b) {
-    if (c->p.splitting == 2) { c->err = "DG-p path: manufactured-solution mode is implemented for degree 1 only"; return -1; }
     if (need_tabs(c, {KNP_TAB_CELL_RHS_EMI, KNP_TAB_FACET_RHS_EMI, KNP_TAB_FACET_MEM_LIN})) return -1;
     TAB_DISPATCH(c, k_tab_emi_rhs, rows_grid(c, 128), dim3(128), c->m, c->tab[KNP_TAB_CELL_RHS_EMI], c->tab[KNP_TAB_FACET_RHS_EMI],
                  c->tab[KNP_TAB_FACET_MEM_LIN], cc, celim, (const double*)c->D, phiM, Ich, ion_z(c), c->p.F, c->p.C_phi,
-                 c->p.splitting, b);
+                 c->p.splitting, (const double*)c->extra_emi, b);
     return 0;
 }
 
 int tab_knp_rhs(knp_ctx* c, const double* cc, const double* cprev, const double* celim, const double* phi, const double* phiM,
                 const double* Ich, double* b) {
-    if (c->p.splitting == 2) { c->err = "DG-p path: manufactured-solution mode is implemented for degree 1 only"; return -1; }
     if (need_tabs(c, {KNP_TAB_CELL_MASS, KNP_TAB_FACET_MEM_KNP})) return -1;
-    KnpRhsTab ra{c->p.F, c->p.C_M, c->p.dt, c->p.splitting};
+    KnpRhsTab ra{c->p.F, c->p.C_M, c->p.dt, c->p.splitting, (const double*)c->mms_C, (const double*)c->extra_knp};
     TAB_DISPATCH(c, k_tab_knp_rhs, rows_grid(c, 128, c->p.n_sys), dim3(128), c->m, c->tab[KNP_TAB_CELL_MASS],
                  c->tab[KNP_TAB_FACET_MEM_KNP], cc, cprev, celim, phi, (const double*)c->D, phiM, Ich, (const double*)c->fsrc,
                  ion_z(c), ra, b);

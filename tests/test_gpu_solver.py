@@ -232,6 +232,24 @@ def test_mms_space_convergence_on_device(hip_lib):
         assert abs(errs[-1][key] - ref[key]) < 2e-3 * ref[key], (key, errs[-1][key], ref[key])
 
 
+def test_mms_space_convergence_p2_on_device(hip_lib):
+    """The same manufactured solution with `Solver(degree_emi=2, degree_knp=2)` (the reference reaches P2 exactly this
+    way, tests/run_MMS_space.py:194-195): L2 order 3 on the assembled-block P2 path, and the same errors as the oracle."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "mms"))
+    import run_MMS_space as R
+    errs = [R.run(r, degree=2) for r in (2, 3, 4)]
+    for key in ("a", "b", "c", "phi"):
+        rate = np.log(errs[-2][key] / errs[-1][key]) / np.log(2)
+        assert rate > 2.8, (key, rate, errs)
+    import mms as omms
+    pb = omms.build_space_mms(4, p=2)
+    for _ in range(2):
+        ko.solve_for_time_step(pb, direct=True)
+    ref = omms.l2_errors(pb)
+    for key in ("a", "b", "c", "phi"):
+        assert abs(errs[-1][key] - ref[key]) < 1e-2 * ref[key], (key, errs[-1][key], ref[key])
+
+
 def test_picard_variant(hip_lib):
     """solve_for_time_step_picard (solver.py:850-927): converges in a few Picard levels and lands close to the plain
     splitting step for a small time step (both are consistent discretisations of the same coupled step)."""
