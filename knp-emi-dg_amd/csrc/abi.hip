@@ -2,6 +2,7 @@
 // interfaces each entry point replaces).
 #include "../../include/knpemi_hip.h"
 #include "knpemi_internal.hpp"
+#include <cstdlib>
 #include "krylov.hpp"
 #include <cstring>
 #include <algorithm>
@@ -15,7 +16,33 @@ struct Fields {
     // solver workspace
     double *binv_emi = nullptr, *binv_knp = nullptr;
     double *r = nullptr, *z = nullptr, *p = nullptr, *w = nullptr, *rhat = nullptr, *v = nullptr, *y = nullptr;
+    // previous converged solutions, for the extrapolated initial guess x0 = 2 x_{k-1} - x_{k-2}
+    double *hist_emi = nullptr, *hist_knp = nullptr;
+    bool have_hist_emi = false, have_hist_knp = false;
 };
+
+// x <- 2 x - h ; h <- x (old)      [first == 1: only h <- x]
+__global__ void k_extrapolate_guess(int64_t n, int first, double* __restrict__ x, double* __restrict__ h) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double xv = x[i];
+    if (!first) x[i] = 2.0 * xv - h[i];
+    h[i] = xv;
+}
+
+// The reference starts every Krylov solve from the previous time step's solution (KSP initial guess non-zero,
+// solver.py:444, 701) and so does this path by default.  KNP_EXTRAPOLATE=1 starts from a linear extrapolation of the
+// last two solutions instead: measured at r=2 it saves ~30 % of the EMI iterations in smooth phases but costs extra
+// iterations right after the stimulus onset and for the concentrations (net +-3 %), hence opt-in.
+static int extrapolate_guess(knp_ctx* c, double* x, double** hist, bool* have, int64_t n) {
+    static const bool on = getenv("KNP_EXTRAPOLATE") && atoi(getenv("KNP_EXTRAPOLATE")) == 1;
+    if (!on || c->p.splitting == 2) return 0;
+    if (!*hist) HIPCHK(c, hipMalloc((void**)hist, sizeof(double) * n));
+    hipLaunchKernelGGL(k_extrapolate_guess, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, n, *have ? 0 : 1, x, *hist);
+    HIPCHK(c, hipGetLastError());
+    *have = true;
+    return 0;
+}
 
 std::map<knp_ctx*, Fields*> g_fields;
 thread_local std::string g_err;
@@ -202,7 +229,7 @@ void knp_ctx_destroy(knp_ctx* c) {
     Fields* fl = g_fields[c];
     if (fl) {
         for (int i = 0; i < KNP_F_COUNT; ++i) hipFree(fl->f[i]);
-        double* wk[] = {fl->binv_emi, fl->binv_knp, fl->r, fl->z, fl->p, fl->w, fl->rhat, fl->v, fl->y};
+        double* wk[] = {fl->binv_emi, fl->binv_knp, fl->r, fl->z, fl->p, fl->w, fl->rhat, fl->v, fl->y, fl->hist_emi, fl->hist_knp};
         for (auto p : wk) hipFree(p);
         delete fl;
         g_fields.erase(c);
@@ -364,6 +391,7 @@ int knp_emi_solve(knp_ctx* c, double rtol, double atol, int maxit, int check_eve
     Fields* f = F(c);
     int rc = launch_emi_blockjacobi(c, f->f[KNP_F_KAPPA], f->binv_emi);
     if (rc) return rc;
+    if ((rc = extrapolate_guess(c, f->f[KNP_F_PHI], &f->hist_emi, &f->have_hist_emi, f->n[KNP_F_PHI]))) return rc;
     KrylovVecs kv{};
     kv.x = f->f[KNP_F_PHI]; kv.b = f->f[KNP_F_B_EMI]; kv.coef = f->f[KNP_F_KAPPA]; kv.binv = f->binv_emi;
     kv.r = f->r; kv.z = f->z; kv.p = f->p; kv.w = f->w; kv.rhat = f->rhat; kv.v = f->v; kv.y = f->y;
@@ -378,6 +406,7 @@ int knp_knp_solve(knp_ctx* c, double rtol, double atol, int maxit, int min_it, i
     Fields* f = F(c);
     int rc = launch_knp_blockjacobi(c, f->f[KNP_F_DNPHI], f->binv_knp);
     if (rc) return rc;
+    if ((rc = extrapolate_guess(c, f->f[KNP_F_C], &f->hist_knp, &f->have_hist_knp, f->n[KNP_F_C]))) return rc;
     KrylovVecs kv{};
     kv.x = f->f[KNP_F_C]; kv.b = f->f[KNP_F_B_KNP]; kv.coef = f->f[KNP_F_DNPHI]; kv.binv = f->binv_knp;
     kv.r = f->r; kv.z = f->z; kv.p = f->p; kv.w = f->w; kv.rhat = f->rhat; kv.v = f->v; kv.y = f->y;
