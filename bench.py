@@ -102,7 +102,7 @@ def main():
     r = args.resolution
     if world > 1 or force_dist:
         from knpemidg.partition import make_distributed_solver
-        S = make_distributed_solver(dim=3, resolution=r, rank=rank, world=world, local_rank=local_rank, dist=dist)
+        S = make_distributed_solver(dim=3, resolution=r, rank=rank, world=world, local_rank=local_rank, dist=dist, degree=args.degree)
     else:
         S = make_solver(dim=3, resolution=r, verbose=False, degree=args.degree)
     sp = solver_parameters(3, r)
