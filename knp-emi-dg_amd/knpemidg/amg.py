@@ -255,6 +255,8 @@ def build_hierarchy(A, theta=0.08, max_coarse=4000, max_levels=12, cheb_degree=2
         lv.dinv = 1.0 / d
         lv.rho = _spectral_radius_DinvA(A, lv.dinv)
         lv.cheb_degree, lv.cheb_lower = cheb_degree, cheb_lower
+        if levels and "KNP_AMG_COARSE_DEGREE" in os.environ:          # experiment knob: smoother degree below level 0
+            lv.cheb_degree = int(os.environ["KNP_AMG_COARSE_DEGREE"])
         levels.append(lv)
         n = A.shape[0]
         if top_interp is not None and len(levels) == 1:
