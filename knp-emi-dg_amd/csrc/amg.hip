@@ -222,6 +222,10 @@ static int amg_vcycle_eager(knp_ctx* c, AmgHierarchy& H) {
     const int nl = (int)H.levels.size();
     for (int l = 0; l < nl - 1; ++l) {
         AmgLevel& L = H.levels[l];
+        if (L.cheb_degree == 0) {                                    // transfer-only level: x = 0, r = b
+            launch_csr<0>(c, L.R, L.b, nullptr, H.levels[l + 1].b);
+            continue;
+        }
         smooth(c, L, true);
         launch_csr<1>(c, L.A, L.x, L.b, L.r);                        // r = b - A x
         launch_csr<0>(c, L.R, L.r, nullptr, H.levels[l + 1].b);      // b_{l+1} = R r
@@ -230,6 +234,10 @@ static int amg_vcycle_eager(knp_ctx* c, AmgHierarchy& H) {
     hipLaunchKernelGGL(k_dense_mv, dim3((unsigned)C.n), dim3(256), 0, c->stream, (int)C.n, (const float*)H.pinv, C.b, C.x);
     for (int l = nl - 2; l >= 0; --l) {
         AmgLevel& L = H.levels[l];
+        if (L.cheb_degree == 0) {
+            launch_csr<0>(c, L.P, H.levels[l + 1].x, nullptr, L.x);  // x = P x_{l+1}
+            continue;
+        }
         launch_csr<2>(c, L.P, H.levels[l + 1].x, nullptr, L.x);      // x += P x_{l+1}
         smooth(c, L, false);
     }

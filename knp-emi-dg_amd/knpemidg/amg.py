@@ -234,7 +234,7 @@ class Level:
 
 
 def build_hierarchy(A, theta=0.08, max_coarse=4000, max_levels=12, cheb_degree=2, cheb_lower=0.3, psmooth=2, trunc=0.04,
-                    top_interp=None, top_degree=3, top_lower=0.1):
+                    top_interp=None, top_degree=3, top_lower=0.1, level0_degree=None):
     """Smoothed-aggregation hierarchy for an SPD (possibly singular, constants) matrix.
     Each level: A (csr), dinv, rho = spectral radius estimate of D^-1 A, P (csr, to the next level).
     Last level: dense pseudo-inverse.  top_interp: geometric prolongator of the first level (conforming P1 -> P2,
@@ -257,6 +257,10 @@ def build_hierarchy(A, theta=0.08, max_coarse=4000, max_levels=12, cheb_degree=2
         lv.cheb_degree, lv.cheb_lower = cheb_degree, cheb_lower
         if levels and "KNP_AMG_COARSE_DEGREE" in os.environ:          # experiment knob: smoother degree below level 0
             lv.cheb_degree = int(os.environ["KNP_AMG_COARSE_DEGREE"])
+        if not levels and top_interp is None and level0_degree is not None:
+            # finest conforming-P1 level: the DG block-Jacobi part of the preconditioner already damps what a smoother on
+            # this level would; 0 = transfer-only level (x = P x_coarse), 1 = one damped-Jacobi step before / after
+            lv.cheb_degree = int(os.environ.get("KNP_AMG_DEGREE0", level0_degree))
         levels.append(lv)
         n = A.shape[0]
         if top_interp is not None and len(levels) == 1:

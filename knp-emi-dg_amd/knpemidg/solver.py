@@ -286,7 +286,9 @@ class Solver:
         mem = np.nonzero((gmesh.facet_cells[:, 1] >= 0) & np.isin(ft, self.membrane_tags))[0]
         if self.degree_knp == 1:
             Ac = self._cspace.stiffness(kappa, membrane=(mem, _f(self.C_phi)))
-            levels = amg.build_hierarchy(Ac, psmooth=2)      # EMI: 68 -> 22 PCG iterations at r=2 vs one smoothing step
+            # EMI: double-smoothed prolongators (68 -> 22 PCG iterations at r=2); no smoother on the finest conforming level
+            # (same 17 iterations with or without it: block-Jacobi on the DG space already does that job)
+            levels = amg.build_hierarchy(Ac, psmooth=2, level0_degree=int(os.environ.get("KNP_AMG_DEGREE0_EMI", 0)))
         else:
             # DG-P2: auxiliary space = conforming P2 (block-Jacobi over-weights continuous quadratics by the penalty
             # factor); the conforming P1 space is its first coarse level, aggregation starts below
@@ -336,7 +338,8 @@ class Solver:
         for k, ion in enumerate(self.ion_list[:-1]):
             if self.degree_knp == 1:
                 Ac = self._cspace.stiffness(self._by_tag(ion['D_sub'], gsub), mass_coef=np.full(nc, 1.0 / _f(self.dt)))
-                levels = amg.build_hierarchy(Ac, psmooth=2)  # 10 -> 8 BiCGStab iterations once P is truncated
+                # 10 -> 8 BiCGStab iterations once P is truncated; one Jacobi step on the finest level is enough
+                levels = amg.build_hierarchy(Ac, psmooth=2, level0_degree=int(os.environ.get("KNP_AMG_DEGREE0_KNP", 1)))
             else:
                 Ac = self._cspace2.stiffness(self._by_tag(ion['D_sub'], gsub), mass_coef=np.full(nc, 1.0 / _f(self.dt)))
                 levels = amg.build_hierarchy(Ac, psmooth=2, top_interp=self._cspace2.interp)
