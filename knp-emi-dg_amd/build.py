@@ -26,7 +26,8 @@ def build(force=False, verbose=False):
     procs = []
     for s in SOURCES:
         o = os.path.join(CSRC, s.replace(".hip", ".o"))
-        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value",   # hipFree / event calls in teardown paths are fire-and-forget
+
                "-c", os.path.join(CSRC, s), "-o", o]
         if verbose:
             cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")

@@ -97,7 +97,12 @@ struct VecDims {
 // op codes
 enum { OP_CG_INIT = 1, OP_CG_ALPHA, OP_CG_BETA, OP_BI_INIT, OP_BI_ALPHA, OP_BI_OMEGA, OP_BI_RHO, OP_SUM_ONLY };
 
-__global__ void k_reduce(const double* __restrict__ partial, int64_t nblocks, int nsys, int nred, double* __restrict__ red) {
+__device__ void scalar_op(int op, int s, const double* red, double* scal, int* status, double rtol, double atol, int min_it);
+
+// op > 0: the block's thread 0 also runs the scalar recurrence of its system (single-GPU: saves one launch per reduction
+// point; with a communicator the all-reduce sits between the two and k_scalar_op runs separately)
+__global__ void k_reduce(const double* __restrict__ partial, int64_t nblocks, int nsys, int nred, double* red, int op, double* scal,
+                         int* status, double rtol, double atol, int min_it) {
     // one block per system; deterministic order
     const int s = blockIdx.x;
     __shared__ double lds[KNP_BLOCK / 64][KNP_MAX_RED];
@@ -120,13 +125,11 @@ __global__ void k_reduce(const double* __restrict__ partial, int64_t nblocks, in
             for (int w = 1; w < KNP_BLOCK / 64; ++w) v += lds[w][r];
             red[s * KNP_MAX_RED + r] = v;
         }
+        if (op > 0) scalar_op(op, s, red, scal, status, rtol, atol, min_it);
     }
 }
 
-__global__ void k_scalar_op(int op, int nsys, const double* __restrict__ red, double* __restrict__ scal, int* __restrict__ status,
-                            double rtol, double atol, int min_it) {
-    const int s = threadIdx.x;
-    if (s >= nsys) return;
+__device__ void scalar_op(int op, int s, const double* red, double* scal, int* status, double rtol, double atol, int min_it) {
     double* S = scal + s * KS_N;
     const double* R = red + s * KNP_MAX_RED;
     int* flag = status + 2 * s;
@@ -185,6 +188,11 @@ __global__ void k_scalar_op(int op, int nsys, const double* __restrict__ red, do
         } break;
         default: break;
     }
+}
+
+__global__ void k_scalar_op(int op, int nsys, const double* __restrict__ red, double* __restrict__ scal, int* __restrict__ status,
+                            double rtol, double atol, int min_it) {
+    if ((int)threadIdx.x < nsys) scalar_op(op, threadIdx.x, red, scal, status, rtol, atol, min_it);
 }
 
 // ---- PCG kernels ----------------------------------------------------------------------------
@@ -490,12 +498,13 @@ int max_abs_diff(knp_ctx* c, const double* a, const double* b, int nsys, double*
 static int finalize(knp_ctx* c, int op, int nsys, int nred, double rtol, double atol, int min_it) {
     const int64_t nb = grid_for(c->m.nc_owned);
     double* red = c->scal + KNP_MAX_SYS * KS_N;
-    hipLaunchKernelGGL(k_reduce, dim3(nsys), dim3(KNP_BLOCK), 0, c->stream, c->partial, nb, nsys, nred, red);
+    hipLaunchKernelGGL(k_reduce, dim3(nsys), dim3(KNP_BLOCK), 0, c->stream, c->partial, nb, nsys, nred, red, c->dist ? 0 : op, c->scal,
+                       c->status, rtol, atol, min_it);
     if (c->dist) {
         int rc = allreduce_red(c, red, nsys * KNP_MAX_RED);
         if (rc) return rc;
+        hipLaunchKernelGGL(k_scalar_op, dim3(1), dim3(64), 0, c->stream, op, nsys, red, c->scal, c->status, rtol, atol, min_it);
     }
-    hipLaunchKernelGGL(k_scalar_op, dim3(1), dim3(64), 0, c->stream, op, nsys, red, c->scal, c->status, rtol, atol, min_it);
     HIPCHK(c, hipGetLastError());
     return 0;
 }
