@@ -244,7 +244,6 @@ def build_hierarchy(A, theta=0.08, max_coarse=4000, max_levels=12, cheb_degree=2
     cheb_degree = int(os.environ.get("KNP_AMG_DEGREE", cheb_degree))
     cheb_lower = float(os.environ.get("KNP_AMG_LOWER", cheb_lower))
     max_coarse = int(os.environ.get("KNP_AMG_MAXCOARSE", max_coarse))
-    psmooth = int(os.environ.get("KNP_AMG_PSMOOTH", psmooth))
     trunc = float(os.environ.get("KNP_AMG_TRUNC", trunc))
     levels = []
     A = A.tocsr().astype(np.float64)

@@ -342,10 +342,11 @@ class Solver:
             if self.degree_knp == 1:
                 Ac = self._cspace.stiffness(self._by_tag(ion['D_sub'], gsub), mass_coef=np.full(nc, 1.0 / _f(self.dt)))
                 # 10 -> 8 BiCGStab iterations once P is truncated; one Jacobi step on the finest level is enough
-                levels = amg.build_hierarchy(Ac, psmooth=2, level0_degree=int(os.environ.get("KNP_AMG_DEGREE0_KNP", 1)))
+                levels = amg.build_hierarchy(Ac, psmooth=int(os.environ.get("KNP_AMG_PSMOOTH_KNP", 2)),
+                                             level0_degree=int(os.environ.get("KNP_AMG_DEGREE0_KNP", 1)))
             else:
                 Ac = self._cspace2.stiffness(self._by_tag(ion['D_sub'], gsub), mass_coef=np.full(nc, 1.0 / _f(self.dt)))
-                levels = amg.build_hierarchy(Ac, psmooth=2, top_interp=self._cspace2.interp)
+                levels = amg.build_hierarchy(Ac, psmooth=int(os.environ.get("KNP_AMG_PSMOOTH_KNP", 2)), top_interp=self._cspace2.interp)
             self.dev.amg_upload(1 + k, self._local_dg2cg(), levels)
             if self.verbose:
                 print(" AMG(KNP %s) levels:" % ion['name'], [lv.A.shape[0] for lv in levels])
