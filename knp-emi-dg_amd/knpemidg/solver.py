@@ -430,6 +430,7 @@ class Solver:
             print(f"{bcolors.OKGREEN} GPU Execution time PDE solve knp: {res:.4f} seconds ({niters} its) {bcolors.ENDC}")
         self.knp_solve_timer += res
         self.knp_niter.append(niters)
+        self.knp_residuals = r                       # per species: initial residual, final residual, |b|
         if self.save_solver_stats:
             self.file_knp_solve.write("solve_time: %.4f \n" % (res))
             if not self.direct_knp:

@@ -27,6 +27,8 @@ t0 = time.perf_counter()
 pr.enable()
 for k in range(1, steps + 1):
     S.step_membrane_models(k); S.solve_for_time_step(k, t)
+    if os.environ.get("KNP_PRINT_RES"):
+        print("knp its", S.knp_niter[-1], "res0/|b|", S.knp_residuals[:, 0] / S.knp_residuals[:, 2], "res/|b|", S.knp_residuals[:, 1] / S.knp_residuals[:, 2])
 S.dev.sync()
 pr.disable()
 print("ms/step %.2f  EMI its %s  KNP its %s" % ((time.perf_counter() - t0) / steps * 1e3, S.emi_niter[-steps:], [max(k) for k in S.knp_niter[-steps:]]))
