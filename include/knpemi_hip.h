@@ -140,6 +140,10 @@ int knp_knp_solve(knp_ctx* ctx, double rtol, double atol, int maxit, int min_it,
  *  knp_amg_finish: dense pseudo-inverse [n*n] of the last level; arms the preconditioner
  *  knp_amg_clear : back to plain block-Jacobi */
 int knp_amg_begin(knp_ctx* ctx, int which, int64_t ncg, const int32_t* dg2cg, const int32_t* cg_ptr, const int32_t* cg_idx);
+/* Optional, between knp_amg_begin and the first knp_amg_level: the hierarchy of slot `which` (>= 1) preconditions the
+ * first ncol KNP species together (their level vectors become [ncol][n] and one chain of kernels carries all columns);
+ * slots of the other species then stay empty.  Used when the species' diffusion coefficients are close. */
+int knp_amg_columns(knp_ctx* ctx, int which, int ncol);
 int knp_amg_level(knp_ctx* ctx, int which, int64_t n, const int32_t* rowptrA, const int32_t* colA, const double* valA,
                   const double* dinv, double rho, int cheb_degree, double cheb_lower, int64_t ncoarse,
                   const int32_t* rowptrP, const int32_t* colP, const double* valP,

@@ -12,6 +12,12 @@
 
 namespace {
 
+// number of right-hand-side columns of the hierarchy whose V-cycle is being enqueued (grid.y of every kernel): the KNP
+// species share one hierarchy when their diffusion coefficients are close, and one chain of kernels then carries all of
+// them instead of one concurrent chain per species
+int s_ncol = 1;
+#define GRIDX(nx) dim3((unsigned)(nx), (unsigned)s_ncol)
+
 template <typename T> int up(knp_ctx* c, T** dst, const T* src, size_t n) {
     HIPCHK(c, hipMalloc((void**)dst, (n ? n : 1) * sizeof(T)));
     if (n) HIPCHK(c, hipMemcpy(*dst, src, n * sizeof(T), hipMemcpyHostToDevice));
@@ -64,6 +70,9 @@ __device__ __forceinline__ double row_dot(const CsrDev& A, int64_t row, int lane
 template <int MODE, int G>
 __global__ __launch_bounds__(256) void k_csr(CsrDev A, const double* __restrict__ x, const double* __restrict__ b,
                                              double* __restrict__ y) {
+    x += (int64_t)blockIdx.y * A.ncols;
+    y += (int64_t)blockIdx.y * A.nrows;
+    if (MODE == 1) b += (int64_t)blockIdx.y * A.nrows;
     const int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) / G;
     const int lane = threadIdx.x % G;
     const double s = row_dot<G>(A, row, lane, x);
@@ -77,11 +86,11 @@ __global__ __launch_bounds__(256) void k_csr(CsrDev A, const double* __restrict_
 template <int MODE> void launch_csr(knp_ctx* c, const CsrDev& A, const double* x, const double* b, double* y) {
     const double avg = A.nrows ? (double)A.nnz / (double)A.nrows : 0.0;
     if (avg <= 12.0) {
-        hipLaunchKernelGGL((k_csr<MODE, 1>), dim3((unsigned)((A.nrows + 255) / 256)), dim3(256), 0, c->stream, A, x, b, y);
+        hipLaunchKernelGGL((k_csr<MODE, 1>), GRIDX((A.nrows + 255) / 256), dim3(256), 0, c->stream, A, x, b, y);
     } else if (avg <= 96.0) {
-        hipLaunchKernelGGL((k_csr<MODE, 8>), dim3((unsigned)((A.nrows * 8 + 255) / 256)), dim3(256), 0, c->stream, A, x, b, y);
+        hipLaunchKernelGGL((k_csr<MODE, 8>), GRIDX((A.nrows * 8 + 255) / 256), dim3(256), 0, c->stream, A, x, b, y);
     } else {
-        hipLaunchKernelGGL((k_csr<MODE, 64>), dim3((unsigned)((A.nrows * 64 + 255) / 256)), dim3(256), 0, c->stream, A, x, b, y);
+        hipLaunchKernelGGL((k_csr<MODE, 64>), GRIDX((A.nrows * 64 + 255) / 256), dim3(256), 0, c->stream, A, x, b, y);
     }
 }
 
@@ -91,6 +100,8 @@ __global__ void k_cheb_first(int64_t n, const double* __restrict__ dinv, const d
     // zero initial guess: r = b ; d = dinv r / theta ; x = d
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    const int64_t o = (int64_t)blockIdx.y * n;
+    b += o; r += o; d += o; x += o;
     const double bi = b[i];
     const double v = dinv[i] * bi * inv_theta;
     r[i] = bi;
@@ -103,6 +114,8 @@ template <int G>
 __global__ __launch_bounds__(256) void k_cheb_first_res(CsrDev A, const double* __restrict__ dinv, const double* __restrict__ b,
                                                         const double* __restrict__ x, double inv_theta, double* __restrict__ r,
                                                         double* __restrict__ d, double* __restrict__ xout) {
+    const int64_t o = (int64_t)blockIdx.y * A.nrows;
+    b += o; x += o; r += o; d += o; xout += o;
     const int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) / G;
     const int lane = threadIdx.x % G;
     const double s = row_dot<G>(A, row, lane, x);
@@ -120,6 +133,8 @@ template <int G>
 __global__ __launch_bounds__(256) void k_cheb_step(CsrDev A, const double* __restrict__ dinv, const double* __restrict__ din,
                                                    double c1, double c2, double* __restrict__ r, double* __restrict__ dout,
                                                    double* __restrict__ x) {
+    const int64_t o = (int64_t)blockIdx.y * A.nrows;
+    din += o; r += o; dout += o; x += o;
     const int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) / G;
     const int lane = threadIdx.x % G;
     const double s = row_dot<G>(A, row, lane, din);
@@ -136,11 +151,11 @@ void launch_cheb_step(knp_ctx* c, const CsrDev& A, const double* dinv, const dou
                       double* dout, double* x) {
     const double avg = A.nrows ? (double)A.nnz / (double)A.nrows : 0.0;
     if (avg <= 12.0)
-        hipLaunchKernelGGL((k_cheb_step<1>), dim3((unsigned)((A.nrows + 255) / 256)), dim3(256), 0, c->stream, A, dinv, din, c1, c2, r, dout, x);
+        hipLaunchKernelGGL((k_cheb_step<1>), GRIDX((A.nrows + 255) / 256), dim3(256), 0, c->stream, A, dinv, din, c1, c2, r, dout, x);
     else if (avg <= 96.0)
-        hipLaunchKernelGGL((k_cheb_step<8>), dim3((unsigned)((A.nrows * 8 + 255) / 256)), dim3(256), 0, c->stream, A, dinv, din, c1, c2, r, dout, x);
+        hipLaunchKernelGGL((k_cheb_step<8>), GRIDX((A.nrows * 8 + 255) / 256), dim3(256), 0, c->stream, A, dinv, din, c1, c2, r, dout, x);
     else
-        hipLaunchKernelGGL((k_cheb_step<64>), dim3((unsigned)((A.nrows * 64 + 255) / 256)), dim3(256), 0, c->stream, A, dinv, din, c1, c2, r, dout, x);
+        hipLaunchKernelGGL((k_cheb_step<64>), GRIDX((A.nrows * 64 + 255) / 256), dim3(256), 0, c->stream, A, dinv, din, c1, c2, r, dout, x);
 }
 
 // dense y = M b on the coarsest level (n up to a few thousand): one workgroup per row, 4 independent loads in flight per
@@ -150,6 +165,8 @@ __global__ __launch_bounds__(256) void k_dense_mv(int n, const float* __restrict
                                                   double* __restrict__ y) {
     __shared__ double part[4];
     const int row = blockIdx.x;
+    b += (int64_t)blockIdx.y * n;
+    y += (int64_t)blockIdx.y * n;
     const float* __restrict__ Mr = M + (int64_t)row * n;
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
     int k = threadIdx.x;
@@ -173,7 +190,9 @@ __global__ __launch_bounds__(256) void k_dense_mv(int n, const float* __restrict
 // G lanes per conforming dof (a vertex is shared by ~24 tets); fixed summation tree -> deterministic
 template <int G>
 __global__ __launch_bounds__(256) void k_dg_restrict(int64_t ncg, const int32_t* __restrict__ ptr, const int32_t* __restrict__ idx,
-                                                     const double* __restrict__ r, double* __restrict__ rc) {
+                                                     const double* __restrict__ r, double* __restrict__ rc, int64_t r_stride) {
+    r += (int64_t)blockIdx.y * r_stride;
+    rc += (int64_t)blockIdx.y * ncg;
     const int64_t v = ((int64_t)blockIdx.x * 256 + threadIdx.x) / G;
     const int lane = threadIdx.x % G;
     double s = 0.0;
@@ -195,16 +214,16 @@ static void smooth(knp_ctx* c, AmgLevel& L, bool zero_guess) {
     double rho = 1.0 / sigma;
     const unsigned g = (unsigned)((L.n + 255) / 256);
     if (zero_guess) {
-        hipLaunchKernelGGL(k_cheb_first, dim3(g), dim3(256), 0, c->stream, L.n, L.dinv, L.b, 1.0 / theta, L.r, L.d0, L.x);
+        hipLaunchKernelGGL(k_cheb_first, GRIDX(g), dim3(256), 0, c->stream, L.n, L.dinv, L.b, 1.0 / theta, L.r, L.d0, L.x);
     } else {
         // x lives in L.x; the fused kernel writes the updated iterate to L.d1 (free at this point), then swap
         const double avg = L.A.nrows ? (double)L.A.nnz / (double)L.A.nrows : 0.0;
         if (avg <= 12.0)
-            hipLaunchKernelGGL((k_cheb_first_res<1>), dim3((unsigned)((L.n + 255) / 256)), dim3(256), 0, c->stream, L.A, L.dinv, L.b, L.x, 1.0 / theta, L.r, L.d0, L.d1);
+            hipLaunchKernelGGL((k_cheb_first_res<1>), GRIDX((L.n + 255) / 256), dim3(256), 0, c->stream, L.A, L.dinv, L.b, L.x, 1.0 / theta, L.r, L.d0, L.d1);
         else if (avg <= 96.0)
-            hipLaunchKernelGGL((k_cheb_first_res<8>), dim3((unsigned)((L.n * 8 + 255) / 256)), dim3(256), 0, c->stream, L.A, L.dinv, L.b, L.x, 1.0 / theta, L.r, L.d0, L.d1);
+            hipLaunchKernelGGL((k_cheb_first_res<8>), GRIDX((L.n * 8 + 255) / 256), dim3(256), 0, c->stream, L.A, L.dinv, L.b, L.x, 1.0 / theta, L.r, L.d0, L.d1);
         else
-            hipLaunchKernelGGL((k_cheb_first_res<64>), dim3((unsigned)((L.n * 64 + 255) / 256)), dim3(256), 0, c->stream, L.A, L.dinv, L.b, L.x, 1.0 / theta, L.r, L.d0, L.d1);
+            hipLaunchKernelGGL((k_cheb_first_res<64>), GRIDX((L.n * 64 + 255) / 256), dim3(256), 0, c->stream, L.A, L.dinv, L.b, L.x, 1.0 / theta, L.r, L.d0, L.d1);
         double* t = L.x; L.x = L.d1; L.d1 = t;
     }
     double* din = L.d0;
@@ -220,6 +239,8 @@ static void smooth(knp_ctx* c, AmgLevel& L, bool zero_guess) {
 // x_0 = V(b_0) ; level vectors b/x of level 0 are filled / read by the caller
 static int amg_vcycle_eager(knp_ctx* c, AmgHierarchy& H) {
     const int nl = (int)H.levels.size();
+    s_ncol = H.ncol;
+    struct Reset { ~Reset() { s_ncol = 1; } } reset_on_exit;
     for (int l = 0; l < nl - 1; ++l) {
         AmgLevel& L = H.levels[l];
         if (L.cheb_degree == 0) {                                    // transfer-only level: x = 0, r = b
@@ -232,7 +253,7 @@ static int amg_vcycle_eager(knp_ctx* c, AmgHierarchy& H) {
         launch_csr<0>(c, L.R, L.r, nullptr, H.levels[l + 1].b);      // b_{l+1} = R r
     }
     AmgLevel& C = H.levels[nl - 1];
-    hipLaunchKernelGGL(k_dense_mv, dim3((unsigned)C.n), dim3(256), 0, c->stream, (int)C.n, (const float*)H.pinv, C.b, C.x);
+    hipLaunchKernelGGL(k_dense_mv, GRIDX(C.n), dim3(256), 0, c->stream, (int)C.n, (const float*)H.pinv, C.b, C.x);
     for (int l = nl - 2; l >= 0; --l) {
         AmgLevel& L = H.levels[l];
         if (L.cheb_degree == 0) {
@@ -273,18 +294,20 @@ int amg_vcycle(knp_ctx* c, AmgHierarchy& H, hipStream_t on_stream) {
     return amg_vcycle_eager(c, H);      // eager fallback always runs on the context's stream
 }
 
-int amg_restrict_from_dg(knp_ctx* c, AmgHierarchy& H, const double* r_dg, hipStream_t on_stream) {
+int amg_restrict_from_dg(knp_ctx* c, AmgHierarchy& H, const double* r_dg, hipStream_t on_stream, int64_t r_stride) {
     if (on_stream && c->dist) { c->err = "amg: the all-reduced restriction runs on the context's stream"; return -1; }
+    s_ncol = H.ncol;
+    struct Reset { ~Reset() { s_ncol = 1; } } reset_on_exit;
     static const int lanes = getenv("KNP_RESTRICT_LANES") ? atoi(getenv("KNP_RESTRICT_LANES")) : 8;
     hipStream_t st = on_stream ? on_stream : c->stream;
     if (lanes == 32)
-        hipLaunchKernelGGL(k_dg_restrict<32>, dim3((unsigned)((H.ncg * 32 + 255) / 256)), dim3(256), 0, st, H.ncg, H.cg_ptr, H.cg_idx, r_dg, H.levels[0].b);
+        hipLaunchKernelGGL(k_dg_restrict<32>, GRIDX((H.ncg * 32 + 255) / 256), dim3(256), 0, st, H.ncg, H.cg_ptr, H.cg_idx, r_dg, H.levels[0].b, r_stride);
     else if (lanes == 16)
-        hipLaunchKernelGGL(k_dg_restrict<16>, dim3((unsigned)((H.ncg * 16 + 255) / 256)), dim3(256), 0, st, H.ncg, H.cg_ptr, H.cg_idx, r_dg, H.levels[0].b);
+        hipLaunchKernelGGL(k_dg_restrict<16>, GRIDX((H.ncg * 16 + 255) / 256), dim3(256), 0, st, H.ncg, H.cg_ptr, H.cg_idx, r_dg, H.levels[0].b, r_stride);
     else if (lanes == 4)
-        hipLaunchKernelGGL(k_dg_restrict<4>, dim3((unsigned)((H.ncg * 4 + 255) / 256)), dim3(256), 0, st, H.ncg, H.cg_ptr, H.cg_idx, r_dg, H.levels[0].b);
+        hipLaunchKernelGGL(k_dg_restrict<4>, GRIDX((H.ncg * 4 + 255) / 256), dim3(256), 0, st, H.ncg, H.cg_ptr, H.cg_idx, r_dg, H.levels[0].b, r_stride);
     else
-        hipLaunchKernelGGL(k_dg_restrict<8>, dim3((unsigned)((H.ncg * 8 + 255) / 256)), dim3(256), 0, st, H.ncg, H.cg_ptr, H.cg_idx, r_dg, H.levels[0].b);
+        hipLaunchKernelGGL(k_dg_restrict<8>, GRIDX((H.ncg * 8 + 255) / 256), dim3(256), 0, st, H.ncg, H.cg_ptr, H.cg_idx, r_dg, H.levels[0].b, r_stride);
     // multi-GPU: the conforming hierarchy is replicated on every rank; the restricted residual is the sum of the
     // ranks' owned-cell contributions (one all-reduce), after which every rank runs the same V-cycle.  When the finest
     // level is transfer-only (EMI) the restriction to level 1 is linear in b, so it is applied to the LOCAL vector first
@@ -292,13 +315,13 @@ int amg_restrict_from_dg(knp_ctx* c, AmgHierarchy& H, const double* r_dg, hipStr
     if (H.levels.size() > 1 && H.levels[0].cheb_degree == 0) {
         AmgLevel& L = H.levels[0];
         const double avg = L.R.nrows ? (double)L.R.nnz / (double)L.R.nrows : 0.0;
-        if (avg <= 12.0) hipLaunchKernelGGL((k_csr<0, 1>), dim3((unsigned)((L.R.nrows + 255) / 256)), dim3(256), 0, st, L.R, (const double*)L.b, (const double*)nullptr, H.levels[1].b);
-        else if (avg <= 96.0) hipLaunchKernelGGL((k_csr<0, 8>), dim3((unsigned)((L.R.nrows * 8 + 255) / 256)), dim3(256), 0, st, L.R, (const double*)L.b, (const double*)nullptr, H.levels[1].b);
-        else hipLaunchKernelGGL((k_csr<0, 64>), dim3((unsigned)((L.R.nrows * 64 + 255) / 256)), dim3(256), 0, st, L.R, (const double*)L.b, (const double*)nullptr, H.levels[1].b);
-        if (c->dist) return allreduce_red(c, H.levels[1].b, (int)H.levels[1].n);
+        if (avg <= 12.0) hipLaunchKernelGGL((k_csr<0, 1>), GRIDX((L.R.nrows + 255) / 256), dim3(256), 0, st, L.R, (const double*)L.b, (const double*)nullptr, H.levels[1].b);
+        else if (avg <= 96.0) hipLaunchKernelGGL((k_csr<0, 8>), GRIDX((L.R.nrows * 8 + 255) / 256), dim3(256), 0, st, L.R, (const double*)L.b, (const double*)nullptr, H.levels[1].b);
+        else hipLaunchKernelGGL((k_csr<0, 64>), GRIDX((L.R.nrows * 64 + 255) / 256), dim3(256), 0, st, L.R, (const double*)L.b, (const double*)nullptr, H.levels[1].b);
+        if (c->dist) return allreduce_red(c, H.levels[1].b, (int)(H.levels[1].n * H.ncol));
         return 0;
     }
-    if (c->dist) return allreduce_red(c, H.levels[0].b, (int)H.ncg);
+    if (c->dist) return allreduce_red(c, H.levels[0].b, (int)(H.ncg * H.ncol));
     return 0;
 }
 
@@ -311,6 +334,7 @@ void amg_free(AmgHierarchy& H) {
     if (H.graph_exec) hipGraphExecDestroy((hipGraphExec_t)H.graph_exec);
     H.graph_exec = nullptr;
     H.graph_tried = false;
+    H.ncol = 1;
     hipFree(H.pinv); hipFree(H.dg2cg); hipFree(H.cg_ptr); hipFree(H.cg_idx);
     H.pinv = nullptr; H.dg2cg = nullptr; H.cg_ptr = nullptr; H.cg_idx = nullptr;
     H.ready = false;
@@ -361,9 +385,10 @@ int knp_amg_level(knp_ctx* c, int which, int64_t n, const int32_t* rpA, const in
         rc |= up_csr(c, L.R, ncoarse, n, rpR, ciR, vR);
     }
     double** w[] = {&L.x, &L.b, &L.r, &L.d0, &L.d1};
+    const size_t nbuf = (size_t)(n ? n : 1) * (size_t)H->ncol;          // [ncol][n]
     for (auto p : w) {
-        if (hipMalloc((void**)p, (size_t)(n ? n : 1) * sizeof(double)) != hipSuccess) rc = -2;
-        else hipMemset(*p, 0, (size_t)(n ? n : 1) * sizeof(double));
+        if (hipMalloc((void**)p, nbuf * sizeof(double)) != hipSuccess) rc = -2;
+        else hipMemset(*p, 0, nbuf * sizeof(double));
     }
     H->levels.push_back(L);
     return rc;
@@ -380,6 +405,15 @@ int knp_amg_finish(knp_ctx* c, int which, int64_t n, const double* pinv) {
     int rc = up(c, &H->pinv, p32.data(), p32.size());
     H->ready = (rc == 0);
     return rc;
+}
+
+int knp_amg_columns(knp_ctx* c, int which, int ncol) {
+    if (!c) return -1;
+    AmgHierarchy* H = amg_slot(c, which);
+    if (!H || !H->levels.empty()) { c->err = "amg: columns must be set after begin and before the first level"; return -1; }
+    if (ncol < 1 || ncol > KNP_MAX_SYS || (which == 0 && ncol != 1)) { c->err = "amg: bad column count"; return -1; }
+    H->ncol = ncol;
+    return 0;
 }
 
 int knp_amg_clear(knp_ctx* c, int which) {

@@ -22,6 +22,7 @@ struct AmgLevel {
 
 struct AmgHierarchy {
     bool ready = false;
+    int ncol = 1;                   // right-hand-side columns carried by one V-cycle (level vectors are [ncol][n])
     int64_t ncg = 0;
     int32_t* dg2cg = nullptr;       // [nc*nd] conforming dof of every DG dof
     int32_t *cg_ptr = nullptr, *cg_idx = nullptr;   // CSR list: conforming dof -> DG dofs (owned cells only)
@@ -33,5 +34,5 @@ struct AmgHierarchy {
 
 struct knp_ctx;
 int amg_vcycle(knp_ctx* c, AmgHierarchy& H, hipStream_t on_stream = nullptr);
-int amg_restrict_from_dg(knp_ctx* c, AmgHierarchy& H, const double* r_dg, hipStream_t on_stream = nullptr);
+int amg_restrict_from_dg(knp_ctx* c, AmgHierarchy& H, const double* r_dg, hipStream_t on_stream = nullptr, int64_t r_stride = 0);
 void amg_free(AmgHierarchy& H);

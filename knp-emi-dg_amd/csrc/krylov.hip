@@ -319,7 +319,12 @@ __global__ __launch_bounds__(KNP_BLOCK) void k_prolong_dot(VecDims d, const int*
 template <int NV>
 __global__ __launch_bounds__(KNP_BLOCK) void k_prolong_add(VecDims d, const int* __restrict__ status, int sys,
                                                            const int32_t* __restrict__ dg2cg, const double* __restrict__ e,
-                                                           double* __restrict__ y) {
+                                                           int64_t ncg, double* __restrict__ y) {
+    if (sys < 0) {                                   // batched: grid.y = species, e is [nsys][ncg], y is [nsys][nc*NV]
+        sys = blockIdx.y;
+        e += (int64_t)sys * ncg;
+        y += (int64_t)sys * d.nc * NV;
+    }
     if (status[2 * sys]) return;
     const int64_t c = (int64_t)blockIdx.x * KNP_BLOCK + threadIdx.x;
     if (c >= d.nc_owned) return;
@@ -611,6 +616,15 @@ static int knp_coarse_correction(knp_ctx* c, const VecDims& d, const double* in,
         if ((int)c->amg.size() > 1 + s && c->amg[1 + s].ready) active[na++] = s;
     if (!na) return 0;
     int rc;
+    if (c->amg[1].ready && c->amg[1].ncol == d.nsys) {
+        // shared hierarchy: one restriction, one V-cycle and one prolongation carry all species as right-hand-side columns
+        AmgHierarchy& H = c->amg[1];
+        if ((rc = amg_restrict_from_dg(c, H, in, nullptr, d.nc * NV))) return rc;
+        if ((rc = amg_vcycle(c, H))) return rc;
+        hipLaunchKernelGGL(k_prolong_add<NV>, dim3(g1.x, (unsigned)d.nsys), b, 0, c->stream, d, c->status, -1, H.dg2cg, H.levels[0].x,
+                           H.ncg, out);
+        return 0;
+    }
     // every species is an independent chain  restrict -> V-cycle -> prolong  of short latency-bound kernels writing
     // disjoint slices: species 0 runs on the context's stream, every further species on its own auxiliary stream
     // (fork / join with events).  With a communicator the restriction ends in an all-reduce on the context's stream, so
@@ -646,7 +660,7 @@ static int knp_coarse_correction(knp_ctx* c, const VecDims& d, const double* in,
         if ((rc = amg_vcycle(c, H, st))) return rc;
         if (fork_all || !st)
             hipLaunchKernelGGL(k_prolong_add<NV>, g1, b, 0, st ? st : c->stream, d, c->status, s, H.dg2cg, H.levels[0].x,
-                               out + (int64_t)s * d.nc * NV);
+                               H.ncg, out + (int64_t)s * d.nc * NV);
         if (st) HIPCHK(c, hipEventRecord(c->aux_events[i - 1], st));
     }
     for (int i = 1; i < na; ++i) {
@@ -655,7 +669,7 @@ static int knp_coarse_correction(knp_ctx* c, const VecDims& d, const double* in,
         HIPCHK(c, hipStreamWaitEvent(c->stream, c->aux_events[i - 1], 0));
         if (!fork_all)
             hipLaunchKernelGGL(k_prolong_add<NV>, g1, b, 0, c->stream, d, c->status, active[i], H.dg2cg, H.levels[0].x,
-                               out + (int64_t)active[i] * d.nc * NV);
+                               H.ncg, out + (int64_t)active[i] * d.nc * NV);
     }
     return 0;
 }

@@ -62,6 +62,7 @@ SIGNATURES = {
     "knp_ode_exchange": (C.c_int, [_ctxp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int]),
     "knp_ode_step": (C.c_int, [_ctxp, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double]),
     "knp_amg_begin": (C.c_int, [_ctxp, C.c_int, C.c_int64, _i32p, _i32p, _i32p]),
+    "knp_amg_columns": (C.c_int, [_ctxp, C.c_int, C.c_int]),
     "knp_amg_level": (C.c_int, [_ctxp, C.c_int, C.c_int64, _i32p, _i32p, _f64p, _f64p, C.c_double, C.c_int, C.c_double,
                                 C.c_int64, _i32p, _i32p, _f64p, _i32p, _i32p, _f64p]),
     "knp_amg_finish": (C.c_int, [_ctxp, C.c_int, C.c_int64, _f64p]),
@@ -418,7 +419,7 @@ class Device:
         self._chk(self.lib.knp_ode_step(self.ctx, handle, t0, dt, rtol, atol), "knp_ode_step")
 
     # -- auxiliary-space AMG (knpemidg/amg.py builds, csrc/amg.hip applies) ------------------
-    def amg_upload(self, which, dg2cg, levels):
+    def amg_upload(self, which, dg2cg, levels, ncol=1):
         """dg2cg [nc, nd]: conforming dof of every DG dof (caller's cell order); levels from amg.build_hierarchy."""
         nd = self.nd
         d2c = np.ascontiguousarray(np.asarray(dg2cg)[self.cell_order].ravel(), dtype=np.int32)
@@ -429,6 +430,8 @@ class Device:
         ptr = np.zeros(ncg + 1, dtype=np.int32)
         np.cumsum(np.bincount(own, minlength=ncg), out=ptr[1:])
         self._chk(self.lib.knp_amg_begin(self.ctx, which, ncg, _p(d2c, _i32p), _p(ptr, _i32p), _p(idx, _i32p)), "knp_amg_begin")
+        if ncol != 1:
+            self._chk(self.lib.knp_amg_columns(self.ctx, which, int(ncol)), "knp_amg_columns")
 
         def csr(M):
             M = M.tocsr()

@@ -338,18 +338,28 @@ class Solver:
         ts = time.perf_counter()
         gmesh, gsub, gsurf = self._amg_global()
         nc = gmesh.num_cells()
-        for k, ion in enumerate(self.ion_list[:-1]):
+        Dk = [self._by_tag(ion['D_sub'], gsub) for ion in self.ion_list[:-1]]
+        # species whose diffusion coefficients differ by < 25 % share one hierarchy built from the mean coefficient (it
+        # only preconditions): one chain of V-cycle kernels then carries all species as right-hand-side columns instead
+        # of one concurrent chain per species
+        pos = Dk[0] > 0
+        shared = (len(Dk) > 1 and os.environ.get("KNP_AMG_SHARED", "1") == "1"
+                  and all(np.all(np.abs(D[pos] / Dk[0][pos] - 1.0) < 0.25) and np.all((D > 0) == pos) for D in Dk[1:]))
+        groups = [(list(range(len(Dk))), np.mean(Dk, axis=0))] if shared else [([k], D) for k, D in enumerate(Dk)]
+        for members, D in groups:
             if self.degree_knp == 1:
-                Ac = self._cspace.stiffness(self._by_tag(ion['D_sub'], gsub), mass_coef=np.full(nc, 1.0 / _f(self.dt)))
+                Ac = self._cspace.stiffness(D, mass_coef=np.full(nc, 1.0 / _f(self.dt)))
                 # 10 -> 8 BiCGStab iterations once P is truncated; one Jacobi step on the finest level is enough
                 levels = amg.build_hierarchy(Ac, psmooth=int(os.environ.get("KNP_AMG_PSMOOTH_KNP", 2)),
                                              level0_degree=int(os.environ.get("KNP_AMG_DEGREE0_KNP", 1)))
             else:
-                Ac = self._cspace2.stiffness(self._by_tag(ion['D_sub'], gsub), mass_coef=np.full(nc, 1.0 / _f(self.dt)))
+                Ac = self._cspace2.stiffness(D, mass_coef=np.full(nc, 1.0 / _f(self.dt)))
                 levels = amg.build_hierarchy(Ac, psmooth=int(os.environ.get("KNP_AMG_PSMOOTH_KNP", 2)), top_interp=self._cspace2.interp)
-            self.dev.amg_upload(1 + k, self._local_dg2cg(), levels)
+            self.dev.amg_upload(1 + members[0], self._local_dg2cg(), levels, ncol=len(members))
+            for k in members[1:]:
+                self.dev.amg_clear(1 + k)
             if self.verbose:
-                print(" AMG(KNP %s) levels:" % ion['name'], [lv.A.shape[0] for lv in levels])
+                print(" AMG(KNP %s) levels:" % "+".join(self.ion_list[k]['name'] for k in members), [lv.A.shape[0] for lv in levels])
         self.amg_setup_timer = getattr(self, "amg_setup_timer", 0.0) + time.perf_counter() - ts
 
     def _read_solver_params(self):
