@@ -14,7 +14,7 @@ struct Fields {
     double* f[KNP_F_COUNT] = {nullptr};
     int64_t n[KNP_F_COUNT] = {0};
     // solver workspace
-    double *binv_emi = nullptr, *binv_knp = nullptr;
+    bjreal *binv_emi = nullptr, *binv_knp = nullptr;
     double *r = nullptr, *z = nullptr, *p = nullptr, *w = nullptr, *rhat = nullptr, *v = nullptr, *y = nullptr;
     // previous converged solutions, for the extrapolated initial guess x0 = 2 x_{k-1} - x_{k-2}
     double *hist_emi = nullptr, *hist_knp = nullptr;
@@ -55,9 +55,9 @@ template <typename T> int dev_alloc_copy(knp_ctx* c, T** dst, const T* src, size
     return 0;
 }
 
-int dev_zeros(knp_ctx* c, double** dst, size_t n) {
-    HIPCHK(c, hipMalloc((void**)dst, std::max<size_t>(n, 1) * sizeof(double)));
-    HIPCHK(c, hipMemset(*dst, 0, std::max<size_t>(n, 1) * sizeof(double)));
+template <typename T> int dev_zeros(knp_ctx* c, T** dst, size_t n) {
+    HIPCHK(c, hipMalloc((void**)dst, std::max<size_t>(n, 1) * sizeof(T)));
+    HIPCHK(c, hipMemset(*dst, 0, std::max<size_t>(n, 1) * sizeof(T)));
     return 0;
 }
 
@@ -229,7 +229,8 @@ void knp_ctx_destroy(knp_ctx* c) {
     Fields* fl = g_fields[c];
     if (fl) {
         for (int i = 0; i < KNP_F_COUNT; ++i) hipFree(fl->f[i]);
-        double* wk[] = {fl->binv_emi, fl->binv_knp, fl->r, fl->z, fl->p, fl->w, fl->rhat, fl->v, fl->y, fl->hist_emi, fl->hist_knp};
+        hipFree(fl->binv_emi); hipFree(fl->binv_knp);
+        double* wk[] = {fl->r, fl->z, fl->p, fl->w, fl->rhat, fl->v, fl->y, fl->hist_emi, fl->hist_knp};
         for (auto p : wk) hipFree(p);
         delete fl;
         g_fields.erase(c);

@@ -461,7 +461,7 @@ template <int N> __device__ __forceinline__ void invert_small(double (*A)[N]) {
 // inverse of the cell-diagonal block of A_emi (block-Jacobi preconditioner), stored [c][row][col]
 template <int D>
 __global__ __launch_bounds__(KNP_BLOCK) void k_emi_blockjacobi(MeshDev m, const double* __restrict__ kappa,
-                                                               double* __restrict__ binv, double C_phi, double tau,
+                                                               bjreal* __restrict__ binv, double C_phi, double tau,
                                                                double shift) {
     constexpr int NV = D + 1;
     const int64_t c = (int64_t)blockIdx.x * KNP_BLOCK + threadIdx.x;
@@ -501,7 +501,7 @@ __global__ __launch_bounds__(KNP_BLOCK) void k_emi_blockjacobi(MeshDev m, const 
 #pragma unroll
     for (int a = 0; a < NV; ++a)
 #pragma unroll
-        for (int b = 0; b < NV; ++b) binv[(c * NV + a) * NV + b] = A[a][b];
+        for (int b = 0; b < NV; ++b) binv[(c * NV + a) * NV + b] = (bjreal)(0.5 * (A[a][b] + A[b][a]));   // exactly symmetric in fp32
 }
 
 // ------------------------------------------------------------------------------------------
@@ -800,7 +800,7 @@ __global__ __launch_bounds__(BLK) void k_knp_apply_cls_staged(MeshDev m, const d
 template <int D>
 __global__ __launch_bounds__(KNP_BLOCK) void k_knp_blockjacobi(MeshDev m, const double* __restrict__ gphi,
                                                                const double* __restrict__ Dall,
-                                                               double* __restrict__ binv, KnpArgs ka) {
+                                                               bjreal* __restrict__ binv, KnpArgs ka) {
     constexpr int NV = D + 1;
     const int64_t c = (int64_t)blockIdx.x * KNP_BLOCK + threadIdx.x;
     const int k = blockIdx.y;
@@ -828,11 +828,11 @@ __global__ __launch_bounds__(KNP_BLOCK) void k_knp_blockjacobi(MeshDev m, const 
         for (int a = 0; a < NV; ++a) A[a][b] = col[0][a];
     }
     invert_small<NV>(A);
-    double* out = binv + ((int64_t)k * m.nc + c) * NV * NV;
+    bjreal* out = binv + ((int64_t)k * m.nc + c) * NV * NV;
 #pragma unroll
     for (int a = 0; a < NV; ++a)
 #pragma unroll
-        for (int b = 0; b < NV; ++b) out[a * NV + b] = A[a][b];
+        for (int b = 0; b < NV; ++b) out[a * NV + b] = (bjreal)A[a][b];
 }
 
 // gphi[c][a] = grad(phi)_c . grad(lambda_a) = sum_b phi_b G_ab
@@ -949,7 +949,7 @@ int launch_knp_apply(knp_ctx* c, const double* x, const double* gphi, double* y)
     return c->m.dim == 3 ? knp_apply_dispatch<3>(c, x, gphi, y) : knp_apply_dispatch<2>(c, x, gphi, y);
 }
 
-int launch_emi_blockjacobi(knp_ctx* c, const double* kappa, double* binv) {
+int launch_emi_blockjacobi(knp_ctx* c, const double* kappa, bjreal* binv) {
     if (c->degree != 1) return tab_block_inverse(c, 0, binv);
     const dim3 g((unsigned)grid_for(c->m.nc_owned)), b(KNP_BLOCK);
     const double shift = 0.0;
@@ -961,7 +961,7 @@ int launch_emi_blockjacobi(knp_ctx* c, const double* kappa, double* binv) {
     return 0;
 }
 
-int launch_knp_blockjacobi(knp_ctx* c, const double* gphi, double* binv) {
+int launch_knp_blockjacobi(knp_ctx* c, const double* gphi, bjreal* binv) {
     if (c->degree != 1) return tab_block_inverse(c, 1, binv);
     const dim3 g((unsigned)grid_for(c->m.nc_owned), (unsigned)c->p.n_sys), b(KNP_BLOCK);
     const KnpArgs ka = make_knp_args(c);

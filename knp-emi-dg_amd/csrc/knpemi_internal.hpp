@@ -8,6 +8,11 @@
 #include <map>
 #include "amg.hpp"
 
+// block-Jacobi inverses are preconditioner data: stored in fp32 (half the bytes of the largest stream of the fused Krylov
+// vector kernels), applied in fp64 arithmetic; the EMI blocks are symmetrised before rounding so that PCG keeps an exactly
+// symmetric preconditioner
+typedef float bjreal;
+
 #define KNP_MAX_IONS 8          // total species incl. the eliminated one
 #define KNP_MAX_SYS 7           // solved species (batched KNP systems)
 #define KNP_BLOCK 256
@@ -117,8 +122,8 @@ struct knp_ctx {
 // ---- launchers implemented in the .hip files --------------------------------------------
 int launch_emi_apply(knp_ctx* c, const double* x, const double* kappa, double* y);
 int launch_knp_apply(knp_ctx* c, const double* x, const double* dnphi, double* y);
-int launch_emi_blockjacobi(knp_ctx* c, const double* kappa, double* binv);
-int launch_knp_blockjacobi(knp_ctx* c, const double* dnphi, double* binv);
+int launch_emi_blockjacobi(knp_ctx* c, const double* kappa, bjreal* binv);
+int launch_knp_blockjacobi(knp_ctx* c, const double* dnphi, bjreal* binv);
 int launch_dnphi(knp_ctx* c, const double* phi, double* dnphi);
 int launch_kappa(knp_ctx* c, const double* cc, const double* celim, double* kappa);
 int launch_emi_rhs(knp_ctx* c, const double* cc, const double* celim, const double* phiM,
@@ -133,7 +138,7 @@ int launch_facet_trace(knp_ctx* c, const double* nodal, int side, double* out);
 int tab_kappa(knp_ctx* c, const double* cc, const double* celim, double* kappa);
 int tab_assemble_knp(knp_ctx* c, const double* phi);
 int tab_apply(knp_ctx* c, int which, const double* x, double* y);
-int tab_block_inverse(knp_ctx* c, int which, double* binv);
+int tab_block_inverse(knp_ctx* c, int which, bjreal* binv);
 int tab_emi_rhs(knp_ctx* c, const double* cc, const double* celim, const double* phiM, const double* Ich, double* b);
 int tab_knp_rhs(knp_ctx* c, const double* cc, const double* cprev, const double* celim, const double* phi, const double* phiM,
                 const double* Ich, double* b);

@@ -75,13 +75,13 @@ template <int NV> __device__ __forceinline__ void prolong_cell(const int32_t* __
     for (int a = 0; a < NV; ++a) add[a] = e[dg2cg[c * NV + a]];
 }
 
-template <int NV> __device__ __forceinline__ void block_matvec(const double* __restrict__ binv, int64_t c, const double* r, double* z) {
-    const double* B = binv + c * NV * NV;
+template <int NV> __device__ __forceinline__ void block_matvec(const bjreal* __restrict__ binv, int64_t c, const double* r, double* z) {
+    const bjreal* B = binv + c * NV * NV;
 #pragma unroll
     for (int a = 0; a < NV; ++a) {
         double s = 0.0;
 #pragma unroll
-        for (int b = 0; b < NV; ++b) s += B[a * NV + b] * r[b];
+        for (int b = 0; b < NV; ++b) s += (double)B[a * NV + b] * r[b];
         z[a] = s;
     }
 }
@@ -199,7 +199,7 @@ __global__ void k_scalar_op(int op, int nsys, const double* __restrict__ red, do
 // r = b - w(=A x);  z = Binv r;  p = z;  partials: r.z, z.z, (Binv b).(Binv b)
 template <int NV>
 __global__ __launch_bounds__(KNP_BLOCK) void k_cg_init(VecDims d, const double* __restrict__ b, const double* __restrict__ w,
-                                                       const double* __restrict__ binv, double* __restrict__ r,
+                                                       const bjreal* __restrict__ binv, double* __restrict__ r,
                                                        double* __restrict__ z, double* __restrict__ p, double* __restrict__ partial) {
     const int64_t c = (int64_t)blockIdx.x * KNP_BLOCK + threadIdx.x;
     double acc[3] = {0.0, 0.0, 0.0};
@@ -252,7 +252,7 @@ __global__ __launch_bounds__(KNP_BLOCK) void k_dot2(VecDims d, const double* __r
 template <int NV>
 __global__ __launch_bounds__(KNP_BLOCK) void k_cg_update(VecDims d, const double* __restrict__ scal, const int* __restrict__ status,
                                                          const double* __restrict__ p, const double* __restrict__ w,
-                                                         const double* __restrict__ binv, double* __restrict__ x,
+                                                         const bjreal* __restrict__ binv, double* __restrict__ x,
                                                          double* __restrict__ r, double* __restrict__ z, double* __restrict__ partial) {
     if (status[0]) return;
     const double alpha = scal[KS_ALPHA];
@@ -339,7 +339,7 @@ __global__ __launch_bounds__(KNP_BLOCK) void k_prolong_add(VecDims d, const int*
 
 // z = Binv r (plain block-Jacobi apply, used to precondition b on init when the AMG term is active)
 template <int NV>
-__global__ __launch_bounds__(KNP_BLOCK) void k_bj_apply(VecDims d, const double* __restrict__ binv, const double* __restrict__ r,
+__global__ __launch_bounds__(KNP_BLOCK) void k_bj_apply(VecDims d, const bjreal* __restrict__ binv, const double* __restrict__ r,
                                                         double* __restrict__ z) {
     const int64_t c = (int64_t)blockIdx.x * KNP_BLOCK + threadIdx.x;
     if (c >= d.nc_owned) return;
@@ -392,7 +392,7 @@ __global__ __launch_bounds__(KNP_BLOCK) void k_bi_init(VecDims d, const double* 
 template <int NV>
 __global__ __launch_bounds__(KNP_BLOCK) void k_bi_p(VecDims d, const double* __restrict__ scal, const int* __restrict__ status,
                                                     const double* __restrict__ r, const double* __restrict__ v,
-                                                    const double* __restrict__ binv, double* __restrict__ p, double* __restrict__ y) {
+                                                    const bjreal* __restrict__ binv, double* __restrict__ p, double* __restrict__ y) {
     const int s = blockIdx.y;
     if (status[2 * s]) return;
     const double beta = scal[s * KS_N + KS_BETA], omega = scal[s * KS_N + KS_OMEGA];
@@ -412,7 +412,7 @@ __global__ __launch_bounds__(KNP_BLOCK) void k_bi_p(VecDims d, const double* __r
 // s = r - alpha v (in place in r) ; z = Binv s
 template <int NV>
 __global__ __launch_bounds__(KNP_BLOCK) void k_bi_s(VecDims d, const double* __restrict__ scal, const int* __restrict__ status,
-                                                    const double* __restrict__ v, const double* __restrict__ binv,
+                                                    const double* __restrict__ v, const bjreal* __restrict__ binv,
                                                     double* __restrict__ r, double* __restrict__ z) {
     const int s = blockIdx.y;
     if (status[2 * s]) return;

@@ -5,7 +5,8 @@
 enum { KS_RHO = 0, KS_RHO_OLD, KS_ALPHA, KS_BETA, KS_OMEGA, KS_RES, KS_RES0, KS_BNORM, KS_TOL, KS_N = 12 };
 
 struct KrylovVecs {
-    double *x, *b, *coef, *binv;           // unknown, rhs, operator coefficient (kappa | dnphi), block-Jacobi inverses
+    double *x, *b, *coef;                  // unknown, rhs, operator coefficient (kappa | dnphi)
+    bjreal* binv;                          // block-Jacobi inverses (fp32 storage)
     double *r, *z, *p, *w;                 // PCG
     double *rhat, *v, *y;                  // BiCGStab extras (t aliases w)
 };

@@ -354,7 +354,7 @@ __global__ __launch_bounds__(256) void k_tab_apply(MeshDev m, const double* __re
 // inverse of the diagonal blocks (block-Jacobi): one thread per cell, its block in LDS (column index strided by the
 // 64 lanes -> conflict free), in-place Gauss-Jordan without pivoting (blocks are SPD resp. mass-dominated)
 template <int D, int ND>
-__global__ __launch_bounds__(64) void k_tab_block_inverse(MeshDev m, const double* __restrict__ blk_all, double* __restrict__ binv_all) {
+__global__ __launch_bounds__(64) void k_tab_block_inverse(MeshDev m, const double* __restrict__ blk_all, bjreal* __restrict__ binv_all, int symmetric) {
     constexpr int NV = D + 1;
     __shared__ double M[ND * ND * 64];
     const int64_t c = (int64_t)blockIdx.x * 64 + threadIdx.x;
@@ -374,8 +374,13 @@ __global__ __launch_bounds__(64) void k_tab_block_inverse(MeshDev m, const doubl
             for (int k = 0; k < ND; ++k) M[(r * ND + k) * 64 + tid] -= f * M[(p * ND + k) * 64 + tid];
         }
     }
-    double* dst = binv_all + (int64_t)s * m.nc * ND * ND + c * ND * ND;
-    for (int k = 0; k < ND * ND; ++k) dst[k] = M[k * 64 + tid];
+    bjreal* dst = binv_all + (int64_t)s * m.nc * ND * ND + c * ND * ND;
+    if (symmetric) {                                   // EMI: exactly symmetric after rounding to fp32
+        for (int a = 0; a < ND; ++a)
+            for (int b = 0; b < ND; ++b) dst[a * ND + b] = (bjreal)(0.5 * (M[(a * ND + b) * 64 + tid] + M[(b * ND + a) * 64 + tid]));
+    } else {
+        for (int k = 0; k < ND * ND; ++k) dst[k] = (bjreal)M[k * 64 + tid];
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -696,11 +701,11 @@ int tab_apply(knp_ctx* c, int which, const double* x, double* y) {
     return 0;
 }
 
-int tab_block_inverse(knp_ctx* c, int which, double* binv) {
+int tab_block_inverse(knp_ctx* c, int which, bjreal* binv) {
     const double* blk = which == 0 ? c->blk_emi : c->blk_knp;
     if (!blk) { c->err = "DG-p path: operator blocks not assembled"; return -1; }
     const dim3 g((unsigned)((c->m.nc_owned + 63) / 64), (unsigned)(which == 0 ? 1 : c->p.n_sys));
-    TAB_DISPATCH(c, k_tab_block_inverse, g, dim3(64), c->m, blk, binv);
+    TAB_DISPATCH(c, k_tab_block_inverse, g, dim3(64), c->m, blk, binv, which == 0 ? 1 : 0);
     return 0;
 }
 
