@@ -28,7 +28,9 @@ int up_csr(knp_ctx* c, CsrDev& M, int64_t nrows, int64_t ncols, const int32_t* r
     M.nrows = nrows; M.ncols = ncols; M.nnz = rp[nrows];
     int rc = up(c, &M.rowptr, rp, (size_t)nrows + 1);
     rc |= up(c, &M.col, ci, (size_t)M.nnz);
-    rc |= up(c, &M.val, v, (size_t)M.nnz);
+    std::vector<float> v32((size_t)M.nnz);
+    for (size_t i = 0; i < v32.size(); ++i) v32[i] = (float)v[i];
+    rc |= up(c, &M.val, v32.data(), v32.size());
     return rc;
 }
 
@@ -45,7 +47,7 @@ __device__ __forceinline__ double row_dot(const CsrDev& A, int64_t row, int lane
         int k = A.rowptr[row] + lane;
         for (; k + 3 * G < e; k += 4 * G) {
             const int c0 = A.col[k], c1 = A.col[k + G], c2 = A.col[k + 2 * G], c3 = A.col[k + 3 * G];
-            const double v0 = A.val[k], v1 = A.val[k + G], v2 = A.val[k + 2 * G], v3 = A.val[k + 3 * G];
+            const double v0 = A.val[k], v1 = A.val[k + G], v2 = A.val[k + 2 * G], v3 = A.val[k + 3 * G];   // float -> double
             s0 = fma(v0, x[c0], s0);
             s1 = fma(v1, x[c1], s1);
             s2 = fma(v2, x[c2], s2);

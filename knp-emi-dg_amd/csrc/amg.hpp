@@ -8,7 +8,7 @@ struct CsrDev {
     int64_t nrows = 0, ncols = 0, nnz = 0;
     int32_t* rowptr = nullptr;
     int32_t* col = nullptr;
-    double* val = nullptr;
+    float* val = nullptr;          // fp32 storage (preconditioner data; symmetric entries round identically), fp64 arithmetic
 };
 
 struct AmgLevel {
