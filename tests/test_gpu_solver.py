@@ -457,3 +457,30 @@ def test_solver_emi_variant(hip_lib):
         assert relerr(S.phi_M_prev_PDE.array()[pb.mem], pb.phi_M[pb.mem]) < 1e-6
     assert np.array_equal(S.c.array(), c0)                       # concentrations frozen
     assert abs(float(t) - 3e-4) < 1e-12
+
+
+@pytest.mark.parametrize("shared", ["1", "0"])
+def test_knp_hierarchy_shared_or_per_species(hip_lib, monkeypatch, shared):
+    """KNP preconditioner variants: one shared hierarchy carrying the species as V-cycle columns (default when the
+    diffusion coefficients are close) vs one hierarchy per species on concurrent streams.  Both must converge to the
+    oracle's step (the preconditioner does not change the converged solution)."""
+    from common_examples import make_solver, solver_parameters, Constant
+    monkeypatch.setenv("KNP_AMG_SHARED", shared)
+    mt = small_3d((10, 4, 4))
+    S = make_solver(dim=3, resolution=0, n_axons=1, mesh_tuple=mt)
+    sp = solver_parameters(3, 0)._replace(rtol_emi=1e-10, rtol_knp=1e-12)
+    S._unpack_solver_params(sp)
+    S.save_fields = S.save_solver_stats = False
+    S.splitting_scheme = True
+    S.setup_varform_emi(); S.setup_varform_knp(); S.setup_solver_emi(); S.setup_solver_knp()
+    pb = ko.build_idealized(mt[0], mt[1].array(), mt[2].array(), membrane_tags=(1,))
+    t = Constant(0.0)
+    for k in range(2):
+        S.step_membrane_models(k)
+        pb.phi_M = S.phi_M_prev_PDE.array().copy()
+        for ion in pb.ions:
+            pb.I_ch[ion["name"]] = S.mem_models[0]['I_ch_k'][ion["name"]].array().copy()
+        S.solve_for_time_step(k, t)
+        ko.solve_for_time_step(pb, direct=True)
+        assert relerr(S.c.array(), pb.c) < 1e-8
+    assert max(max(n) for n in S.knp_niter) < 60          # the auxiliary space is active (block-Jacobi alone needs hundreds)
