@@ -21,7 +21,7 @@ from knpemidg.utils import pcws_constant_project, plus, minus                # n
 from knpemidg.models import mm_glial, mm_hh_emix                             # noqa: E402
 from knpemidg.h5lite import read_xdmf_mesh                                   # noqa: E402
 
-MESH_XDMF = os.path.join(HERE, "meshes", "emix_meshes", "volume_ncells_5_size_5000", "mesh.xdmf")
+MESH_XDMF = os.path.join(os.path.dirname(os.path.dirname(HERE)), "tests", "golden", "emix_mesh", "mesh.xdmf")   # input-data fixture
 # label -> subdomain: 1 = ECS -> 0; 2, 3 = neurons -> 2; 4, 5, 6 = glial cells -> 1   (run_EMIx_simulation.py:173-185)
 LABEL_TO_SUBDOMAIN = {1: 0, 2: 2, 3: 2, 4: 1, 5: 1, 6: 1}
 
