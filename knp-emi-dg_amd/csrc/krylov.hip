@@ -429,6 +429,38 @@ __global__ __launch_bounds__(KNP_BLOCK) void k_bi_s(VecDims d, const double* __r
     stv<NV>(SYS_PTR(z, s), c, zv);
 }
 
+// second step of the two-step Chebyshev iteration on Binv A (zero initial guess), given y0 = Binv r and t = A y0:
+//   y = ca y0 + cb Binv (r - ct t)
+template <int NV>
+__global__ __launch_bounds__(KNP_BLOCK) void k_bj_cheb2(VecDims d, const int* __restrict__ status, const bjreal* __restrict__ binv,
+                                                        const double* __restrict__ r, const double* __restrict__ t,
+                                                        double* __restrict__ y, double ca, double cb, double ct) {
+    const int s = blockIdx.y;
+    if (status && status[2 * s]) return;
+    const int64_t c = (int64_t)blockIdx.x * KNP_BLOCK + threadIdx.x;
+    if (c >= d.nc_owned) return;
+    double rv[NV], tv[NV], yv[NV], uv[NV];
+    ldv<NV>(SYS_PTR(r, s), c, rv);
+    ldv<NV>(SYS_PTR(t, s), c, tv);
+    ldv<NV>(SYS_PTR(y, s), c, yv);
+#pragma unroll
+    for (int a = 0; a < NV; ++a) rv[a] -= ct * tv[a];
+    block_matvec<NV>(binv + (int64_t)s * d.nc * NV * NV, c, rv, uv);
+#pragma unroll
+    for (int a = 0; a < NV; ++a) yv[a] = ca * yv[a] + cb * uv[a];
+    stv<NV>(SYS_PTR(y, s), c, yv);
+}
+
+// out = alpha[s] * in  (per system)
+__global__ void k_scale_sys(int64_t n_owned, int64_t stride, const double* __restrict__ in, double a0, double a1, double a2, double a3,
+                            double* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_owned) return;
+    const int s = blockIdx.y;
+    const double a = s == 0 ? a0 : (s == 1 ? a1 : (s == 2 ? a2 : a3));
+    out[(int64_t)s * stride + i] = a * in[(int64_t)s * stride + i];
+}
+
 // x += alpha y + omega z ; r = s - omega t ; partials rhat.r, r.r
 template <int NV>
 __global__ __launch_bounds__(KNP_BLOCK) void k_bi_x(VecDims d, const double* __restrict__ scal, const int* __restrict__ status,
@@ -674,6 +706,64 @@ static int knp_coarse_correction(knp_ctx* c, const VecDims& d, const double* in,
     return 0;
 }
 
+// y (= Binv r on entry) <- two-step Chebyshev block-Jacobi of r:  costs one operator apply and one fused vector kernel
+template <int NV>
+static int bj_cheb2(knp_ctx* c, const VecDims& d, const KrylovVecs& kv, const double* r, double* y) {
+    int rc;
+    if (c->dist && (rc = halo_exchange(c, y, d.nsys))) return rc;
+    if ((rc = launch_knp_apply(c, y, kv.coef, kv.tmp))) return rc;
+    const double lmax = kv.bj_lmax, lmin = 0.2 * lmax;
+    const double theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin), sigma = theta / delta, rho0 = 1.0 / sigma;
+    const double rho1 = 1.0 / (2.0 * sigma - rho0);
+    const dim3 g((unsigned)grid_for(c->m.nc_owned), (unsigned)d.nsys), b(KNP_BLOCK);
+    hipLaunchKernelGGL(k_bj_cheb2<NV>, g, b, 0, c->stream, d, (const int*)c->status, kv.binv, r, (const double*)kv.tmp, y,
+                       (1.0 + rho1 * rho0) / theta, 2.0 * rho1 / delta, 1.0 / theta);
+    return 0;
+}
+
+// power iteration for lambda_max(Binv A) of the batched KNP operator (inf-norm normalisation; max over the species)
+template <int NV>
+static int bj_lambda_max_impl(knp_ctx* c, KrylovVecs& kv, int iters, double* out) {
+    const int ns = c->p.n_sys;
+    if (ns > 4) { *out = 0.0; return 0; }
+    VecDims d{c->m.nc_owned, c->m.nc, ns};
+    const dim3 g((unsigned)grid_for(c->m.nc_owned), (unsigned)ns), b(KNP_BLOCK);
+    const int64_t n_owned = c->m.nc_owned * NV, stride = c->m.nc * NV;
+    const dim3 gs((unsigned)((n_owned + 255) / 256), (unsigned)ns);
+    int rc;
+    HIPCHK(c, hipMemsetAsync(kv.z, 0, sizeof(double) * ns * stride, c->stream));
+    HIPCHK(c, hipMemcpyAsync(kv.v, kv.b, sizeof(double) * ns * stride, hipMemcpyDeviceToDevice, c->stream));
+    double lam = 0.0, nv = 0.0;
+    if ((rc = max_abs_diff(c, kv.v, kv.z, ns, &nv))) return rc;
+    if (!(nv > 0.0)) { *out = 0.0; return 0; }
+    for (int it = 0; it < iters; ++it) {
+        if (c->dist && (rc = halo_exchange(c, kv.v, ns))) return rc;
+        if ((rc = launch_knp_apply(c, kv.v, kv.coef, kv.w))) return rc;
+        for (int s = 0; s < ns; ++s)
+            hipLaunchKernelGGL(k_bj_apply<NV>, dim3(g.x), b, 0, c->stream, d, kv.binv + (int64_t)s * c->m.nc * NV * NV,
+                               (const double*)(kv.w + (int64_t)s * stride), kv.y + (int64_t)s * stride);
+        double ny = 0.0;
+        if ((rc = max_abs_diff(c, kv.y, kv.z, ns, &ny))) return rc;
+        lam = ny / nv;
+        if (!(ny > 0.0)) break;
+        const double a = 1.0 / ny;
+        hipLaunchKernelGGL(k_scale_sys, gs, dim3(256), 0, c->stream, n_owned, stride, (const double*)kv.y, a, a, a, a, kv.v);
+        nv = 1.0;
+    }
+    *out = lam;
+    return 0;
+}
+
+int knp_bj_lambda_max(knp_ctx* c, KrylovVecs& kv, int iters, double* out) {
+    switch (c->nd) {
+        case 3: return bj_lambda_max_impl<3>(c, kv, iters, out);
+        case 4: return bj_lambda_max_impl<4>(c, kv, iters, out);
+        case 6: return bj_lambda_max_impl<6>(c, kv, iters, out);
+        case 10: return bj_lambda_max_impl<10>(c, kv, iters, out);
+    }
+    return -1;
+}
+
 template <int NV>
 static int bicgstab_impl(knp_ctx* c, KrylovVecs& kv, double rtol, double atol, int maxit, int min_it, int check_every,
                          int* niter, double* res) {
@@ -693,6 +783,7 @@ static int bicgstab_impl(knp_ctx* c, KrylovVecs& kv, double rtol, double atol, i
         const int chunk = next_chunk(it, maxit, check_every, c->last_it_knp);
         for (int k = 0; k < chunk; ++k) {
             hipLaunchKernelGGL(k_bi_p<NV>, g, b, 0, c->stream, d, c->scal, c->status, kv.r, kv.v, kv.binv, kv.p, kv.y);
+            if (kv.bj_lmax > 0.0 && (rc = bj_cheb2<NV>(c, d, kv, kv.p, kv.y))) return rc;
             if ((rc = knp_coarse_correction<NV>(c, d, kv.p, kv.y))) return rc;
             if (c->dist && (rc = halo_exchange(c, kv.y, ns))) return rc;
             if ((rc = launch_knp_apply(c, kv.y, kv.coef, kv.v))) return rc;
@@ -700,6 +791,7 @@ static int bicgstab_impl(knp_ctx* c, KrylovVecs& kv, double rtol, double atol, i
                                c->partial, c->status);
             if ((rc = finalize(c, OP_BI_ALPHA, ns, 1, rtol, atol, min_it))) return rc;
             hipLaunchKernelGGL(k_bi_s<NV>, g, b, 0, c->stream, d, c->scal, c->status, kv.v, kv.binv, kv.r, kv.z);
+            if (kv.bj_lmax > 0.0 && (rc = bj_cheb2<NV>(c, d, kv, kv.r, kv.z))) return rc;
             if ((rc = knp_coarse_correction<NV>(c, d, kv.r, kv.z))) return rc;
             if (c->dist && (rc = halo_exchange(c, kv.z, ns))) return rc;
             if ((rc = launch_knp_apply(c, kv.z, kv.coef, kv.w))) return rc;

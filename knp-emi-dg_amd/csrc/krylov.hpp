@@ -9,8 +9,11 @@ struct KrylovVecs {
     bjreal* binv;                          // block-Jacobi inverses (fp32 storage)
     double *r, *z, *p, *w;                 // PCG
     double *rhat, *v, *y;                  // BiCGStab extras (t aliases w)
+    double* tmp = nullptr;                 // scratch of the Chebyshev block-Jacobi smoother (BiCGStab), or null
+    double bj_lmax = 0.0;                  // > 0: lambda_max(Binv A) estimate -> two-step Chebyshev block-Jacobi
 };
 
 int pcg_solve(knp_ctx* c, KrylovVecs& kv, double rtol, double atol, int maxit, int check_every, int* niter, double* res);
+int knp_bj_lambda_max(knp_ctx* c, KrylovVecs& kv, int iters, double* out);
 int bicgstab_solve(knp_ctx* c, KrylovVecs& kv, double rtol, double atol, int maxit, int min_it, int check_every, int* niter,
                    double* res);
