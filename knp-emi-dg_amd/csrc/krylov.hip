@@ -8,6 +8,7 @@
 // Replaces PETSc KSP cg / gmres + hypre (reference: src/knpemidg/solver.py:425-444,509,684-701,771).
 #include "cell_geom.hpp"
 #include "krylov.hpp"
+#include <cstdlib>
 
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
@@ -712,7 +713,8 @@ static int bj_cheb2(knp_ctx* c, const VecDims& d, const KrylovVecs& kv, const do
     int rc;
     if (c->dist && (rc = halo_exchange(c, y, d.nsys))) return rc;
     if ((rc = launch_knp_apply(c, y, kv.coef, kv.tmp))) return rc;
-    const double lmax = kv.bj_lmax, lmin = 0.2 * lmax;
+    static const double lmin_frac = getenv("KNP_BJ_LMIN") ? atof(getenv("KNP_BJ_LMIN")) : 0.05;   // measured best over 30 steps at r=2 (0.03..0.06)
+    const double lmax = kv.bj_lmax, lmin = lmin_frac * lmax;
     const double theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin), sigma = theta / delta, rho0 = 1.0 / sigma;
     const double rho1 = 1.0 / (2.0 * sigma - rho0);
     const dim3 g((unsigned)grid_for(c->m.nc_owned), (unsigned)d.nsys), b(KNP_BLOCK);
