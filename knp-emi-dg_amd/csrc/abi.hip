@@ -22,6 +22,9 @@ struct Fields {
     double* tmp_knp = nullptr;     // scratch of the Chebyshev block-Jacobi smoother
     double bj_lmax_knp = 0.0;      // lambda_max(Binv A_knp) estimate (power iteration at the first solve, refreshed rarely)
     int bj_lmax_age = 0;
+    double* tmp_emi = nullptr;
+    double bj_lmax_emi = 0.0;
+    int bj_lmax_emi_age = 0;
     bool have_hist_emi = false, have_hist_knp = false;
 };
 
@@ -234,7 +237,7 @@ void knp_ctx_destroy(knp_ctx* c) {
     if (fl) {
         for (int i = 0; i < KNP_F_COUNT; ++i) hipFree(fl->f[i]);
         hipFree(fl->binv_emi); hipFree(fl->binv_knp);
-        double* wk[] = {fl->r, fl->z, fl->p, fl->w, fl->rhat, fl->v, fl->y, fl->hist_emi, fl->hist_knp, fl->tmp_knp};
+        double* wk[] = {fl->r, fl->z, fl->p, fl->w, fl->rhat, fl->v, fl->y, fl->hist_emi, fl->hist_knp, fl->tmp_knp, fl->tmp_emi};
         for (auto p : wk) hipFree(p);
         delete fl;
         g_fields.erase(c);
@@ -400,6 +403,22 @@ int knp_emi_solve(knp_ctx* c, double rtol, double atol, int maxit, int check_eve
     KrylovVecs kv{};
     kv.x = f->f[KNP_F_PHI]; kv.b = f->f[KNP_F_B_EMI]; kv.coef = f->f[KNP_F_KAPPA]; kv.binv = f->binv_emi;
     kv.r = f->r; kv.z = f->z; kv.p = f->p; kv.w = f->w; kv.rhat = f->rhat; kv.v = f->v; kv.y = f->y;
+    // the same two-step Chebyshev block-Jacobi smoother for EMI is opt-in (KNP_EMI_CHEB=1): measured at r=2 it leaves the
+    // PCG iteration count where it is (8..15 -> 8..13 through an action potential; EMI is limited by the auxiliary-space
+    // part, not by block-Jacobi) and the extra apply makes the step 1 % slower
+    static const int cheb_emi = getenv("KNP_EMI_CHEB") ? atoi(getenv("KNP_EMI_CHEB")) : 0;
+    if (cheb_emi && c->amg.size() && c->amg[0].ready) {
+        if (!f->tmp_emi) HIPCHK(c, hipMalloc((void**)&f->tmp_emi, sizeof(double) * f->n[KNP_F_PHI]));
+        kv.tmp = f->tmp_emi;
+        if (f->bj_lmax_emi <= 0.0 || ++f->bj_lmax_emi_age >= 200) {
+            double lam = 0.0;
+            if ((rc = knp_bj_lambda_max(c, kv, 20, &lam, true))) return rc;
+            f->bj_lmax_emi = 1.1 * lam;
+            f->bj_lmax_emi_age = 0;
+            if (getenv("KNP_DEBUG")) fprintf(stderr, "[knp] lambda_max(Binv A_emi) ~ %.4f\n", lam);
+        }
+        kv.bj_lmax = f->bj_lmax_emi;
+    }
     rc = pcg_solve(c, kv, rtol, atol, maxit, check_every, niter, res);
     if (rc) return rc;
     if (c->dist) return halo_exchange(c, kv.x, 1);     // ghostUpdate (solver.py:529)

@@ -567,6 +567,66 @@ static inline int next_chunk(int it, int maxit, int check_every, int predicted) 
     return (maxit - it < chunk) ? (maxit - it) : chunk;
 }
 
+// y (= Binv r on entry) <- two-step Chebyshev block-Jacobi of r:  costs one operator apply and one fused vector kernel
+template <int NV, bool EMI>
+static int bj_cheb2(knp_ctx* c, const VecDims& d, const KrylovVecs& kv, const double* r, double* y, bool use_status = true) {
+    int rc;
+    if (c->dist && (rc = halo_exchange(c, y, d.nsys))) return rc;
+    if ((rc = EMI ? launch_emi_apply(c, y, kv.coef, kv.tmp) : launch_knp_apply(c, y, kv.coef, kv.tmp))) return rc;
+    static const double lmin_frac = getenv("KNP_BJ_LMIN") ? atof(getenv("KNP_BJ_LMIN")) : 0.05;   // measured best over 30 steps at r=2 (0.03..0.06)
+    const double lmax = kv.bj_lmax, lmin = lmin_frac * lmax;
+    const double theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin), sigma = theta / delta, rho0 = 1.0 / sigma;
+    const double rho1 = 1.0 / (2.0 * sigma - rho0);
+    const dim3 g((unsigned)grid_for(c->m.nc_owned), (unsigned)d.nsys), b(KNP_BLOCK);
+    hipLaunchKernelGGL(k_bj_cheb2<NV>, g, b, 0, c->stream, d, use_status ? (const int*)c->status : (const int*)nullptr, kv.binv, r,
+                       (const double*)kv.tmp, y,
+                       (1.0 + rho1 * rho0) / theta, 2.0 * rho1 / delta, 1.0 / theta);
+    return 0;
+}
+
+// power iteration for lambda_max(Binv A) of the batched KNP operator (inf-norm normalisation; max over the species)
+template <int NV, bool EMI>
+static int bj_lambda_max_impl(knp_ctx* c, KrylovVecs& kv, int iters, double* out) {
+    const int ns = EMI ? 1 : c->p.n_sys;
+    if (ns > 4) { *out = 0.0; return 0; }
+    VecDims d{c->m.nc_owned, c->m.nc, ns};
+    const dim3 g((unsigned)grid_for(c->m.nc_owned), (unsigned)ns), b(KNP_BLOCK);
+    const int64_t n_owned = c->m.nc_owned * NV, stride = c->m.nc * NV;
+    const dim3 gs((unsigned)((n_owned + 255) / 256), (unsigned)ns);
+    int rc;
+    HIPCHK(c, hipMemsetAsync(kv.z, 0, sizeof(double) * ns * stride, c->stream));
+    HIPCHK(c, hipMemcpyAsync(kv.v, kv.b, sizeof(double) * ns * stride, hipMemcpyDeviceToDevice, c->stream));
+    double lam = 0.0, nv = 0.0;
+    if ((rc = max_abs_diff(c, kv.v, kv.z, ns, &nv))) return rc;
+    if (!(nv > 0.0)) { *out = 0.0; return 0; }
+    for (int it = 0; it < iters; ++it) {
+        if (c->dist && (rc = halo_exchange(c, kv.v, ns))) return rc;
+        if ((rc = EMI ? launch_emi_apply(c, kv.v, kv.coef, kv.w) : launch_knp_apply(c, kv.v, kv.coef, kv.w))) return rc;
+        for (int s = 0; s < ns; ++s)
+            hipLaunchKernelGGL(k_bj_apply<NV>, dim3(g.x), b, 0, c->stream, d, kv.binv + (int64_t)s * c->m.nc * NV * NV,
+                               (const double*)(kv.w + (int64_t)s * stride), kv.y + (int64_t)s * stride);
+        double ny = 0.0;
+        if ((rc = max_abs_diff(c, kv.y, kv.z, ns, &ny))) return rc;
+        lam = ny / nv;
+        if (!(ny > 0.0)) break;
+        const double a = 1.0 / ny;
+        hipLaunchKernelGGL(k_scale_sys, gs, dim3(256), 0, c->stream, n_owned, stride, (const double*)kv.y, a, a, a, a, kv.v);
+        nv = 1.0;
+    }
+    *out = lam;
+    return 0;
+}
+
+int knp_bj_lambda_max(knp_ctx* c, KrylovVecs& kv, int iters, double* out, bool emi) {
+    switch (c->nd) {
+        case 3: return emi ? bj_lambda_max_impl<3, true>(c, kv, iters, out) : bj_lambda_max_impl<3, false>(c, kv, iters, out);
+        case 4: return emi ? bj_lambda_max_impl<4, true>(c, kv, iters, out) : bj_lambda_max_impl<4, false>(c, kv, iters, out);
+        case 6: return emi ? bj_lambda_max_impl<6, true>(c, kv, iters, out) : bj_lambda_max_impl<6, false>(c, kv, iters, out);
+        case 10: return emi ? bj_lambda_max_impl<10, true>(c, kv, iters, out) : bj_lambda_max_impl<10, false>(c, kv, iters, out);
+    }
+    return -1;
+}
+
 template <int NV>
 static int pcg_impl(knp_ctx* c, KrylovVecs& kv, double rtol, double atol, int maxit, int check_every, int* niter, double* res) {
     VecDims d{c->m.nc_owned, c->m.nc, 1};
@@ -579,6 +639,10 @@ static int pcg_impl(knp_ctx* c, KrylovVecs& kv, double rtol, double atol, int ma
     if (H) {
         // z = Binv r + P V(P^T r) ; reference norm uses the same preconditioner on b (stored in y)
         hipLaunchKernelGGL(k_bj_apply<NV>, g, b, 0, c->stream, d, kv.binv, kv.b, kv.y);
+        if (kv.bj_lmax > 0.0) {                  // same DG-level smoother on b (reference norm) and on r
+            if ((rc = bj_cheb2<NV, true>(c, d, kv, kv.b, kv.y, false))) return rc;
+            if ((rc = bj_cheb2<NV, true>(c, d, kv, kv.r, kv.z, false))) return rc;
+        }
         if ((rc = amg_restrict_from_dg(c, *H, kv.b))) return rc;
         if ((rc = amg_vcycle(c, *H))) return rc;
         HIPCHK(c, hipMemcpyAsync(kv.v, H->levels[0].x, sizeof(double) * H->ncg, hipMemcpyDeviceToDevice, c->stream));
@@ -603,6 +667,7 @@ static int pcg_impl(knp_ctx* c, KrylovVecs& kv, double rtol, double atol, int ma
             hipLaunchKernelGGL(k_cg_update<NV>, g, b, 0, c->stream, d, c->scal, c->status, kv.p, kv.w, kv.binv, kv.x, kv.r, kv.z,
                                c->partial);
             if (H) {
+                if (kv.bj_lmax > 0.0 && (rc = bj_cheb2<NV, true>(c, d, kv, kv.r, kv.z))) return rc;
                 if ((rc = amg_restrict_from_dg(c, *H, kv.r))) return rc;
                 if ((rc = amg_vcycle(c, *H))) return rc;
                 hipLaunchKernelGGL((k_prolong_dot<NV, 2>), g, b, 0, c->stream, d, c->status, 1, H->dg2cg, H->levels[0].x, kv.r,
@@ -707,65 +772,6 @@ static int knp_coarse_correction(knp_ctx* c, const VecDims& d, const double* in,
     return 0;
 }
 
-// y (= Binv r on entry) <- two-step Chebyshev block-Jacobi of r:  costs one operator apply and one fused vector kernel
-template <int NV>
-static int bj_cheb2(knp_ctx* c, const VecDims& d, const KrylovVecs& kv, const double* r, double* y) {
-    int rc;
-    if (c->dist && (rc = halo_exchange(c, y, d.nsys))) return rc;
-    if ((rc = launch_knp_apply(c, y, kv.coef, kv.tmp))) return rc;
-    static const double lmin_frac = getenv("KNP_BJ_LMIN") ? atof(getenv("KNP_BJ_LMIN")) : 0.05;   // measured best over 30 steps at r=2 (0.03..0.06)
-    const double lmax = kv.bj_lmax, lmin = lmin_frac * lmax;
-    const double theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin), sigma = theta / delta, rho0 = 1.0 / sigma;
-    const double rho1 = 1.0 / (2.0 * sigma - rho0);
-    const dim3 g((unsigned)grid_for(c->m.nc_owned), (unsigned)d.nsys), b(KNP_BLOCK);
-    hipLaunchKernelGGL(k_bj_cheb2<NV>, g, b, 0, c->stream, d, (const int*)c->status, kv.binv, r, (const double*)kv.tmp, y,
-                       (1.0 + rho1 * rho0) / theta, 2.0 * rho1 / delta, 1.0 / theta);
-    return 0;
-}
-
-// power iteration for lambda_max(Binv A) of the batched KNP operator (inf-norm normalisation; max over the species)
-template <int NV>
-static int bj_lambda_max_impl(knp_ctx* c, KrylovVecs& kv, int iters, double* out) {
-    const int ns = c->p.n_sys;
-    if (ns > 4) { *out = 0.0; return 0; }
-    VecDims d{c->m.nc_owned, c->m.nc, ns};
-    const dim3 g((unsigned)grid_for(c->m.nc_owned), (unsigned)ns), b(KNP_BLOCK);
-    const int64_t n_owned = c->m.nc_owned * NV, stride = c->m.nc * NV;
-    const dim3 gs((unsigned)((n_owned + 255) / 256), (unsigned)ns);
-    int rc;
-    HIPCHK(c, hipMemsetAsync(kv.z, 0, sizeof(double) * ns * stride, c->stream));
-    HIPCHK(c, hipMemcpyAsync(kv.v, kv.b, sizeof(double) * ns * stride, hipMemcpyDeviceToDevice, c->stream));
-    double lam = 0.0, nv = 0.0;
-    if ((rc = max_abs_diff(c, kv.v, kv.z, ns, &nv))) return rc;
-    if (!(nv > 0.0)) { *out = 0.0; return 0; }
-    for (int it = 0; it < iters; ++it) {
-        if (c->dist && (rc = halo_exchange(c, kv.v, ns))) return rc;
-        if ((rc = launch_knp_apply(c, kv.v, kv.coef, kv.w))) return rc;
-        for (int s = 0; s < ns; ++s)
-            hipLaunchKernelGGL(k_bj_apply<NV>, dim3(g.x), b, 0, c->stream, d, kv.binv + (int64_t)s * c->m.nc * NV * NV,
-                               (const double*)(kv.w + (int64_t)s * stride), kv.y + (int64_t)s * stride);
-        double ny = 0.0;
-        if ((rc = max_abs_diff(c, kv.y, kv.z, ns, &ny))) return rc;
-        lam = ny / nv;
-        if (!(ny > 0.0)) break;
-        const double a = 1.0 / ny;
-        hipLaunchKernelGGL(k_scale_sys, gs, dim3(256), 0, c->stream, n_owned, stride, (const double*)kv.y, a, a, a, a, kv.v);
-        nv = 1.0;
-    }
-    *out = lam;
-    return 0;
-}
-
-int knp_bj_lambda_max(knp_ctx* c, KrylovVecs& kv, int iters, double* out) {
-    switch (c->nd) {
-        case 3: return bj_lambda_max_impl<3>(c, kv, iters, out);
-        case 4: return bj_lambda_max_impl<4>(c, kv, iters, out);
-        case 6: return bj_lambda_max_impl<6>(c, kv, iters, out);
-        case 10: return bj_lambda_max_impl<10>(c, kv, iters, out);
-    }
-    return -1;
-}
-
 template <int NV>
 static int bicgstab_impl(knp_ctx* c, KrylovVecs& kv, double rtol, double atol, int maxit, int min_it, int check_every,
                          int* niter, double* res) {
@@ -785,7 +791,7 @@ static int bicgstab_impl(knp_ctx* c, KrylovVecs& kv, double rtol, double atol, i
         const int chunk = next_chunk(it, maxit, check_every, c->last_it_knp);
         for (int k = 0; k < chunk; ++k) {
             hipLaunchKernelGGL(k_bi_p<NV>, g, b, 0, c->stream, d, c->scal, c->status, kv.r, kv.v, kv.binv, kv.p, kv.y);
-            if (kv.bj_lmax > 0.0 && (rc = bj_cheb2<NV>(c, d, kv, kv.p, kv.y))) return rc;
+            if (kv.bj_lmax > 0.0 && (rc = bj_cheb2<NV, false>(c, d, kv, kv.p, kv.y))) return rc;
             if ((rc = knp_coarse_correction<NV>(c, d, kv.p, kv.y))) return rc;
             if (c->dist && (rc = halo_exchange(c, kv.y, ns))) return rc;
             if ((rc = launch_knp_apply(c, kv.y, kv.coef, kv.v))) return rc;
@@ -793,7 +799,7 @@ static int bicgstab_impl(knp_ctx* c, KrylovVecs& kv, double rtol, double atol, i
                                c->partial, c->status);
             if ((rc = finalize(c, OP_BI_ALPHA, ns, 1, rtol, atol, min_it))) return rc;
             hipLaunchKernelGGL(k_bi_s<NV>, g, b, 0, c->stream, d, c->scal, c->status, kv.v, kv.binv, kv.r, kv.z);
-            if (kv.bj_lmax > 0.0 && (rc = bj_cheb2<NV>(c, d, kv, kv.r, kv.z))) return rc;
+            if (kv.bj_lmax > 0.0 && (rc = bj_cheb2<NV, false>(c, d, kv, kv.r, kv.z))) return rc;
             if ((rc = knp_coarse_correction<NV>(c, d, kv.r, kv.z))) return rc;
             if (c->dist && (rc = halo_exchange(c, kv.z, ns))) return rc;
             if ((rc = launch_knp_apply(c, kv.z, kv.coef, kv.w))) return rc;

@@ -14,6 +14,6 @@ struct KrylovVecs {
 };
 
 int pcg_solve(knp_ctx* c, KrylovVecs& kv, double rtol, double atol, int maxit, int check_every, int* niter, double* res);
-int knp_bj_lambda_max(knp_ctx* c, KrylovVecs& kv, int iters, double* out);
+int knp_bj_lambda_max(knp_ctx* c, KrylovVecs& kv, int iters, double* out, bool emi = false);
 int bicgstab_solve(knp_ctx* c, KrylovVecs& kv, double rtol, double atol, int maxit, int min_it, int check_every, int* niter,
                    double* res);
