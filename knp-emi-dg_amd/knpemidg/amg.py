@@ -247,6 +247,7 @@ def build_hierarchy(A, theta=0.08, max_coarse=4000, max_levels=12, cheb_degree=2
     trunc = float(os.environ.get("KNP_AMG_TRUNC", trunc))
     levels = []
     A = A.tocsr().astype(np.float64)
+    Bnull = np.ones(A.shape[0])
     while True:
         lv = Level()
         lv.A = A
@@ -274,6 +275,7 @@ def build_hierarchy(A, theta=0.08, max_coarse=4000, max_levels=12, cheb_degree=2
             lv.R.sort_indices()
             A = (lv.R @ A @ P).tocsr()
             A.sort_indices()
+            Bnull = np.ones(A.shape[0])          # the geometric interpolation reproduces constants exactly
             continue
         if n <= max_coarse or len(levels) >= max_levels:
             break
@@ -285,8 +287,12 @@ def build_hierarchy(A, theta=0.08, max_coarse=4000, max_levels=12, cheb_degree=2
         agg, nagg = mis2_aggregate(S, seed=len(levels))
         if nagg >= n:
             break
-        cnt = np.bincount(agg, minlength=nagg).astype(np.float64)
-        T = sp.csr_matrix((1.0 / np.sqrt(cnt[agg]), (np.arange(n), agg)), shape=(n, nagg))
+        # tentative prolongator from the near-null-space candidate Bnull of THIS level (the constant on level 0; on
+        # coarser levels its coarse representation, which is not constant because the aggregates differ in size):
+        # T[i, agg(i)] = Bnull[i] / |Bnull restricted to the aggregate|, and the next level's candidate is that norm, so
+        # that T Bnull_coarse = Bnull on every level
+        nrm = np.sqrt(np.bincount(agg, weights=Bnull * Bnull, minlength=nagg))
+        T = sp.csr_matrix((Bnull / nrm[agg], (np.arange(n), agg)), shape=(n, nagg))
         # prolongator smoothing: `psmooth` damped-Jacobi steps on the tentative prolongator.  Two steps instead of the
         # textbook one cut the V-cycle's convergence factor on the anisotropic conforming operator from ~0.63 to
         # ~0.25 (CG on Ac: 39 -> 13 iterations at r=1) for 1.8x the operator complexity
@@ -303,7 +309,7 @@ def build_hierarchy(A, theta=0.08, max_coarse=4000, max_levels=12, cheb_degree=2
             np.maximum.at(rowmax, Pc.row, np.abs(Pc.data))
             keep = np.abs(Pc.data) >= trunc * rowmax[Pc.row]
             Pt = sp.csr_matrix((Pc.data[keep], (Pc.row[keep], Pc.col[keep])), shape=P.shape)
-            Bc = np.sqrt(cnt)
+            Bc = nrm
             tgt, got = P @ Bc, Pt @ Bc
             P = (sp.diags(np.where(np.abs(got) > 1e-300, tgt / np.where(got == 0, 1.0, got), 1.0)) @ Pt).tocsr()
         P.sort_indices()
@@ -312,6 +318,7 @@ def build_hierarchy(A, theta=0.08, max_coarse=4000, max_levels=12, cheb_degree=2
         lv.R.sort_indices()
         A = (lv.R @ A @ P).tocsr()
         A.sort_indices()
+        Bnull = nrm
     last = levels[-1]
     # dense pseudo-inverse through the eigen-decomposition: the constant mode of the singular EMI operator reaches
     # the coarsest level as a tiny but non-zero eigenvalue (smoothed prolongators do not reproduce constants to
