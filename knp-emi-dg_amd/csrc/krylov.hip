@@ -562,7 +562,7 @@ static inline int next_chunk(int it, int maxit, int check_every, int predicted) 
     int chunk = check_every;
     if (predicted > 0) {
         const int ahead = predicted - 1 - it;
-        chunk = ahead > 0 ? (ahead < 4 * check_every ? ahead : 4 * check_every) : 2;
+        chunk = ahead > 0 ? (ahead < 4 * check_every ? ahead : 4 * check_every) : (predicted <= 2 ? 1 : 2);   // 1-2 iteration solves: look every time
     }
     return (maxit - it < chunk) ? (maxit - it) : chunk;
 }
