@@ -164,3 +164,53 @@ def test_membrane_tag_without_facets(hip_lib):
         S.solve_for_time_step(k, t)
     assert np.isfinite(S.phi.array()).all() and np.isfinite(S.c.array()).all()
     S.dev.close()
+
+
+def test_p2_edge_cases_and_argument_checks(hip_lib):
+    """DG-P2 path on the smallest mesh (two tets, one interior facet, single solved species), plus the argument checks of
+    knp_set_tabulation / knp_amg_columns and the loud failure when a tabulation slot is missing."""
+    import ctypes as C
+    from knpemidg import _abi as A
+    from knpemidg.mesh import Mesh, MeshFunction
+    coords = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1], [1, 1, 1.0]]) * 1e-6
+    m = Mesh(coords, np.array([[0, 1, 2, 3], [1, 2, 3, 4]]))
+    s = MeshFunction(m, 3, np.array([0, 1]))
+    f = MeshFunction(m, 2, 0)
+    f.array()[m.facet_cells[:, 1] >= 0] = 1                        # the interior facet is a membrane
+    pb = ko.build_idealized(m, s.array(), f.array(), p=2, membrane_tags=(1,))
+    x = synthetic_state(pb)
+    dev = device_for(pb)
+    push_state(dev, pb)
+    dev.update_kappa(); dev.update_dnphi()
+    Aemi, b, _ = ko.assemble_emi(pb, want_B=False)
+    dev.upload(A.F_X, x[0]); dev.emi_apply(A.F_X, A.F_Y)
+    assert relerr(dev.download(A.F_Y, 0, pb.ndof), Aemi @ x[0].ravel()) < 1e-11
+    dev.upload(A.F_X, x); dev.knp_apply(A.F_X, A.F_Y)
+    y = dev.download(A.F_Y).reshape(pb.N_ions, -1)
+    for k in range(pb.N_ions):
+        assert relerr(y[k], ko.assemble_knp(pb, k) @ x[k].ravel()) < 1e-11
+    dev.emi_rhs(); dev.knp_rhs()
+    assert relerr(dev.download(A.F_B_EMI), b) < 1e-11
+    # argument checks
+    w = np.ones(1); B = np.ones(10); dB = np.zeros(40)
+    p = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    assert dev.lib.knp_set_tabulation(dev.ctx, 99, 1, 1, p(w), p(B), p(dB)) != 0          # unknown slot
+    assert dev.lib.knp_set_tabulation(dev.ctx, 0, 4, 1, p(w), p(B), p(dB)) != 0           # cell rule with facet layout
+    assert dev.lib.knp_set_tabulation(dev.ctx, 3, 1, 1, p(w), p(B), p(dB)) != 0           # facet rule with cell layout
+    assert dev.lib.knp_amg_columns(dev.ctx, 0, 2) != 0                                    # EMI hierarchy is single-column
+    assert dev.lib.knp_amg_columns(dev.ctx, 1, 99) != 0
+    dev.close()
+    # a degree-2 context whose tabulations were never uploaded must refuse to assemble
+    ctx = C.c_void_p()
+    from knpemidg._abi import load, _p, _f64p, _i32p, _u32p, _i8p
+    lib = load()
+    cells = np.ascontiguousarray(m.cells, dtype=np.int32)
+    mt = np.array([1], dtype=np.uint32)
+    rc = lib.knp_ctx_create(C.byref(ctx), 0, 3, 2, 3, m.num_vertices(), 2, 2, m.num_facets(), _p(np.ascontiguousarray(m.coords), _f64p),
+                            _p(cells, _i32p), _p(s.array().astype(np.uint32), _u32p),
+                            _p(np.ascontiguousarray(m.facet_cells, dtype=np.int32), _i32p),
+                            _p(np.ascontiguousarray(m.facet_local, dtype=np.int8), _i8p), _p(f.array().astype(np.uint32), _u32p), 1,
+                            _p(mt, _u32p))
+    assert rc == 0
+    assert lib.knp_update_kappa(ctx) != 0 and b"tabulation" in lib.knp_last_error(ctx)
+    lib.knp_ctx_destroy(ctx)
