@@ -19,6 +19,7 @@ struct Fields {
     double *r = nullptr, *z = nullptr, *p = nullptr, *w = nullptr, *rhat = nullptr, *v = nullptr, *y = nullptr;
     // previous converged solutions, for the extrapolated initial guess x0 = 2 x_{k-1} - x_{k-2}
     double *hist_emi = nullptr, *hist_knp = nullptr;
+    int bj_age_emi = 0, bj_age_knp = 0;   // solves since the block-Jacobi inverses were rebuilt (lagged like the AMG hierarchy)
     double* tmp_knp = nullptr;     // scratch of the Chebyshev block-Jacobi smoother
     double bj_lmax_knp = 0.0;      // lambda_max(Binv A_knp) estimate (power iteration at the first solve, refreshed rarely)
     int bj_lmax_age = 0;
@@ -261,6 +262,7 @@ int knp_set_params(knp_ctx* c, double C_M, double dt, double Fc, double R, doubl
     p.C_M = C_M; p.dt = dt; p.F = Fc; p.R = R; p.T = T; p.C_phi = C_phi; p.psi = Fc / (R * T);
     p.tau_emi = tau_emi; p.tau_knp = tau_knp; p.splitting = splitting;
     if (splitting == 2 && !c->mms_C) { c->err = "MMS mode needs knp_set_mms first"; return -1; }
+    if (g_fields.count(c)) F(c)->bj_age_emi = F(c)->bj_age_knp = 0;          // new coefficients: rebuild the block-Jacobi inverses
     for (int i = 0; i < p.n_ions; ++i) {
         p.z[i] = z[i];
         if (z[i] == 0.0) { c->err = "ion valence z must be non-zero"; return -1; }
@@ -328,6 +330,8 @@ int knp_upload(knp_ctx* c, int field, const double* src, int64_t offset, int64_t
     if (offset < 0 || count < 0 || offset + count > F(c)->n[field]) { c->err = "upload range out of bounds"; return -1; }
     HIPCHK(c, hipMemcpyAsync(F(c)->f[field] + offset, src, sizeof(double) * count, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    // a caller-supplied state may be far from the one the lagged block-Jacobi inverses were built for
+    if (field == KNP_F_C || field == KNP_F_C_ELIM || field == KNP_F_PHI || field == KNP_F_KAPPA) F(c)->bj_age_emi = F(c)->bj_age_knp = 0;
     return 0;
 }
 
@@ -397,7 +401,12 @@ int knp_knp_rhs(knp_ctx* c) {
 int knp_emi_solve(knp_ctx* c, double rtol, double atol, int maxit, int check_every, int* niter, double* res) {
     if (!c || !niter || !res) return -1;
     Fields* f = F(c);
-    int rc = launch_emi_blockjacobi(c, f->f[KNP_F_KAPPA], f->binv_emi);
+    // the cell-block inverses only precondition: rebuilt every KNP_BJ_LAG-th solve (default 8; the coefficients move by < 1 %
+    // per step), like the lagged AMG hierarchy; 1 = every solve
+    static const int bj_lag = getenv("KNP_BJ_LAG") ? atoi(getenv("KNP_BJ_LAG")) : 8;
+    int rc = 0;
+    if (f->bj_age_emi % (bj_lag > 0 ? bj_lag : 1) == 0) rc = launch_emi_blockjacobi(c, f->f[KNP_F_KAPPA], f->binv_emi);
+    ++f->bj_age_emi;
     if (rc) return rc;
     if ((rc = extrapolate_guess(c, f->f[KNP_F_PHI], &f->hist_emi, &f->have_hist_emi, f->n[KNP_F_PHI]))) return rc;
     KrylovVecs kv{};
@@ -428,7 +437,10 @@ int knp_emi_solve(knp_ctx* c, double rtol, double atol, int maxit, int check_eve
 int knp_knp_solve(knp_ctx* c, double rtol, double atol, int maxit, int min_it, int check_every, int* niter, double* res) {
     if (!c || !niter || !res) return -1;
     Fields* f = F(c);
-    int rc = launch_knp_blockjacobi(c, f->f[KNP_F_DNPHI], f->binv_knp);
+    static const int bj_lag = getenv("KNP_BJ_LAG") ? atoi(getenv("KNP_BJ_LAG")) : 8;
+    int rc = 0;
+    if (f->bj_age_knp % (bj_lag > 0 ? bj_lag : 1) == 0) rc = launch_knp_blockjacobi(c, f->f[KNP_F_DNPHI], f->binv_knp);
+    ++f->bj_age_knp;
     if (rc) return rc;
     if ((rc = extrapolate_guess(c, f->f[KNP_F_C], &f->hist_knp, &f->have_hist_knp, f->n[KNP_F_C]))) return rc;
     KrylovVecs kv{};
