@@ -231,6 +231,7 @@ class Device:
             self.ctx = None
             raise KnpError("knp_ctx_create failed (%d): %s" % (rc, msg.decode() if msg else "?"))
         self.n_geometry_classes = 0
+        self.nranks = 1
         self.degree = int(degree)
         if degree != 1:
             # DG-p path: the device integrates the forms with host-tabulated rules (csrc/tab_dg.hip)
@@ -384,6 +385,7 @@ class Device:
     # -- multi-GPU ---------------------------------------------------------------------
     def comm_init(self, rank, nranks, uid):
         self._chk(self.lib.knp_comm_init(self.ctx, rank, nranks, uid), "knp_comm_init")
+        self.nranks = int(nranks)
 
     def halo_tables(self, peers, send_lists, recv_offsets, recv_counts):
         peers = np.ascontiguousarray(peers, dtype=np.int32)
