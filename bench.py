@@ -139,7 +139,10 @@ def main():
     progress("warm-up done")
     t0 = time.perf_counter()
     for _ in range(args.steps):
+        ts = time.perf_counter()
         S.step_membrane_models(k); S.solve_for_time_step(k, t); k += 1
+        if os.environ.get("KNP_BENCH_STEP_TIMES"):
+            progress("step %d enqueued/solved in %.2f ms" % (k, 1e3 * (time.perf_counter() - ts)))
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
