@@ -19,12 +19,12 @@ from common import synthetic_state, small_3d                   # noqa: E402
 from knpemidg.mesh import make_mesh_2D                         # noqa: E402
 
 
-def one_case(name, mesh_tuple):
+def one_case(name, mesh_tuple, p=1):
     m, s, f = mesh_tuple
-    pb = ko.build_idealized(m, s.array(), f.array(), membrane_tags=(1,))
+    pb = ko.build_idealized(m, s.array(), f.array(), p=p, membrane_tags=(1,))
     x = synthetic_state(pb)
     A, b_emi, _ = ko.assemble_emi(pb, want_B=False)
-    out = dict(coords=m.coords, cells=m.cells, cell_tags=s.array(), facet_tags=f.array(),
+    out = dict(degree=np.int64(p), coords=m.coords, cells=m.cells, cell_tags=s.array(), facet_tags=f.array(),
                facet_cells=m.facet_cells, facet_local=m.facet_local,
                x=x, c=pb.c, c_prev=pb.c_prev_n, c_elim=pb.c_elim, phi=pb.phi, phi_M=pb.phi_M,
                I_ch=np.stack([pb.I_ch[i["name"]] for i in pb.ions]),
@@ -44,3 +44,5 @@ def one_case(name, mesh_tuple):
 if __name__ == "__main__":
     one_case("idealized_2D_r0", make_mesh_2D(0))
     one_case("box_3D_8x4x4", small_3d())
+    one_case("box_3D_6x3x3_P2", small_3d((6, 3, 3)), p=2)
+    one_case("idealized_2D_r0_P2", make_mesh_2D(0), p=2)

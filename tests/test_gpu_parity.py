@@ -115,7 +115,7 @@ def test_step_updates(case):
     assert relerr(Na_i[pb.mem], ref) < 1e-14
 
 
-@pytest.mark.parametrize("name", ["idealized_2D_r0", "box_3D_8x4x4"])
+@pytest.mark.parametrize("name", ["idealized_2D_r0", "box_3D_8x4x4", "box_3D_6x3x3_P2", "idealized_2D_r0_P2"])
 def test_gpu_matches_golden(hip_lib, name):
     """HIP path vs the committed fixtures (tests/golden/*.npz): applies, right-hand sides and one converged
     splitting step.  The 2D r=0 case has membrane-tagged facets between EQUAL-tag cells (the mesh is too
@@ -126,7 +126,7 @@ def test_gpu_matches_golden(hip_lib, name):
     from common import mean_free
     g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".npz"))
     mesh = Mesh(g["coords"], g["cells"])
-    pb = ko.build_idealized(mesh, g["cell_tags"], g["facet_tags"], membrane_tags=(1,))
+    pb = ko.build_idealized(mesh, g["cell_tags"], g["facet_tags"], p=int(g["degree"]) if "degree" in g else 1, membrane_tags=(1,))
     pb.c, pb.c_prev_n, pb.c_elim, pb.phi, pb.phi_M = g["c"], g["c_prev"], g["c_elim"], g["phi"], g["phi_M"]
     for k, ion in enumerate(pb.ions):
         pb.I_ch[ion["name"]] = g["I_ch"][k]

@@ -109,13 +109,13 @@ def test_rest_state_stays_at_rest():
     assert np.abs(E["K"] - EK).max() < 1e-12 and abs(EK + 0.0936) < 2e-4       # SURVEY: E_K ~ -93.6 mV
 
 
-@pytest.mark.parametrize("name", ["idealized_2D_r0", "box_3D_8x4x4"])
+@pytest.mark.parametrize("name", ["idealized_2D_r0", "box_3D_8x4x4", "box_3D_6x3x3_P2", "idealized_2D_r0_P2"])
 def test_oracle_matches_golden(name):
     from knpemidg.mesh import Mesh
     g = np.load(os.path.join(GOLD, name + ".npz"))
     mesh = Mesh(g["coords"], g["cells"])
     assert np.array_equal(mesh.facet_cells, g["facet_cells"]) and np.array_equal(mesh.facet_local, g["facet_local"])
-    pb = ko.build_idealized(mesh, g["cell_tags"], g["facet_tags"], membrane_tags=(1,))
+    pb = ko.build_idealized(mesh, g["cell_tags"], g["facet_tags"], p=int(g["degree"]) if "degree" in g else 1, membrane_tags=(1,))
     pb.c, pb.c_prev_n, pb.c_elim, pb.phi, pb.phi_M = g["c"], g["c_prev"], g["c_elim"], g["phi"], g["phi_M"]
     for k, ion in enumerate(pb.ions):
         pb.I_ch[ion["name"]] = g["I_ch"][k]
