@@ -39,7 +39,7 @@ enum knp_field {
     KNP_F_B_KNP = 10,    /* assembled L_knp                  [n_sys][nc*nd]   bb_knp              solver.py:731 */
     KNP_F_X = 11,        /* scratch vector                   [n_sys][nc*nd] */
     KNP_F_Y = 12,        /* scratch vector                   [n_sys][nc*nd] */
-    KNP_F_FACET_TMP = 13,/* scratch facet field              [nf] */
+    KNP_F_FACET_TMP = 13,/* scratch facet fields             [KNP_FACET_TMP_SLOTS][nf]   results of pcws_constant_project */
     KNP_F_COUNT = 14
 };
 
@@ -159,9 +159,11 @@ int knp_nernst(knp_ctx* ctx);              /* E only, from the current C / C_ELI
  * knp_max_abs_diff = inf-norm of the difference of two nodal fields (the eps of solver.py:879-880). */
 int knp_picard_updates(knp_ctx* ctx);
 int knp_max_abs_diff(knp_ctx* ctx, int field_a, int field_b, double* out);
-/* FACET_TMP <- facet average of the plus (side 0, ECS-like) or minus (side 1) trace of a nodal field;
- * species indexes into [n_sys] fields (update_ode hook, examples/idealized-geometries/run_3D.py:39-51). */
-int knp_facet_trace(knp_ctx* ctx, int field, int species, int side);
+/* FACET_TMP[slot] <- facet average of the plus (side 0, ECS-like) or minus (side 1) trace of a nodal field;
+ * species indexes into [n_sys] fields (update_ode hook, examples/idealized-geometries/run_3D.py:39-51).  Several slots, so
+ * that consecutive projections (K_e, Na_i, ...) do not overwrite each other before they are consumed. */
+#define KNP_FACET_TMP_SLOTS 4
+int knp_facet_trace(knp_ctx* ctx, int field, int species, int side, int slot);
 
 /* ---- membrane ODEs: batched device integrator replacing the per-facet LSODA loop of
  * MembraneModel.step_lsoda (membrane.py:84-119).  model: 1 = Hodgkin-Huxley + stimulus (mm_hh.py), 2 = without
@@ -170,11 +172,20 @@ int knp_facet_trace(knp_ctx* ctx, int field, int species, int side);
  *  knp_ode_table   : what 0 = states, 1 = parameters; upload != 0 copies host -> device, else device -> host
  *  knp_ode_exchange: table column <- facet field (to_facet = 0, set_state/set_parameter) or facet field <- table
  *                    column (to_facet = 1, get_state/get_parameter); offset selects the row of [n_ions][nf] fields
- *  knp_ode_step    : adaptive Dormand-Prince 5(4) from t0 to t0+dt per node; -4 if a node fails (assert success) */
+ *  knp_ode_exchange_multi: n such copies in ONE launch (what[k], col[k], field[k], offset[k]); a membrane step moves V, E_k,
+ *                    K_e, Na_i in and V, I_ch_k out (solver.py:1086-1112)
+ *  knp_ode_set_stimulus: parameter columns cols[k] take values[k] on the rows with mask[row] != 0 at the start of EVERY
+ *                    knp_ode_step (the reference re-imposes the stimulus every step, membrane.py:98-104); 0 entries clears
+ *  knp_ode_step    : adaptive Dormand-Prince 5(4) from t0 to t0+dt per node (rtol 1e-8, atol 0: membrane.py:112).
+ *                    Asynchronous: a node that fails (`assert success`, membrane.py:113) raises a device flag that the next
+ *                    knp_emi_solve / knp_knp_solve status poll, knp_ode_table or knp_sync reports as -4 */
 int knp_ode_create(knp_ctx* ctx, int model, int64_t n, const int32_t* facets, int ns, int np, const double* states,
                    const double* params);
 int knp_ode_table(knp_ctx* ctx, int handle, int what, int upload, double* host);
 int knp_ode_exchange(knp_ctx* ctx, int handle, int what, int col, int field, int64_t offset, int to_facet);
+int knp_ode_exchange_multi(knp_ctx* ctx, int handle, int n, const int32_t* what, const int32_t* col, const int32_t* field,
+                           const int64_t* offset, int to_facet);
+int knp_ode_set_stimulus(knp_ctx* ctx, int handle, int n_entries, const int32_t* cols, const double* values, const uint8_t* mask);
 int knp_ode_step(knp_ctx* ctx, int handle, double t0, double dt, double rtol, double atol);
 
 /* ---- timing / sync ------------------------------------------------------------------------------ */

@@ -21,8 +21,9 @@ struct Fields {
     double *hist_emi = nullptr, *hist_knp = nullptr;
     int bj_age_emi = 0, bj_age_knp = 0;   // solves since the block-Jacobi inverses were rebuilt (lagged like the AMG hierarchy)
     double* tmp_knp = nullptr;     // scratch of the Chebyshev block-Jacobi smoother
-    double bj_lmax_knp = 0.0;      // lambda_max(Binv A_knp) estimate (power iteration at the first solve, refreshed rarely)
-    int bj_lmax_age = 0;
+    double bj_lmax_knp = 0.0;      // lambda_max(Binv A_knp) estimate (power iteration; redone after every reset of the lagged
+    int bj_lmax_age = 0;           // inverses, every 64 solves, and when the iteration count jumps by > 1.5x)
+    int it_ref_knp = 0, it_ref_emi = 0;   // iteration counts right after the last estimate
     double* tmp_emi = nullptr;
     double bj_lmax_emi = 0.0;
     int bj_lmax_emi_age = 0;
@@ -50,6 +51,13 @@ static int extrapolate_guess(knp_ctx* c, double* x, double** hist, bool* have, i
     HIPCHK(c, hipGetLastError());
     *have = true;
     return 0;
+}
+
+// everything that is lagged behind the coefficients: the block-Jacobi inverses AND the spectral bound of the Chebyshev
+// block-Jacobi smoother built on them (a stale / too small lambda_max makes the polynomial amplify the top modes)
+static void reset_lagged(Fields* f) {
+    f->bj_age_emi = f->bj_age_knp = 0;
+    f->bj_lmax_knp = f->bj_lmax_emi = 0.0;
 }
 
 std::map<knp_ctx*, Fields*> g_fields;
@@ -201,7 +209,7 @@ int knp_ctx_create(knp_ctx** out, int device, int dim, int degree, int n_ions, i
     Fields* fl = new Fields();
     const int64_t ndof = nc * ND, ns = c->p.n_sys;
     const int64_t sizes[KNP_F_COUNT] = {ndof, ns * ndof, ns * ndof, ndof, nf, n_ions * nf, n_ions * nf, ndof, ndof,
-                                        ndof, ns * ndof, ns * ndof, ns * ndof, nf};
+                                        ndof, ns * ndof, ns * ndof, ns * ndof, (int64_t)KNP_FACET_TMP_SLOTS * nf};
     for (int i = 0; i < KNP_F_COUNT; ++i) {
         fl->n[i] = sizes[i];
         rc |= dev_zeros(c, &fl->f[i], sizes[i]);
@@ -215,8 +223,8 @@ int knp_ctx_create(knp_ctx** out, int device, int dim, int degree, int n_ions, i
     c->partial_blocks = grid_for(nc_owned) + 8;
     rc |= dev_zeros(c, &c->partial, (size_t)c->partial_blocks * KNP_MAX_SYS * KNP_MAX_RED);
     rc |= dev_zeros(c, &c->scal, KNP_MAX_SYS * KS_N + KNP_MAX_SYS * KNP_MAX_RED);
-    if (!rc && hipMalloc((void**)&c->status, sizeof(int) * 2 * KNP_MAX_SYS) != hipSuccess) rc = -2;
-    if (!rc) hipMemset(c->status, 0, sizeof(int) * 2 * KNP_MAX_SYS);
+    if (!rc && hipMalloc((void**)&c->status, sizeof(int) * KNP_STATUS_WORDS) != hipSuccess) rc = -2;
+    if (!rc) hipMemset(c->status, 0, sizeof(int) * KNP_STATUS_WORDS);
     if (!rc && hipHostMalloc(&c->pinned, 4096) != hipSuccess) rc = -2;
     if (rc) { g_err = "device allocation failed: " + c->err; delete fl; delete c; return -2; }
     g_fields[c] = fl;
@@ -262,7 +270,7 @@ int knp_set_params(knp_ctx* c, double C_M, double dt, double Fc, double R, doubl
     p.C_M = C_M; p.dt = dt; p.F = Fc; p.R = R; p.T = T; p.C_phi = C_phi; p.psi = Fc / (R * T);
     p.tau_emi = tau_emi; p.tau_knp = tau_knp; p.splitting = splitting;
     if (splitting == 2 && !c->mms_C) { c->err = "MMS mode needs knp_set_mms first"; return -1; }
-    if (g_fields.count(c)) F(c)->bj_age_emi = F(c)->bj_age_knp = 0;          // new coefficients: rebuild the block-Jacobi inverses
+    if (g_fields.count(c)) reset_lagged(F(c));                               // new coefficients: rebuild the block-Jacobi inverses
     for (int i = 0; i < p.n_ions; ++i) {
         p.z[i] = z[i];
         if (z[i] == 0.0) { c->err = "ion valence z must be non-zero"; return -1; }
@@ -331,7 +339,7 @@ int knp_upload(knp_ctx* c, int field, const double* src, int64_t offset, int64_t
     HIPCHK(c, hipMemcpyAsync(F(c)->f[field] + offset, src, sizeof(double) * count, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     // a caller-supplied state may be far from the one the lagged block-Jacobi inverses were built for
-    if (field == KNP_F_C || field == KNP_F_C_ELIM || field == KNP_F_PHI || field == KNP_F_KAPPA) F(c)->bj_age_emi = F(c)->bj_age_knp = 0;
+    if (field == KNP_F_C || field == KNP_F_C_ELIM || field == KNP_F_PHI || field == KNP_F_KAPPA) reset_lagged(F(c));
     return 0;
 }
 
@@ -419,17 +427,19 @@ int knp_emi_solve(knp_ctx* c, double rtol, double atol, int maxit, int check_eve
     if (cheb_emi && c->amg.size() && c->amg[0].ready) {
         if (!f->tmp_emi) HIPCHK(c, hipMalloc((void**)&f->tmp_emi, sizeof(double) * f->n[KNP_F_PHI]));
         kv.tmp = f->tmp_emi;
-        if (f->bj_lmax_emi <= 0.0 || ++f->bj_lmax_emi_age >= 200) {
+        if (f->bj_lmax_emi <= 0.0 || ++f->bj_lmax_emi_age >= 64 || (f->it_ref_emi > 0 && 2 * c->last_it_emi > 3 * f->it_ref_emi + 2)) {
             double lam = 0.0;
             if ((rc = knp_bj_lambda_max(c, kv, 20, &lam, true))) return rc;
             f->bj_lmax_emi = 1.1 * lam;
             f->bj_lmax_emi_age = 0;
+            f->it_ref_emi = -1;
             if (getenv("KNP_DEBUG")) fprintf(stderr, "[knp] lambda_max(Binv A_emi) ~ %.4f\n", lam);
         }
         kv.bj_lmax = f->bj_lmax_emi;
     }
     rc = pcg_solve(c, kv, rtol, atol, maxit, check_every, niter, res);
     if (rc) return rc;
+    if (f->it_ref_emi < 0) f->it_ref_emi = c->last_it_emi;
     if (c->dist) return halo_exchange(c, kv.x, 1);     // ghostUpdate (solver.py:529)
     return 0;
 }
@@ -455,17 +465,19 @@ int knp_knp_solve(knp_ctx* c, double rtol, double atol, int maxit, int min_it, i
     if (cheb && c->p.n_sys <= 4) {
         if (!f->tmp_knp) HIPCHK(c, hipMalloc((void**)&f->tmp_knp, sizeof(double) * f->n[KNP_F_C]));
         kv.tmp = f->tmp_knp;
-        if (f->bj_lmax_knp <= 0.0 || ++f->bj_lmax_age >= 200) {
+        if (f->bj_lmax_knp <= 0.0 || ++f->bj_lmax_age >= 64 || (f->it_ref_knp > 0 && 2 * c->last_it_knp > 3 * f->it_ref_knp + 2)) {
             double lam = 0.0;
             if ((rc = knp_bj_lambda_max(c, kv, 20, &lam))) return rc;
             f->bj_lmax_knp = 1.1 * lam;                 // the power iteration approaches lambda_max from below
             f->bj_lmax_age = 0;
+            f->it_ref_knp = -1;
             if (getenv("KNP_DEBUG")) fprintf(stderr, "[knp] lambda_max(Binv A_knp) ~ %.4f\n", lam);
         }
         kv.bj_lmax = f->bj_lmax_knp;
     }
     rc = bicgstab_solve(c, kv, rtol, atol, maxit, min_it, check_every, niter, res);
     if (rc) return rc;
+    if (f->it_ref_knp < 0) f->it_ref_knp = c->last_it_knp;
     if (c->dist) return halo_exchange(c, kv.x, c->p.n_sys);   // ghostUpdate (solver.py:789)
     return 0;
 }
@@ -499,17 +511,19 @@ int knp_nernst(knp_ctx* c) {
     return launch_nernst_only(c, f->f[KNP_F_C], f->f[KNP_F_C_ELIM], f->f[KNP_F_E]);
 }
 
-int knp_facet_trace(knp_ctx* c, int field, int species, int side) {
+int knp_facet_trace(knp_ctx* c, int field, int species, int side, int slot) {
     if (chk_field(c, field)) return -1;
     if (side != 0 && side != 1) { c->err = "side must be 0 (plus) or 1 (minus)"; return -1; }
+    if (slot < 0 || slot >= KNP_FACET_TMP_SLOTS) { c->err = "facet_trace: scratch slot out of range"; return -1; }
     const int64_t ndof = c->m.nc * c->nd;
     if (species < 0 || (int64_t)(species + 1) * ndof > F(c)->n[field]) { c->err = "facet_trace: species out of range"; return -1; }
-    return launch_facet_trace(c, F(c)->f[field] + (int64_t)species * ndof, side, F(c)->f[KNP_F_FACET_TMP]);
+    return launch_facet_trace(c, F(c)->f[field] + (int64_t)species * ndof, side, F(c)->f[KNP_F_FACET_TMP] + (int64_t)slot * c->m.nf);
 }
 
 int knp_sync(knp_ctx* c) {
     if (!c) return -1;
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (ode_check_failed(c)) return -4;
     return 0;
 }
 

@@ -105,7 +105,7 @@ int knp_comm_init(knp_ctx* c, int rank, int nranks, const char* id128) {
     c->nranks = nranks;
     // KNP_FORCE_COMM=1: build the communicator and take every collective code path even with one rank (a 1-GPU box can
     // then exercise ncclCommInitRank / ncclAllReduce on the solver's stream; RCCL refuses two ranks on one device)
-    if (nranks == 1 && !getenv("KNP_FORCE_COMM")) return 0;
+    if (nranks == 1 && !(getenv("KNP_FORCE_COMM") && atoi(getenv("KNP_FORCE_COMM")) == 1)) return 0;
     ncclUniqueId id;
     memcpy(&id, id128, sizeof(id));
     HIPCHK(c, hipSetDevice(c->device));

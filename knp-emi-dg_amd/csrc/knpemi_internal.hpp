@@ -17,6 +17,8 @@ typedef float bjreal;
 #define KNP_MAX_SYS 7           // solved species (batched KNP systems)
 #define KNP_BLOCK 256
 #define KNP_MAX_RED 8           // partial sums per block per system in one reduction pass
+#define KNP_ODE_FAIL_SLOT (2 * KNP_MAX_SYS)   // word of knp_ctx::status raised by k_ode_step (read back with the solver status)
+#define KNP_STATUS_WORDS (2 * KNP_MAX_SYS + 1)
 
 // facet kinds stored in bits 2..3 of the per-(cell, local facet) flag byte
 enum : uint32_t { FK_SIPG = 0u, FK_MEMBRANE = 1u, FK_EXTERIOR = 2u, FK_INACTIVE = 3u };
@@ -89,7 +91,7 @@ struct knp_ctx {
     double* partial = nullptr;     // [grid][KNP_MAX_SYS][KNP_MAX_RED]
     int64_t partial_blocks = 0;
     double* scal = nullptr;        // device scalars
-    int* status = nullptr;         // device: [0]=converged flag, [1]=iterations
+    int* status = nullptr;         // device: per system {converged flag, iterations}, then the ODE failure flag
     void* pinned = nullptr;        // host pinned mirror for status/scalars
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int last_it_emi = 0, last_it_knp = 0;   // iteration counts of the previous solves (chunking of the status polls)
@@ -154,3 +156,4 @@ void comm_destroy(knp_ctx* c);
 int allreduce_red(knp_ctx* c, double* red, int count);
 int allreduce_max(knp_ctx* c, double* host_value);
 int max_abs_diff(knp_ctx* c, const double* a, const double* b, int nsys, double* out);
+int ode_check_failed(knp_ctx* c);   // ode.hip: reads and clears the ODE failure flag (stream idle); sets c->err

@@ -172,7 +172,7 @@ __device__ void scalar_op(int op, int s, const double* red, double* scal, int* s
             *flag = (R[0] == 0.0) ? 1 : 0;   // exact zero residual: nothing to do (rest state)
         } break;
         case OP_BI_ALPHA: {             // R: rhat.v
-            if (R[0] == 0.0) { *flag = 2; S[KS_ALPHA] = 0.0; }
+            if (R[0] == 0.0) { *flag = (S[KS_RES] <= S[KS_TOL]) ? 1 : 2; S[KS_ALPHA] = 0.0; }   // breakdown at a converged residual (forced min_it iterations of a steady state) is convergence
             else S[KS_ALPHA] = S[KS_RHO] / R[0];
         } break;
         case OP_BI_OMEGA: {             // R: t.s, t.t
@@ -548,9 +548,14 @@ static int finalize(knp_ctx* c, int op, int nsys, int nred, double rtol, double 
 }
 
 static int poll_status(knp_ctx* c, int nsys, int* host_status) {
-    HIPCHK(c, hipMemcpyAsync(c->pinned, c->status, sizeof(int) * 2 * nsys, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->pinned, c->status, sizeof(int) * KNP_STATUS_WORDS, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     for (int i = 0; i < 2 * nsys; ++i) host_status[i] = ((int*)c->pinned)[i];
+    if (((int*)c->pinned)[KNP_ODE_FAIL_SLOT]) {      // raised by k_ode_step earlier in this time step (`assert success`, membrane.py:113)
+        hipMemsetAsync(c->status + KNP_ODE_FAIL_SLOT, 0, sizeof(int), c->stream);
+        c->err = "ODE integrator did not reach the end time";
+        return -4;
+    }
     return 0;
 }
 

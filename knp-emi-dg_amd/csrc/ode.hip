@@ -9,6 +9,8 @@
 
 #define ODE_MAX_STATES 4
 #define ODE_MAX_PARAMS 20
+#define ODE_MAX_STIM 4
+#define ODE_MAX_OPS 12
 
 struct OdeSet {
     int model = 0;              // 1 = HH with synaptic stimulus, 2 = HH without, 3 = EMIx HH (cm/ms/mV), 4 = glial
@@ -18,8 +20,14 @@ struct OdeSet {
     double* states = nullptr;   // [n][ns]
     double* params = nullptr;   // [n][np]
     double* h = nullptr;        // [n] last accepted step size
-    int* fail = nullptr;        // device flag
+    int* fail = nullptr;        // device flag: the context's status word KNP_ODE_FAIL_SLOT (read back with the next status poll)
+    uint8_t* stim_mask = nullptr;   // [n] rows on which the stimulus parameters are re-imposed every step (membrane.py:98-104)
+    int n_stim = 0;
+    int stim_col[ODE_MAX_STIM] = {0};
+    double stim_val[ODE_MAX_STIM] = {0};
 };
+
+struct StimArgs { int n; int col[ODE_MAX_STIM]; double val[ODE_MAX_STIM]; };
 
 static std::map<knp_ctx*, std::vector<OdeSet>> g_ode;
 
@@ -108,7 +116,8 @@ template <int MODEL> __device__ __forceinline__ void model_rhs(double t, const d
 template <int MODEL, int NS, int NP>
 __global__ __launch_bounds__(64) void k_ode_step(int64_t n, double t0, double t1, double rtol, double atol, int max_steps,
                                                  double* __restrict__ states, double* __restrict__ params,
-                                                 double* __restrict__ hstore, int* __restrict__ fail) {
+                                                 double* __restrict__ hstore, int* __restrict__ fail,
+                                                 const uint8_t* __restrict__ stim_mask, StimArgs stim) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     double y[NS], p[NP], k[7][NS];
@@ -116,6 +125,14 @@ __global__ __launch_bounds__(64) void k_ode_step(int64_t n, double t0, double t1
     for (int s = 0; s < NS; ++s) y[s] = states[i * NS + s];
 #pragma unroll
     for (int q = 0; q < NP; ++q) p[q] = params[i * NP + q];
+    // the stimulus overwrites its parameters on the masked rows at the start of EVERY step (membrane.py:102-104), whatever a
+    // hook or a parameter upload wrote there in between
+    if (stim.n > 0 && stim_mask[i]) {
+        for (int e = 0; e < stim.n; ++e)
+#pragma unroll
+            for (int q = 0; q < NP; ++q)
+                if (q == stim.col[e]) p[q] = stim.val[e];
+    }
     // Dormand-Prince 5(4)
     const double C[7] = {0, 1.0 / 5, 3.0 / 10, 4.0 / 5, 8.0 / 9, 1, 1};
     const double A[7][6] = {{0, 0, 0, 0, 0, 0},
@@ -156,7 +173,7 @@ __global__ __launch_bounds__(64) void k_ode_step(int64_t n, double t0, double t1
 #pragma unroll
             for (int j = 0; j < 7; ++j) { a5 += B5[j] * k[j][q]; ae += (B5[j] - B4[j]) * k[j][q]; }
             y5[q] = y[q] + hh * a5;
-            const double scale = atol + rtol * fmax(fabs(y[q]), fabs(y5[q]));
+            const double scale = fmax(atol + rtol * fmax(fabs(y[q]), fabs(y5[q])), 1e-300);   // atol = 0 is the reference's (membrane.py:112)
             e = fmax(e, fabs(hh * ae) / scale);
         }
         if (!(e == e) || isinf(e)) e = 1e10;
@@ -192,7 +209,31 @@ __global__ void k_ode_to_facet(int64_t n, const int32_t* __restrict__ facet, con
     if (i < n) field[facet[i]] = table[i * stride + col];
 }
 
+// the same for a list of columns in ONE launch (a membrane step moves V, E_k, K_e, Na_i in and V, I_ch_k out)
+struct OdeOps { int n; int stride[ODE_MAX_OPS]; int col[ODE_MAX_OPS]; double* table[ODE_MAX_OPS]; double* field[ODE_MAX_OPS]; };
+__global__ void k_ode_exchange_multi(int64_t n, const int32_t* __restrict__ facet, OdeOps ops, int to_facet) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int f = facet[i];
+    for (int k = 0; k < ops.n; ++k) {
+        double* t = ops.table[k] + i * ops.stride[k] + ops.col[k];
+        if (to_facet) ops.field[k][f] = *t;
+        else *t = ops.field[k][f];
+    }
+}
+
 double* knp_field_ptr(knp_ctx* c, int field, int64_t* n);   // abi.hip
+
+// `assert success` of membrane.py:113, deferred: knp_ode_step does not synchronise; the flag travels with the next status poll of
+// a solve (krylov.hip: poll_status), a table download or knp_sync.  Call with the stream idle.
+int ode_check_failed(knp_ctx* c) {
+    int fail = 0;
+    if (hipMemcpy(&fail, c->status + KNP_ODE_FAIL_SLOT, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return 0;
+    if (!fail) return 0;
+    hipMemset(c->status + KNP_ODE_FAIL_SLOT, 0, sizeof(int));
+    c->err = "ODE integrator did not reach the end time";
+    return 1;
+}
 
 static OdeSet* get_set(knp_ctx* c, int handle) {
     auto it = g_ode.find(c);
@@ -203,7 +244,7 @@ static OdeSet* get_set(knp_ctx* c, int handle) {
 void ode_destroy_all(knp_ctx* c) {
     auto it = g_ode.find(c);
     if (it == g_ode.end()) return;
-    for (auto& S : it->second) { hipFree(S.facet); hipFree(S.states); hipFree(S.params); hipFree(S.h); hipFree(S.fail); }
+    for (auto& S : it->second) { hipFree(S.facet); hipFree(S.states); hipFree(S.params); hipFree(S.h); hipFree(S.stim_mask); }
     g_ode.erase(it);
 }
 
@@ -224,9 +265,10 @@ int knp_ode_create(knp_ctx* c, int model, int64_t n, const int32_t* facets, int 
     HIPCHK(c, hipMalloc((void**)&S.states, m * ns * sizeof(double)));
     HIPCHK(c, hipMalloc((void**)&S.params, m * np * sizeof(double)));
     HIPCHK(c, hipMalloc((void**)&S.h, m * sizeof(double)));
-    HIPCHK(c, hipMalloc((void**)&S.fail, sizeof(int)));
+    HIPCHK(c, hipMalloc((void**)&S.stim_mask, m));
+    HIPCHK(c, hipMemset(S.stim_mask, 0, m));
+    S.fail = c->status + KNP_ODE_FAIL_SLOT;
     HIPCHK(c, hipMemset(S.h, 0, m * sizeof(double)));
-    HIPCHK(c, hipMemset(S.fail, 0, sizeof(int)));
     if (n) {
         HIPCHK(c, hipMemcpy(S.facet, facets, n * sizeof(int32_t), hipMemcpyHostToDevice));
         HIPCHK(c, hipMemcpy(S.states, states, n * ns * sizeof(double), hipMemcpyHostToDevice));
@@ -243,6 +285,7 @@ int knp_ode_table(knp_ctx* c, int handle, int what, int upload, double* host) {
     double* dev = what == 0 ? S->states : S->params;
     const size_t bytes = (size_t)S->n * (what == 0 ? S->ns : S->np) * sizeof(double);
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (ode_check_failed(c)) return -4;
     if (bytes) HIPCHK(c, hipMemcpy(upload ? (void*)dev : (void*)host, upload ? (void*)host : (void*)dev, bytes,
                                    upload ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost));
     return 0;
@@ -265,25 +308,68 @@ int knp_ode_exchange(knp_ctx* c, int handle, int what, int col, int field, int64
     return 0;
 }
 
+int knp_ode_set_stimulus(knp_ctx* c, int handle, int n_entries, const int32_t* cols, const double* values, const uint8_t* mask) {
+    OdeSet* S = get_set(c, handle);
+    if (!S) return -1;
+    if (n_entries < 0 || n_entries > ODE_MAX_STIM) { c->err = "ode_set_stimulus: at most 4 stimulus parameters"; return -1; }
+    for (int e = 0; e < n_entries; ++e)
+        if (cols[e] < 0 || cols[e] >= S->np) { c->err = "ode_set_stimulus: parameter column out of range"; return -1; }
+    S->n_stim = n_entries;
+    for (int e = 0; e < n_entries; ++e) { S->stim_col[e] = cols[e]; S->stim_val[e] = values[e]; }
+    if (n_entries && S->n) {
+        if (!mask) { c->err = "ode_set_stimulus: mask missing"; return -1; }
+        HIPCHK(c, hipMemcpyAsync(S->stim_mask, mask, (size_t)S->n, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    return 0;
+}
+
+int knp_ode_exchange_multi(knp_ctx* c, int handle, int n, const int32_t* what, const int32_t* col, const int32_t* field,
+                           const int64_t* offset, int to_facet) {
+    OdeSet* S = get_set(c, handle);
+    if (!S || n < 0 || (n && (!what || !col || !field || !offset))) return -1;
+    for (int k0 = 0; k0 < n; k0 += ODE_MAX_OPS) {
+        OdeOps ops;
+        ops.n = (n - k0 < ODE_MAX_OPS) ? n - k0 : ODE_MAX_OPS;
+        for (int k = 0; k < ops.n; ++k) {
+            int64_t nfld = 0;
+            double* f = knp_field_ptr(c, field[k0 + k], &nfld);
+            const int stride = what[k0 + k] == 0 ? S->ns : S->np;
+            if (!f || col[k0 + k] < 0 || col[k0 + k] >= stride || offset[k0 + k] < 0 || offset[k0 + k] + c->m.nf > nfld) {
+                c->err = "ode_exchange: bad field / column";
+                return -1;
+            }
+            ops.stride[k] = stride; ops.col[k] = col[k0 + k];
+            ops.table[k] = what[k0 + k] == 0 ? S->states : S->params;
+            ops.field[k] = f + offset[k0 + k];
+        }
+        if (!S->n || !ops.n) continue;
+        hipLaunchKernelGGL(k_ode_exchange_multi, dim3((unsigned)((S->n + 255) / 256)), dim3(256), 0, c->stream, S->n, S->facet, ops, to_facet);
+        HIPCHK(c, hipGetLastError());
+    }
+    return 0;
+}
+
+// Asynchronous: a node that cannot reach t0 + dt raises the context's ODE failure flag, reported (-4) by the next solve's status
+// poll, table download or knp_sync -- no host round trip per membrane model and step.
 int knp_ode_step(knp_ctx* c, int handle, double t0, double dt, double rtol, double atol) {
     OdeSet* S = get_set(c, handle);
     if (!S) return -1;
     if (!S->n) return 0;
     const dim3 g((unsigned)((S->n + 63) / 64)), b(64);
     const int max_steps = 100000;
-    if (S->model == 1)
-        hipLaunchKernelGGL((k_ode_step<1, 4, 17>), g, b, 0, c->stream, S->n, t0, t0 + dt, rtol, atol, max_steps, S->states, S->params, S->h, S->fail);
-    else if (S->model == 2)
-        hipLaunchKernelGGL((k_ode_step<2, 4, 17>), g, b, 0, c->stream, S->n, t0, t0 + dt, rtol, atol, max_steps, S->states, S->params, S->h, S->fail);
-    else if (S->model == 3)
-        hipLaunchKernelGGL((k_ode_step<3, 4, 17>), g, b, 0, c->stream, S->n, t0, t0 + dt, rtol, atol, max_steps, S->states, S->params, S->h, S->fail);
-    else
-        hipLaunchKernelGGL((k_ode_step<4, 1, 19>), g, b, 0, c->stream, S->n, t0, t0 + dt, rtol, atol, max_steps, S->states, S->params, S->h, S->fail);
+    StimArgs st;
+    st.n = S->n_stim;
+    for (int e = 0; e < ODE_MAX_STIM; ++e) { st.col[e] = S->stim_col[e]; st.val[e] = S->stim_val[e]; }
+#define ODE_LAUNCH(MODEL, NS, NP)                                                                                          \
+    hipLaunchKernelGGL((k_ode_step<MODEL, NS, NP>), g, b, 0, c->stream, S->n, t0, t0 + dt, rtol, atol, max_steps, S->states, \
+                       S->params, S->h, S->fail, (const uint8_t*)S->stim_mask, st)
+    if (S->model == 1) ODE_LAUNCH(1, 4, 17);
+    else if (S->model == 2) ODE_LAUNCH(2, 4, 17);
+    else if (S->model == 3) ODE_LAUNCH(3, 4, 17);
+    else ODE_LAUNCH(4, 1, 19);
+#undef ODE_LAUNCH
     HIPCHK(c, hipGetLastError());
-    int fail = 0;
-    HIPCHK(c, hipMemcpyAsync(&fail, S->fail, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (fail) { c->err = "ODE integrator did not reach the end time"; return -4; }   // `assert success`, membrane.py:113
     return 0;
 }
 

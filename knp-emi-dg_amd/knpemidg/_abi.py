@@ -15,6 +15,8 @@ LIB_PATH = os.path.join(_HERE, "libknpemi_hip.so")
 F_PHI, F_C, F_C_PREV, F_C_ELIM, F_PHI_M, F_I_CH, F_E, F_KAPPA, F_DNPHI, F_B_EMI, F_B_KNP, F_X, F_Y, \
     F_FACET_TMP = range(14)
 
+FACET_TMP_SLOTS = 4        # KNP_FACET_TMP_SLOTS (include/knpemi_hip.h)
+
 _f64p = C.POINTER(C.c_double)
 _i32p = C.POINTER(C.c_int32)
 _i64p = C.POINTER(C.c_int64)
@@ -48,7 +50,7 @@ SIGNATURES = {
     "knp_nernst": (C.c_int, [_ctxp]),
     "knp_picard_updates": (C.c_int, [_ctxp]),
     "knp_max_abs_diff": (C.c_int, [_ctxp, C.c_int, C.c_int, _f64p]),
-    "knp_facet_trace": (C.c_int, [_ctxp, C.c_int, C.c_int, C.c_int]),
+    "knp_facet_trace": (C.c_int, [_ctxp, C.c_int, C.c_int, C.c_int, C.c_int]),
     "knp_sync": (C.c_int, [_ctxp]),
     "knp_timer_begin": (C.c_int, [_ctxp]),
     "knp_timer_end": (C.c_int, [_ctxp, C.POINTER(C.c_float)]),
@@ -60,6 +62,8 @@ SIGNATURES = {
     "knp_ode_create": (C.c_int, [_ctxp, C.c_int, C.c_int64, _i32p, C.c_int, C.c_int, _f64p, _f64p]),
     "knp_ode_table": (C.c_int, [_ctxp, C.c_int, C.c_int, C.c_int, _f64p]),
     "knp_ode_exchange": (C.c_int, [_ctxp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int]),
+    "knp_ode_exchange_multi": (C.c_int, [_ctxp, C.c_int, C.c_int, _i32p, _i32p, _i32p, _i64p, C.c_int]),
+    "knp_ode_set_stimulus": (C.c_int, [_ctxp, C.c_int, C.c_int, _i32p, _f64p, C.POINTER(C.c_uint8)]),
     "knp_ode_step": (C.c_int, [_ctxp, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double]),
     "knp_amg_begin": (C.c_int, [_ctxp, C.c_int, C.c_int64, _i32p, _i32p, _i32p]),
     "knp_amg_columns": (C.c_int, [_ctxp, C.c_int, C.c_int]),
@@ -233,6 +237,9 @@ class Device:
         self.n_geometry_classes = 0
         self.nranks = 1
         self.degree = int(degree)
+        self._pending = []                 # queued PDE<->ODE column copies: (handle, to_facet, what, col, field, offset)
+        self._tmp_slot = -1                # rotating scratch slot of facet_trace results
+        self._tmp_gen = [0] * FACET_TMP_SLOTS
         if degree != 1:
             # DG-p path: the device integrates the forms with host-tabulated rules (csrc/tab_dg.hip)
             from knpemidg import dgtab
@@ -363,8 +370,21 @@ class Device:
         self._chk(self.lib.knp_nernst(self.ctx), "knp_nernst")
 
     def facet_trace(self, field, species, side, download=True):
-        self._chk(self.lib.knp_facet_trace(self.ctx, field, species, side), "knp_facet_trace")
-        return self.download(F_FACET_TMP) if download else None
+        """Facet average of a trace into the next scratch slot of F_FACET_TMP.  download=True returns the values
+        ([nf] array); otherwise returns (slot, generation) -- the slot is recycled after FACET_TMP_SLOTS further
+        projections, `tmp_slot_valid` tells whether a result is still there."""
+        self._tmp_slot = slot = (self._tmp_slot + 1) % FACET_TMP_SLOTS
+        # queued ODE copies that still read this slot must run before it is overwritten
+        if any(f == F_FACET_TMP and off == slot * self.nf for (_, _, _, _, f, off) in self._pending):
+            self._flush()
+        self._tmp_gen[slot] += 1
+        self._chk(self.lib.knp_facet_trace(self.ctx, field, species, side, slot), "knp_facet_trace")
+        if download:
+            return self.download(F_FACET_TMP, slot * self.nf, self.nf)
+        return slot, self._tmp_gen[slot]
+
+    def tmp_slot_valid(self, slot, gen):
+        return self._tmp_gen[slot] == gen
 
     def sync(self):
         self._chk(self.lib.knp_sync(self.ctx), "knp_sync")
@@ -414,10 +434,37 @@ class Device:
         return a
 
     def ode_exchange(self, handle, what, col, field, row, to_facet):
-        self._chk(self.lib.knp_ode_exchange(self.ctx, handle, what, int(col), field, int(row) * self.nf, int(to_facet)),
-                  "knp_ode_exchange")
+        """Queue one PDE<->ODE column copy.  Consecutive copies of one membrane model and direction leave as ONE
+        kernel (knp_ode_exchange_multi) the next time anything else touches the device (`_flush`)."""
+        self._pending.append((int(handle), int(to_facet), int(what), int(col), int(field), int(row) * self.nf))
 
-    def ode_step(self, handle, t0, dt, rtol=1.0e-8, atol=1.0e-12):
+    def _flush(self):
+        if not self._pending:
+            return
+        ops, self._pending = self._pending, []
+        i = 0
+        while i < len(ops):
+            j = i
+            while j < len(ops) and ops[j][:2] == ops[i][:2]:
+                j += 1
+            grp = ops[i:j]
+            what = np.ascontiguousarray([g[2] for g in grp], dtype=np.int32)
+            col = np.ascontiguousarray([g[3] for g in grp], dtype=np.int32)
+            fld = np.ascontiguousarray([g[4] for g in grp], dtype=np.int32)
+            off = np.ascontiguousarray([g[5] for g in grp], dtype=np.int64)
+            self._chk(self.lib.knp_ode_exchange_multi(self.ctx, grp[0][0], len(grp), _p(what, _i32p), _p(col, _i32p),
+                                                      _p(fld, _i32p), _p(off, _i64p), grp[0][1]), "knp_ode_exchange_multi")
+            i = j
+
+    def ode_set_stimulus(self, handle, cols, values, mask):
+        cols = np.ascontiguousarray(cols, dtype=np.int32)
+        values = np.ascontiguousarray(values, dtype=np.float64)
+        mask = np.ascontiguousarray(mask, dtype=np.uint8)
+        self._chk(self.lib.knp_ode_set_stimulus(self.ctx, handle, len(cols), _p(cols, _i32p), _p(values, _f64p),
+                                                _p(mask, C.POINTER(C.c_uint8))), "knp_ode_set_stimulus")
+
+    def ode_step(self, handle, t0, dt, rtol=1.0e-8, atol=0.0):
+        """Asynchronous (no host round trip); a failed node surfaces as KnpError at the next solve / sync / table read."""
         self._chk(self.lib.knp_ode_step(self.ctx, handle, t0, dt, rtol, atol), "knp_ode_step")
 
     # -- auxiliary-space AMG (knpemidg/amg.py builds, csrc/amg.hip applies) ------------------
@@ -462,6 +509,23 @@ class Device:
 
     def halo_exchange(self, field):
         self._chk(self.lib.knp_halo_exchange(self.ctx, field), "knp_halo_exchange")
+
+
+def _flushing(fn):
+    def wrapped(self, *a, **k):
+        if self._pending:
+            self._flush()
+        return fn(self, *a, **k)
+    wrapped.__name__, wrapped.__doc__ = fn.__name__, fn.__doc__
+    return wrapped
+
+
+# every call that reads or writes device data first issues the queued PDE<->ODE copies (order is preserved)
+for _name in ("close", "set_params", "set_mms", "upload", "download", "copy_field", "update_kappa", "update_dnphi", "emi_apply",
+              "knp_apply", "emi_rhs", "knp_rhs", "emi_solve", "knp_solve", "step_updates", "picard_updates", "max_abs_diff",
+              "nernst", "sync", "timer_begin", "timer_end", "bench_apply", "ode_table", "ode_step", "ode_set_stimulus",
+              "amg_upload", "halo_exchange"):
+    setattr(Device, _name, _flushing(getattr(Device, _name)))
 
 
 def comm_unique_id():

@@ -74,15 +74,22 @@ class FacetFunction:
 
 
 class DeviceFacetFunction(FacetFunction):
-    """DLT0 function living in a device field row (PHI_M, E_k, I_ch_k)."""
+    """DLT0 function living in a device field row (PHI_M, E_k, I_ch_k, or a scratch slot holding a
+    pcws_constant_project result -- then `generation` identifies the projection that wrote the slot)."""
 
-    def __init__(self, Q, dev, field, row=0):
-        self.Q, self.dev, self.field, self.row = Q, dev, field, row
+    def __init__(self, Q, dev, field, row=0, generation=None):
+        self.Q, self.dev, self.field, self.row, self.generation = Q, dev, field, row, generation
 
     def _n(self):
         return self.Q.dim()
 
+    def check_valid(self):
+        if self.generation is not None and not self.dev.tmp_slot_valid(self.row, self.generation):
+            raise RuntimeError("this pcws_constant_project result has been overwritten by later projections "
+                               "(scratch slots are recycled): consume or copy it earlier")
+
     def array(self):
+        self.check_valid()
         return self.dev.download(self.field, self.row * self._n(), self._n())
 
     def vector(self):

@@ -71,7 +71,7 @@ def integrate_batch(rhs, t0, t1, y, params, rtol=1.0e-8, atol=1.0e-12, h0=None, 
             k[s] = rhs(t + _C[s] * hh, ys, params)
         y5 = y + hc * sum(b * kk for b, kk in zip(_B5, k) if b != 0)
         err = hc * sum((b5 - b4) * kk for b5, b4, kk in zip(_B5, _B4, k))
-        scale = atol + rtol * np.maximum(np.abs(y), np.abs(y5))
+        scale = np.maximum(atol + rtol * np.maximum(np.abs(y), np.abs(y5)), 1e-300)
         e = np.max(np.abs(err) / scale, axis=1)
         e = np.where(np.isfinite(e), e, 1e10)
         steps += 1
@@ -86,6 +86,10 @@ def integrate_batch(rhs, t0, t1, y, params, rtol=1.0e-8, atol=1.0e-12, h0=None, 
         raise AssertionError("ODE integrator did not reach the end time")   # `assert success`, membrane.py:113
     rhs(np.full(n, float(t1)), y, params)                 # leave I_ch_k evaluated at the end state
     return y, h
+
+
+def _EVERYWHERE(x):
+    return True
 
 
 class MembraneModel:
@@ -114,6 +118,8 @@ class MembraneModel:
         self._dev = None
         self._handle = None
         self._stim_applied = None
+        self._stim_locator = None
+        self._stim_mask = None
 
     # --- device backing: tables live on the GPU, the batched HIP integrator steps them (csrc/ode.hip) ---
     def attach_device(self, dev):
@@ -188,18 +194,22 @@ class MembraneModel:
         if stimulus is None:
             stimulus = {}
         if stimulus_locator is None:
-            stimulus_locator = lambda x: True
+            stimulus_locator = _EVERYWHERE
         if self.on_device:
-            # the stimulus overwrites the same parameter entries every step (membrane.py:102-104): apply once
-            sig = (tuple(sorted(stimulus.items())), id(stimulus_locator))
-            if sig != self._stim_applied and stimulus:
-                mask = np.fromiter(map(stimulus_locator, self.dof_locations), dtype=bool, count=self.nodes)
-                p = self.parameters
-                for key, value in stimulus.items():
-                    p[mask, self.ode.parameter_indices(key)] = value
-                self.parameters = p
-            self._stim_applied = sig
-            self._dev.ode_step(self._handle, float(self.time), float(dt), rtol=1.0e-8, atol=1.0e-12)
+            # The stimulus is re-imposed on the masked rows at the start of every step (membrane.py:98-104) by the
+            # device kernel itself; the host only (re)sends mask + values when they change.  The locator is evaluated
+            # again whenever a different callable (held by reference, so its identity cannot be recycled) or a different
+            # stimulus dict arrives, and the upload is keyed on the mask CONTENTS.
+            items = tuple(sorted(stimulus.items()))
+            if self._stim_locator is not stimulus_locator or self._stim_mask is None:
+                self._stim_mask = np.fromiter(map(stimulus_locator, self.dof_locations), dtype=bool, count=self.nodes)
+                self._stim_locator = stimulus_locator
+            sig = (items, self._stim_mask.tobytes())
+            if sig != self._stim_applied:
+                cols = [self.ode.parameter_indices(key) for key, _ in items]
+                self._dev.ode_set_stimulus(self._handle, cols, [float(v) for _, v in items], self._stim_mask)
+                self._stim_applied = sig
+            self._dev.ode_step(self._handle, float(self.time), float(dt), rtol=1.0e-8, atol=0.0)   # membrane.py:112
             self.time = self.time + dt
             return None
         mask = np.fromiter(map(stimulus_locator, self.dof_locations), dtype=bool, count=self.nodes)
@@ -207,7 +217,7 @@ class MembraneModel:
             self._parameters[mask, self.ode.parameter_indices(key)] = value
         if self.nodes:
             self._states, self._h = integrate_batch(self.ode.rhs, self.time, self.time + dt, self._states,
-                                                    self._parameters, rtol=1.0e-8, h0=self._h)
+                                                    self._parameters, rtol=1.0e-8, atol=0.0, h0=self._h)
         self.time = self.time + dt
         return self._states
 
@@ -221,6 +231,8 @@ class MembraneModel:
     def _device_field(self, u):
         """(field, row) if `u` lives in a facet field of this model's device, else None."""
         if self.on_device and getattr(u, "dev", None) is self._dev and hasattr(u, "field"):
+            if hasattr(u, "check_valid"):
+                u.check_valid()
             return u.field, getattr(u, "row", 0)
         return None
 
@@ -230,9 +242,12 @@ class MembraneModel:
         if self.on_device and locator is None:
             from knpemidg import _abi
             loc = self._device_field(u)
-            if loc is None:                                     # host data: stage through the facet scratch field
-                self._dev.upload(_abi.F_FACET_TMP, u.array() if hasattr(u, "array") else np.asarray(u))
-                loc = (_abi.F_FACET_TMP, 0)
+            if loc is None:                                     # host data: the copy must be issued before the staging
+                a = u.array() if hasattr(u, "array") else np.asarray(u)     # slot is reused, so do it right away
+                self._dev.upload(_abi.F_FACET_TMP, a, 0)
+                self._dev.ode_exchange(self._handle, 0 if what == 'state' else 1, the_index, _abi.F_FACET_TMP, 0, to_facet=0)
+                self._dev._flush()
+                return None
             self._dev.ode_exchange(self._handle, 0 if what == 'state' else 1, the_index, loc[0], loc[1], to_facet=0)
             return None
         destination = self.states if what == 'state' else self.parameters

@@ -91,9 +91,11 @@ def pcws_constant_project(f, V, fV=None):
         raise NotImplementedError("pcws_constant_project expects a device-backed nodal function")
     from knpemidg import _abi
     from knpemidg.functions import DeviceFacetFunction
-    u.dev.facet_trace(u.field, u.component, f.side, download=False)
-    out = DeviceFacetFunction(V, u.dev, _abi.F_FACET_TMP)     # lives in the device's facet scratch field: consume it
-    if fV is not None:                                        # before the next projection (every reference hook does)
+    slot, gen = u.dev.facet_trace(u.field, u.component, f.side, download=False)
+    # the result lives in one of the device's scratch facet slots (recycled after a few further projections; a stale
+    # result raises instead of silently aliasing a later one)
+    out = DeviceFacetFunction(V, u.dev, _abi.F_FACET_TMP, row=slot, generation=gen)
+    if fV is not None:
         fV.assign(out)
         return fV
     return out

@@ -1,4 +1,7 @@
 """Edge cases and error behaviour of the device path (failure detection; section 8b: errors)."""
+import os
+import sys
+
 import numpy as np
 import pytest
 
@@ -214,3 +217,128 @@ def test_p2_edge_cases_and_argument_checks(hip_lib):
     assert rc == 0
     assert lib.knp_update_kappa(ctx) != 0 and b"tabulation" in lib.knp_last_error(ctx)
     lib.knp_ctx_destroy(ctx)
+
+
+def test_device_ode_matches_lsoda_oracle(hip_lib):
+    """k_ode_step (batched Dormand-Prince 5(4), csrc/ode.hip) against the ORACLE's membrane step: one scipy-LSODA call per
+    facet at the reference's rtol 1e-8 / atol 0 on the restated mm_hh.py right-hand side (oracle/membrane_oracle.py,
+    reference membrane.py:98-114) -- rows with spatially varying K_e, Na_i, Nernst potentials and a stimulus on part of
+    them, 25 steps through the upstroke.  Tolerance: both integrate to rtol 1e-8 per step -> 1e-6 after 25 steps."""
+    import membrane_oracle as mo
+    from knpemidg import _abi as A
+    from knpemidg.mesh import make_mesh_2D
+    from knpemidg.functions import FacetSpace, FacetFunction
+    from knpemidg.membrane import MembraneModel
+    from knpemidg.models import mm_hh, mm_hh_no_stim
+    m, s, f = make_mesh_2D(1)
+    pb = ko.build_idealized(m, s.array(), f.array(), membrane_tags=(1,))
+    dev = device_for(pb)
+    Q = FacetSpace(m)
+    rng = np.random.default_rng(11)
+    fields = {'K_e': 3.32 * (1 + 0.1 * rng.uniform(-1, 1, Q.dim())), 'Na_i': 12.8 * (1 + 0.1 * rng.uniform(-1, 1, Q.dim())),
+              'E_K': -0.0936 + 2e-3 * rng.uniform(-1, 1, Q.dim()), 'E_Na': 0.0533 + 2e-3 * rng.uniform(-1, 1, Q.dim())}
+    locator = lambda x: x[0] < 20e-6
+    for ode, stim in ((mm_hh, True), (mm_hh_no_stim, False)):
+        mm = MembraneModel(ode, facet_f=f, tag=1, V=Q)
+        mm.set_parameter_values({'Cm': lambda x: 0.02})
+        assert mm.attach_device(dev)
+        for name, val in fields.items():
+            mm.set_parameter(name, FacetFunction(Q, val))
+        n = mm.nodes
+        st = np.tile(mo.hh_init_states(), (n, 1))
+        pr = np.tile(mo.hh_init_parameters(), (n, 1))
+        pr[:, mo.P_IDX['Cm']] = 0.02
+        for name, val in fields.items():
+            pr[:, mo.P_IDX[name]] = val[mm.indices]
+        mask = np.fromiter(map(locator, mm.dof_locations), dtype=bool, count=n)
+        assert 0 < mask.sum() < n
+        for k in range(25):
+            mm.step_lsoda(dt=1e-4, stimulus={'stim_amplitude': 40.0}, stimulus_locator=locator)
+            mo.step_lsoda(st, pr, k * 1e-4, 1e-4, stim=stim, stimulus={'stim_amplitude': 40.0}, stimulus_mask=mask)
+        sd, pd = mm.states, mm.parameters
+        assert np.abs(sd - st).max() < 1e-6 * np.abs(st).max(), (stim, np.abs(sd - st).max())
+        cur = slice(mo.P_IDX['I_ch_Na'], mo.P_IDX['I_ch_K'] + 1)
+        assert np.abs(pd[:, cur] - pr[:, cur]).max() < 1e-5 * np.abs(pr[:, cur]).max()
+        if stim:
+            assert st[mask, 3].max() > 0.0 and st[~mask, 3].max() < -0.06       # stimulated rows fired, the others rest
+    dev.close()
+
+
+def test_stimulus_is_reimposed_every_step(hip_lib):
+    """The reference overwrites the stimulus parameters on the masked rows at the start of every step_lsoda call
+    (membrane.py:98-104): a hook that rewrites the whole parameter table between steps must not lose the stimulus."""
+    from knpemidg.mesh import make_mesh_2D
+    from knpemidg.functions import FacetSpace
+    from knpemidg.membrane import MembraneModel
+    from knpemidg.models import mm_hh
+    m, s, f = make_mesh_2D(0)
+    pb = ko.build_idealized(m, s.array(), f.array(), membrane_tags=(1,))
+    dev = device_for(pb)
+    Q = FacetSpace(m)
+    res = []
+    for clobber in (False, True):
+        mm = MembraneModel(mm_hh, facet_f=f, tag=1, V=Q)
+        mm.set_parameter_values({'Cm': lambda x: 0.02, 'K_e': lambda x: 3.32, 'Na_i': lambda x: 12.8,
+                                 'E_K': lambda x: -0.0936, 'E_Na': lambda x: 0.0533})
+        assert mm.attach_device(dev)
+        for k in range(8):
+            if clobber:
+                p = mm.parameters
+                p[:, mm_hh.parameter_indices('stim_amplitude')] = 0.0        # a hook wipes the stimulus column
+                mm.parameters = p
+            mm.step_lsoda(dt=1e-4, stimulus={'stim_amplitude': 40.0}, stimulus_locator=lambda x: x[0] < 20e-6)
+        res.append(mm.states)
+    assert np.array_equal(res[0], res[1])
+    assert res[0][:, 3].max() > -0.06
+    dev.close()
+
+
+def test_set_params_between_solves_refreshes_lagged_preconditioner_data(hip_lib):
+    """dt (and with it C_phi and the KNP mass term) changes through set_params between solves: the lagged block-Jacobi
+    inverses AND the Chebyshev bound lambda_max(Binv A) built on them must be rebuilt, otherwise the two-step Chebyshev
+    smoother amplifies the top modes and BiCGStab stagnates.  Both steps must converge to the oracle's solution."""
+    from knpemidg import _abi as A
+    m, s, f = small_3d((10, 4, 4))
+    pb = ko.build_idealized(m, s.array(), f.array(), membrane_tags=(1,))
+    synthetic_state(pb)
+    dev = device_for(pb)
+    push_state(dev, pb)
+    z = [ion["z"] for ion in pb.ions]
+    D = np.stack([ion["D"] for ion in pb.ions])
+    its = []
+    for dt in (1e-4, 1e-7, 1e-2):
+        pb.dt = dt
+        pb.C_phi = pb.C_M / dt
+        dev.set_params(pb.C_M, dt, pb.F, pb.R, pb.T, pb.C_phi, pb.tau, pb.tau, z, D, rho=pb.rho, splitting=True)
+        ko.solve_emi(pb, direct=True)
+        dev.upload(A.F_PHI, pb.phi)
+        dev.update_dnphi(); dev.knp_rhs()
+        dev.upload(A.F_C, pb.c)
+        niter, res = dev.knp_solve(1e-12, maxit=400)
+        c = dev.download(A.F_C).reshape(pb.c.shape)
+        c0 = pb.c.copy()
+        ref = ko.solve_knp(pb, direct=True)
+        pb.c = c0
+        assert relerr(c, ref) < 1e-8, (dt, niter, res)
+        its.append(max(niter))
+    assert max(its) < 200, its
+    dev.close()
+
+
+def test_stale_projection_result_raises(hip_lib):
+    """pcws_constant_project results live in a few rotating device scratch slots: a result that has been overwritten by
+    later projections raises instead of silently aliasing them; results consumed in time are distinct."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "idealized_geometries"))
+    from idealized_common import make_solver
+    from knpemidg.utils import pcws_constant_project, plus, minus
+    S = make_solver(dim=2, resolution=0)
+    a = pcws_constant_project(plus(S.c_prev_k.split()[0], S.n_g), S.Q)
+    b = pcws_constant_project(minus(S.ion_list[-1]['c'], S.n_g), S.Q)
+    va, vb = a.array(), b.array()
+    mem = np.nonzero(S.surfaces.array() == 1)[0]
+    assert np.allclose(va[mem], 3.3236967382705265) and np.allclose(vb[mem], 12.838513108648856)   # K_e, Na_i: both alive
+    for _ in range(4):
+        pcws_constant_project(plus(S.c_prev_k.split()[1], S.n_g), S.Q)
+    with pytest.raises(RuntimeError, match="overwritten"):
+        a.array()
+    S.dev.close()

@@ -93,6 +93,32 @@ def test_knp_rhs(case):
         assert relerr(b[k], ko.knp_rhs(pb, k)) < TOL
 
 
+def test_rhs_without_splitting(case):
+    """Original (non-splitting) Robin data: g = phi_M - I_ch / C_phi in L_emi (solver.py:337) and
+    g_k = phi_M - dt / (C_M alpha) I_ch_k in L_knp without the + dt / C_M I_ch term (solver.py:619-622)."""
+    pb, dev, x, A = case
+    z = [ion["z"] for ion in pb.ions]
+    D = np.stack([ion["D"] for ion in pb.ions])
+    try:
+        pb.splitting = False
+        dev.set_params(pb.C_M, pb.dt, pb.F, pb.R, pb.T, pb.C_phi, pb.tau, pb.tau, z, D, rho=pb.rho, splitting=False)
+        dev.emi_rhs()
+        ref_split = None
+        assert relerr(dev.download(A.F_B_EMI), ko.emi_rhs(pb)) < TOL
+        dev.knp_rhs()
+        b = dev.download(A.F_B_KNP).reshape(pb.N_ions, -1)
+        for k in range(pb.N_ions):
+            ref = ko.knp_rhs(pb, k)
+            assert relerr(b[k], ref) < TOL
+            pb.splitting = True
+            ref_split = ko.knp_rhs(pb, k)
+            pb.splitting = False
+            assert relerr(ref, ref_split) > 1e-6          # the two Robin data really differ on this state
+    finally:
+        pb.splitting = True
+        dev.set_params(pb.C_M, pb.dt, pb.F, pb.R, pb.T, pb.C_phi, pb.tau, pb.tau, z, D, rho=pb.rho, splitting=True)
+
+
 def test_step_updates(case):
     pb, dev, x, A = case
     import copy
