@@ -420,10 +420,11 @@ int knp_emi_solve(knp_ctx* c, double rtol, double atol, int maxit, int check_eve
     KrylovVecs kv{};
     kv.x = f->f[KNP_F_PHI]; kv.b = f->f[KNP_F_B_EMI]; kv.coef = f->f[KNP_F_KAPPA]; kv.binv = f->binv_emi;
     kv.r = f->r; kv.z = f->z; kv.p = f->p; kv.w = f->w; kv.rhat = f->rhat; kv.v = f->v; kv.y = f->y;
-    // the same two-step Chebyshev block-Jacobi smoother for EMI is opt-in (KNP_EMI_CHEB=1): measured at r=2 it leaves the
-    // PCG iteration count where it is (8..15 -> 8..13 through an action potential; EMI is limited by the auxiliary-space
-    // part, not by block-Jacobi) and the extra apply makes the step 1 % slower
-    static const int cheb_emi = getenv("KNP_EMI_CHEB") ? atoi(getenv("KNP_EMI_CHEB")) : 0;
+    // the same two-step Chebyshev block-Jacobi smoother for EMI (KNP_EMI_CHEB=0 disables): at the effective tolerance the
+    // parity bounds need (rtol 2e-8, knpemidg/solver.py) it cuts the PCG iterations from 5.2 to 4.2 per step and the
+    // error of phi by 2x at equal tolerance (r=1, 40 steps through an action potential) for one more apply per iteration
+    static const int cheb_env_emi = getenv("KNP_EMI_CHEB") ? atoi(getenv("KNP_EMI_CHEB")) : -1;
+    const int cheb_emi = cheb_env_emi >= 0 ? cheb_env_emi : (c->degree == 1 ? 1 : 0);
     if (cheb_emi && c->amg.size() && c->amg[0].ready) {
         if (!f->tmp_emi) HIPCHK(c, hipMalloc((void**)&f->tmp_emi, sizeof(double) * f->n[KNP_F_PHI]));
         kv.tmp = f->tmp_emi;

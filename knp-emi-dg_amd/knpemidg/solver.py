@@ -372,7 +372,14 @@ class Solver:
         self.max_it_knp = int(getattr(sp, "max_it_knp", self.max_it_knp))
         # direct solvers (MUMPS, solver.py:412-422, 671-681) have no device counterpart: emulate with a tight
         # iterative tolerance
-        self._rtol_emi = float(getattr(sp, "rtol_direct", 1e-10)) if self.direct_emi else float(self.rtol_emi)
+        # PETSc tests ||M^-1 r|| <= rtol ||M^-1 b|| with M = BoomerAMG (solver.py:425-444); with this build's preconditioner the
+        # same nominal rtol 1e-5 leaves mean-free phi accurate to 1e-4 of its maximum but the concentrations only to 3e-5
+        # (they inherit the RELATIVE error of phi through the drift and membrane terms), measured against direct solves
+        # through an action potential (tests/test_gpu_trajectory.py, tools/tolerance_sweep.py).  The nominal tolerance is
+        # therefore scaled so that the stated parity bounds (c <= 1e-6, phi <= 1e-4) hold at every step.
+        scale = float(os.environ.get("KNP_EMI_RTOL_SCALE", 2.0e-3))
+        rt = float(self.rtol_emi) if not self.direct_emi else 0.0
+        self._rtol_emi = float(getattr(sp, "rtol_direct", 1e-10)) if self.direct_emi else max(rt * scale, min(rt, 1.0e-11))
         self._atol_emi = 1e-40 if self.direct_emi else float(self.atol_emi)
         self._rtol_knp = float(getattr(sp, "rtol_direct", 1e-10)) if self.direct_knp else float(self.rtol_knp)
         self._atol_knp = 1e-40 if self.direct_knp else float(self.atol_knp)
