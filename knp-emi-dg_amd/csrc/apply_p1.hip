@@ -864,7 +864,7 @@ int64_t grid_for(int64_t n) { return (n + KNP_BLOCK - 1) / KNP_BLOCK; }
 static inline int64_t grid8(int64_t n) { return ((grid_for(n) + 7) / 8) * 8; }
 
 int launch_emi_apply(knp_ctx* c, const double* x, const double* kappa, double* y) {
-    if (c->degree != 1) return tab_apply(c, 0, x, y);
+    if (c->degree != 1) return p2_assembled() ? tab_apply(c, 0, x, y) : p2_emi_apply(c, x, kappa, y);
     static const int variant = getenv("KNP_EMI_VARIANT") ? atoi(getenv("KNP_EMI_VARIANT")) : 1;
     if (c->m.cls && c->m.dim == 3 && variant != 4) {
         if (c->m.ncls <= CLS_MAX_LDS && variant != 5) {
@@ -945,12 +945,12 @@ template <int D> static int knp_apply_dispatch(knp_ctx* c, const double* x, cons
 }
 
 int launch_knp_apply(knp_ctx* c, const double* x, const double* gphi, double* y) {
-    if (c->degree != 1) return tab_apply(c, 1, x, y);
+    if (c->degree != 1) return p2_assembled() ? tab_apply(c, 1, x, y) : p2_knp_apply(c, x, gphi, y);     // P2: gphi holds phi (launch_dnphi)
     return c->m.dim == 3 ? knp_apply_dispatch<3>(c, x, gphi, y) : knp_apply_dispatch<2>(c, x, gphi, y);
 }
 
 int launch_emi_blockjacobi(knp_ctx* c, const double* kappa, bjreal* binv) {
-    if (c->degree != 1) return tab_block_inverse(c, 0, binv);
+    if (c->degree != 1) return p2_assembled() ? tab_block_inverse(c, 0, binv) : p2_block_inverse(c, 0, kappa, binv);
     const dim3 g((unsigned)grid_for(c->m.nc_owned)), b(KNP_BLOCK);
     const double shift = 0.0;
     if (c->m.dim == 3)
@@ -962,7 +962,7 @@ int launch_emi_blockjacobi(knp_ctx* c, const double* kappa, bjreal* binv) {
 }
 
 int launch_knp_blockjacobi(knp_ctx* c, const double* gphi, bjreal* binv) {
-    if (c->degree != 1) return tab_block_inverse(c, 1, binv);
+    if (c->degree != 1) return p2_assembled() ? tab_block_inverse(c, 1, binv) : p2_block_inverse(c, 1, gphi, binv);
     const dim3 g((unsigned)grid_for(c->m.nc_owned), (unsigned)c->p.n_sys), b(KNP_BLOCK);
     const KnpArgs ka = make_knp_args(c);
     if (c->m.dim == 3)
@@ -974,7 +974,13 @@ int launch_knp_blockjacobi(knp_ctx* c, const double* gphi, bjreal* binv) {
 }
 
 int launch_dnphi(knp_ctx* c, const double* phi, double* gphi) {
-    if (c->degree != 1) return tab_assemble_knp(c, phi);     // P2: the drift enters the assembled blocks
+    if (c->degree != 1) {
+        // P2: the matrix-free apply evaluates the drift from phi itself; the "derived" field keeps the potential the KNP
+        // solve is frozen at (the assembled variant integrates it into the cell blocks instead)
+        if (p2_assembled()) return tab_assemble_knp(c, phi);
+        HIPCHK(c, hipMemcpyAsync(gphi, phi, sizeof(double) * c->m.nc * c->nd, hipMemcpyDeviceToDevice, c->stream));
+        return 0;
+    }
     const dim3 g((unsigned)grid_for(c->m.nc)), b(KNP_BLOCK);
     if (c->m.dim == 3)
         hipLaunchKernelGGL(k_gphi<3>, g, b, 0, c->stream, c->m, phi, gphi);

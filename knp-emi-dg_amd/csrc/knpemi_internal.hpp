@@ -147,6 +147,12 @@ int tab_knp_rhs(knp_ctx* c, const double* cc, const double* cprev, const double*
 int tab_step_updates(knp_ctx* c, const double* cc, double* celim, const double* phi, double* phiM, double* E, bool do_celim);
 int tab_facet_trace(knp_ctx* c, const double* nodal, int side, double* out);
 void tab_free(knp_ctx* c);
+bool p2_assembled();                 // KNP_P2_ASSEMBLED=1: round-1 path (quadrature-assembled cell blocks) instead of the matrix-free applies
+
+// matrix-free DG-P2 applies (apply_p2.hip)
+int p2_emi_apply(knp_ctx* c, const double* x, const double* kappa, double* y);
+int p2_knp_apply(knp_ctx* c, const double* x, const double* phi, double* y);
+int p2_block_inverse(knp_ctx* c, int which, const double* coef, bjreal* binv);
 
 int halo_exchange(knp_ctx* c, double* v, int nfields);
 

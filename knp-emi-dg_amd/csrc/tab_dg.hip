@@ -16,6 +16,7 @@
 #include "../../include/knpemi_hip.h"
 #include "knpemi_internal.hpp"
 #include "cell_geom.hpp"
+#include <cstdlib>
 
 namespace {
 
@@ -663,6 +664,11 @@ static int need_tabs(knp_ctx* c, std::initializer_list<int> slots) {
         HIPCHK(c, hipGetLastError());                                                                        \
     } while (0)
 
+bool p2_assembled() {
+    static const bool on = getenv("KNP_P2_ASSEMBLED") && atoi(getenv("KNP_P2_ASSEMBLED")) == 1;
+    return on;
+}
+
 static int ensure_blocks(knp_ctx* c) {
     const size_t per = (size_t)c->m.nc * (c->m.dim + 2) * c->nd * c->nd;
     if (!c->blk_emi) HIPCHK(c, hipMalloc((void**)&c->blk_emi, sizeof(double) * per));
@@ -675,10 +681,12 @@ static dim3 rows_grid(knp_ctx* c, int block, int ny = 1) {
 }
 
 int tab_kappa(knp_ctx* c, const double* cc, const double* celim, double* kappa) {
-    if (need_tabs(c, {KNP_TAB_CELL_STIFF, KNP_TAB_FACET_EMI, KNP_TAB_FACET_MEM}) || ensure_blocks(c)) return -1;
     const int64_t n = c->m.nc * c->nd;
     hipLaunchKernelGGL(k_tab_kappa, dim3((unsigned)grid_for(n)), dim3(KNP_BLOCK), 0, c->stream, c->m.nc, c->nd, cc, celim,
                        (const double*)c->D, ion_z(c), c->p.F, c->p.psi, kappa);
+    HIPCHK(c, hipGetLastError());
+    if (!p2_assembled()) return 0;                       // matrix-free applies read kappa directly (apply_p2.hip)
+    if (need_tabs(c, {KNP_TAB_CELL_STIFF, KNP_TAB_FACET_EMI, KNP_TAB_FACET_MEM}) || ensure_blocks(c)) return -1;
     TAB_DISPATCH(c, k_tab_assemble_emi, rows_grid(c, 128), dim3(128), c->m, c->tab[KNP_TAB_CELL_STIFF], c->tab[KNP_TAB_FACET_EMI],
                  c->tab[KNP_TAB_FACET_MEM], (const double*)kappa, c->p.tau_emi, c->p.C_phi, c->blk_emi);
     return 0;

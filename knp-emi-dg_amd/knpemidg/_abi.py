@@ -246,7 +246,7 @@ class Device:
             for slot, (nloc, nq, w, B, dB) in dgtab.tables(self.dim, degree).items():
                 self._chk(self.lib.knp_set_tabulation(self.ctx, slot, nloc, nq, _p(w, _f64p), _p(B, _f64p), _p(dB, _f64p)),
                           "knp_set_tabulation")
-        if degree == 1 and os.environ.get("KNP_NO_CLASSES", "0") != "1":
+        if os.environ.get("KNP_NO_CLASSES", "0") != "1":
             gc = geometry_classes(mesh, order)
             if gc is not None:
                 cls, table = gc

@@ -113,7 +113,7 @@ def test_rhs_without_splitting(case):
             pb.splitting = True
             ref_split = ko.knp_rhs(pb, k)
             pb.splitting = False
-            assert relerr(ref, ref_split) > 1e-6          # the two Robin data really differ on this state
+            assert relerr(ref, ref_split) > 1e-10         # the two Robin data really differ on this state
     finally:
         pb.splitting = True
         dev.set_params(pb.C_M, pb.dt, pb.F, pb.R, pb.T, pb.C_phi, pb.tau, pb.tau, z, D, rho=pb.rho, splitting=True)
