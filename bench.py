@@ -151,13 +151,24 @@ def main():
         elapsed = float(tt.item())
     ms_per_step = 1e3 * elapsed / args.steps
 
-    # --- roofline of the dominant kernel (EMI operator apply), HIP events on the context's stream
+    # --- roofline of the dominant kernels (operator applies), HIP events on the context's stream.
+    # (1) in-solver: every apply launched by the solves of two further steps is bracketed by an event pair (knp_apply_timing);
+    # (2) back-to-back: 200 launches rotating three vector pairs (knp_bench_apply) -- the figure `roofline.achieved` uses is
+    #     the SLOWER, in-solver one.
     nc_local = S.dev.nc_owned
+    S.dev.apply_timing(True)
+    for _ in range(2):
+        S.step_membrane_models(k); S.solve_for_time_step(k, t); k += 1
+    emi_solver_ms, emi_n = S.dev.apply_timing_read(0)
+    knp_solver_ms, knp_n = S.dev.apply_timing_read(1)
+    S.dev.apply_timing(False)
     rng = np.random.default_rng(0)
     S.dev.upload(A.F_X, rng.uniform(-1, 1, size=S.dev.size(A.F_X)))
     S.dev.update_kappa(); S.dev.update_dnphi()
-    emi_ms = S.dev.bench_apply(0, 200)
-    knp_ms = S.dev.bench_apply(1, 200)
+    emi_b2b_ms = S.dev.bench_apply(0, 200)
+    knp_b2b_ms = S.dev.bench_apply(1, 200)
+    emi_ms = max(emi_solver_ms, emi_b2b_ms) if emi_n else emi_b2b_ms
+    knp_ms = max(knp_solver_ms, knp_b2b_ms) if knp_n else knp_b2b_ms
     # algorithmic bytes per cell: P1 137 / 217, P2 281 / 457
     emi_bpc = EMI_BYTES_PER_CELL if args.degree == 1 else 281.0
     knp_bpc = KNP_BYTES_PER_CELL if args.degree == 1 else 457.0
@@ -166,18 +177,20 @@ def main():
 
     # HBM-side traffic of the same kernel on the same workload, from the committed rocprofv3 --pmc passes
     # (counters cannot be read from inside this process); null when the workload differs
-    emi_name = "k_emi_apply_cls_staged<3,256>" if S.dev.n_geometry_classes else "k_emi_apply<3,3>"
-    knp_name = "k_knp_apply_cls_staged<3,2,256>" if S.dev.n_geometry_classes else "k_knp_apply<3,2>"
-    if args.degree != 1:
-        emi_name = knp_name = "k_tab_apply<3,10>"
+    cls = bool(S.dev.n_geometry_classes)
+    if args.degree == 1:
+        emi_name = "k_emi_apply_cls_staged<3,256>" if cls else "k_emi_apply<3,3>"
+        knp_name = "k_knp_apply_cls_staged<3,2,256>" if cls else "k_knp_apply<3,2>"
+    else:
+        emi_name = "k_emi_apply_p2<3,256,%s>" % ("true" if cls else "false")
+        knp_name = "k_knp_apply_p2<3,256,%s>" % ("true" if cls else "false")
     traffic = traffic_emi = None
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
         if pmc.get(emi_name, {}).get("cells_per_launch") == nc_local:
             traffic_emi = pmc[emi_name]["traffic_bytes"]
-        knp_key = knp_name if args.degree == 1 else knp_name + ":knp"
-        if pmc.get(knp_key, {}).get("cells_per_launch") == nc_local:
-            traffic = pmc[knp_key]["traffic_bytes"]
+        if pmc.get(knp_name, {}).get("cells_per_launch") == nc_local:
+            traffic = pmc[knp_name]["traffic_bytes"]
     except (OSError, ValueError):
         pass
 
@@ -200,8 +213,11 @@ def main():
             "roofline": {"bound": "hbm", "kernel": knp_name, "achieved": knp_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": knp_gbs / HBM_PEAK_GBS, "traffic": traffic, "avg_kernel_us": knp_ms * 1e3,
                          "algorithmic_bytes_per_cell": knp_bpc, "cells_per_launch": nc_local,
+                         "in_solver_us": knp_solver_ms * 1e3, "in_solver_launches": knp_n, "back_to_back_us": knp_b2b_ms * 1e3,
                          "emi_apply": {"kernel": emi_name, "achieved": emi_gbs, "frac": emi_gbs / HBM_PEAK_GBS, "traffic": traffic_emi,
-                                       "avg_kernel_us": emi_ms * 1e3, "algorithmic_bytes_per_cell": emi_bpc}},
+                                       "avg_kernel_us": emi_ms * 1e3, "algorithmic_bytes_per_cell": emi_bpc,
+                                       "in_solver_us": emi_solver_ms * 1e3, "in_solver_launches": emi_n,
+                                       "back_to_back_us": emi_b2b_ms * 1e3}},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()

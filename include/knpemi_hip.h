@@ -193,8 +193,20 @@ int knp_sync(knp_ctx* ctx);
 int knp_timer_begin(knp_ctx* ctx);         /* records a HIP event on the context's stream */
 int knp_timer_end(knp_ctx* ctx, float* ms);/* records, synchronises, returns elapsed ms */
 /* Launches `reps` back-to-back applies (which: 0 = EMI, 1 = KNP) on X -> Y and returns the average
- * kernel duration measured with HIP events on the stream the kernel runs on. */
+ * kernel duration measured with HIP events on the stream the kernel runs on.  Three input / output vector pairs are used in
+ * rotation so that the launches are not served from the Infinity Cache. */
 int knp_bench_apply(knp_ctx* ctx, int which, int reps, float* avg_ms);
+/* In-solver timing of the same kernels: while enabled, every operator apply launched by the solves is bracketed by a HIP event
+ * pair on the context's stream; knp_apply_timing_read synchronises, returns the average duration and the number of launches
+ * since the last read (which: 0 = EMI, 1 = KNP) and resets the tally. */
+int knp_apply_timing(knp_ctx* ctx, int enable);
+int knp_apply_timing_read(knp_ctx* ctx, int which, float* avg_ms, int* count);
+
+/* FP64 MFMA probe of the DG-P2 path's dense facet-quadrature contraction (csrc/apply_p2.hip): variant 0 = per-thread FMA chain
+ * (what the product kernels use), 1 = v_mfma_f64_16x16x4_f64 tiles.  in[ncol][26] = {jump(u)[6], kappa[6], kappa'[6], dn u[3],
+ * dn u'[3], area, penalty}, out[ncol][9] = {r[6], T[3]}; returns the average kernel time over `reps` launches.  Diagnostic
+ * (no counterpart in the reference): it documents why the product path keeps the vector pipe. */
+int knp_probe_facet_contraction(knp_ctx* ctx, int variant, int64_t ncol, int reps, const double* in, double* out, float* avg_ms);
 
 /* ---- multi-GPU (one process per GPU, RCCL over xGMI) ------------------------------------------------
  * Replaces DOLFIN ghosting + PETSc VecGhost/MatMult scatters + KSP reductions (solver.py:16,529,789). */

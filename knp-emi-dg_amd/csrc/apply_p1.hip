@@ -863,7 +863,40 @@ __global__ __launch_bounds__(KNP_BLOCK) void k_gphi(MeshDev m, const double* __r
 int64_t grid_for(int64_t n) { return (n + KNP_BLOCK - 1) / KNP_BLOCK; }
 static inline int64_t grid8(int64_t n) { return ((grid_for(n) + 7) / 8) * 8; }
 
+// event pair around one apply launch while knp_apply_timing is on (the in-solver figure next to knp_bench_apply's)
+struct ApplyTimerScope {
+    knp_ctx* c; int which; bool on;
+    ApplyTimerScope(knp_ctx* ctx, int w) : c(ctx), which(w), on(ctx->time_applies) {
+        if (!on) return;
+        auto& pool = c->tev[which];
+        if (c->tev_used[which] == pool.size()) {
+            hipEvent_t a, b;
+            if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { on = false; return; }
+            pool.push_back({a, b});
+        }
+        hipEventRecord(pool[c->tev_used[which]].first, c->stream);
+    }
+    ~ApplyTimerScope() {
+        if (!on) return;
+        hipEventRecord(c->tev[which][c->tev_used[which]].second, c->stream);
+        ++c->tev_used[which];
+    }
+};
+
+static int emi_apply_impl(knp_ctx* c, const double* x, const double* kappa, double* y);
+static int knp_apply_impl(knp_ctx* c, const double* x, const double* gphi, double* y);
+
 int launch_emi_apply(knp_ctx* c, const double* x, const double* kappa, double* y) {
+    ApplyTimerScope t(c, 0);
+    return emi_apply_impl(c, x, kappa, y);
+}
+
+int launch_knp_apply(knp_ctx* c, const double* x, const double* gphi, double* y) {
+    ApplyTimerScope t(c, 1);
+    return knp_apply_impl(c, x, gphi, y);
+}
+
+static int emi_apply_impl(knp_ctx* c, const double* x, const double* kappa, double* y) {
     if (c->degree != 1) return p2_assembled() ? tab_apply(c, 0, x, y) : p2_emi_apply(c, x, kappa, y);
     static const int variant = getenv("KNP_EMI_VARIANT") ? atoi(getenv("KNP_EMI_VARIANT")) : 1;
     if (c->m.cls && c->m.dim == 3 && variant != 4) {
@@ -944,7 +977,7 @@ template <int D> static int knp_apply_dispatch(knp_ctx* c, const double* x, cons
     return 0;
 }
 
-int launch_knp_apply(knp_ctx* c, const double* x, const double* gphi, double* y) {
+static int knp_apply_impl(knp_ctx* c, const double* x, const double* gphi, double* y) {
     if (c->degree != 1) return p2_assembled() ? tab_apply(c, 1, x, y) : p2_knp_apply(c, x, gphi, y);     // P2: gphi holds phi (launch_dnphi)
     return c->m.dim == 3 ? knp_apply_dispatch<3>(c, x, gphi, y) : knp_apply_dispatch<2>(c, x, gphi, y);
 }

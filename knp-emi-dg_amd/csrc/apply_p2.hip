@@ -44,6 +44,27 @@ template <int D> struct P2 {
         return k + (hi - lo - 1);
     }
     static constexpr int ae(int m) { return 1 + D + NFE + m; } // frame slot of the edge (apex, facet vertex m)
+    // cell dof behind frame slot s of local facet I (= P2Tab<D>::FRAME_SLOTS[I][s], as arithmetic so that it folds to a
+    // register index at compile time; loads from the table would be run-time loads + dynamic register indexing)
+    static constexpr int fs(int I, int s) {
+        if (s == 0) return I;
+        if (s <= D) return (s - 1) + ((s - 1) >= I ? 1 : 0);
+        if (s <= D + NFE) {
+            int k = 1 + D;
+            for (int a = 0; a < D; ++a)
+                for (int b = a + 1; b < D; ++b) {
+                    if (k == s) return edge(a + (a >= I ? 1 : 0), b + (b >= I ? 1 : 0));
+                    ++k;
+                }
+        }
+        const int mm = s - 1 - D - NFE;
+        return edge(I, mm + (mm >= I ? 1 : 0));
+    }
+    static constexpr uint64_t packed(int j) {                 // nibble s = fs(j, s)
+        uint64_t p = 0;
+        for (int s = 0; s < ND; ++s) p |= (uint64_t)fs(j, s) << (4 * s);
+        return p;
+    }
     static constexpr int pair(int a, int b) {                 // index of the unordered vertex pair in M3
         const int lo = a < b ? a : b, hi = a < b ? b : a;
         int k = 0;
@@ -112,26 +133,28 @@ template <int D> __device__ __forceinline__ void dn_vertices(const double* F, do
 
 // y (cell dofs) += sum_m T[m] * (normal derivative of the own basis functions at facet vertex m); frame of local facet I
 template <int D, int I> __device__ __forceinline__ void back_project(const double* T, double gnA, const double* gnV, double* y) {
-    constexpr const int* FS = P2Tab<D>::FRAME_SLOTS[I];
 #pragma unroll
     for (int m = 0; m < D; ++m) {
-        y[FS[1 + m]] = fma(3.0 * gnV[m], T[m], y[FS[1 + m]]);
-        y[FS[0]] = fma(-gnA, T[m], y[FS[0]]);
-        y[FS[P2<D>::ae(m)]] = fma(4.0 * gnA, T[m], y[FS[P2<D>::ae(m)]]);
+        y[P2<D>::fs(I, 1 + m)] = fma(3.0 * gnV[m], T[m], y[P2<D>::fs(I, 1 + m)]);
+        y[P2<D>::fs(I, 0)] = fma(-gnA, T[m], y[P2<D>::fs(I, 0)]);
+        y[P2<D>::fs(I, P2<D>::ae(m))] = fma(4.0 * gnA, T[m], y[P2<D>::fs(I, P2<D>::ae(m))]);
 #pragma unroll
         for (int mp = 0; mp < D; ++mp)
             if (mp != m) {
-                y[FS[1 + mp]] = fma(-gnV[mp], T[m], y[FS[1 + mp]]);
-                y[FS[P2<D>::fe(m, mp)]] = fma(4.0 * gnV[mp], T[m], y[FS[P2<D>::fe(m, mp)]]);
+                y[P2<D>::fs(I, 1 + mp)] = fma(-gnV[mp], T[m], y[P2<D>::fs(I, 1 + mp)]);
+                y[P2<D>::fs(I, P2<D>::fe(m, mp))] = fma(4.0 * gnV[mp], T[m], y[P2<D>::fs(I, P2<D>::fe(m, mp))]);
             }
     }
 }
 
 template <int D> __device__ __forceinline__ uint64_t frame_packed(int j) {
-    uint64_t p = P2Tab<D>::FRAME_PACKED[0];
-    if (j == 1) p = P2Tab<D>::FRAME_PACKED[1];
-    if (j == 2) p = P2Tab<D>::FRAME_PACKED[2];
-    if (D == 3 && j == 3) p = P2Tab<D>::FRAME_PACKED[D == 3 ? 3 : 0];
+    constexpr uint64_t p0 = P2<D>::packed(0), p1 = P2<D>::packed(1), p2 = P2<D>::packed(2), p3 = P2<D>::packed(D == 3 ? 3 : 0);
+    static_assert(p0 == P2Tab<D>::FRAME_PACKED[0] && p1 == P2Tab<D>::FRAME_PACKED[1] && p2 == P2Tab<D>::FRAME_PACKED[2] &&
+                  p3 == P2Tab<D>::FRAME_PACKED[D == 3 ? 3 : 0], "frame permutation disagrees with the generated table");
+    uint64_t p = p0;
+    if (j == 1) p = p1;
+    if (j == 2) p = p2;
+    if (D == 3 && j == 3) p = p3;
     return p;
 }
 
@@ -190,7 +213,6 @@ __device__ __forceinline__ void emi_facet_p2(const MeshDev& m, const CellGeom<D>
                                              const double* __restrict__ kappa, const StageP2<D>& st, double C_phi, double tau,
                                              double* y) {
     constexpr int NV = D + 1, ND = P2<D>::ND, NF = P2<D>::NF;
-    constexpr const int* FS = P2Tab<D>::FRAME_SLOTS[I];
     const uint32_t fb = (flags >> (8 * I)) & 0xffu;
     const uint32_t kind = (fb >> 2) & 3u;
     if (kind >= FK_EXTERIOR) return;
@@ -212,7 +234,7 @@ __device__ __forceinline__ void emi_facet_p2(const MeshDev& m, const CellGeom<D>
     }
     double ju[NF];
 #pragma unroll
-    for (int n = 0; n < NF; ++n) ju[n] = xv[FS[1 + n]] - Fn[1 + n];
+    for (int n = 0; n < NF; ++n) ju[n] = xv[P2<D>::fs(I, 1 + n)] - Fn[1 + n];
     double L[NV], sqG, hinv;
     facet_geometry<D, I, CLS>(m, K, rec, c, Kp, j, L, sqG, hinv);
     const double area = sqG * (double)D * K.vol;
@@ -223,7 +245,7 @@ __device__ __forceinline__ void emi_facet_p2(const MeshDev& m, const CellGeom<D>
             double s = 0.0;
 #pragma unroll
             for (int k = 0; k < NF; ++k) s = fma(P2Tab<D>::FMASS[n][k], ju[k], s);
-            y[FS[1 + n]] = fma(w, s, y[FS[1 + n]]);
+            y[P2<D>::fs(I, 1 + n)] = fma(w, s, y[P2<D>::fs(I, 1 + n)]);
         }
         return;
     }
@@ -239,7 +261,7 @@ __device__ __forceinline__ void emi_facet_p2(const MeshDev& m, const CellGeom<D>
     }
     double Fo[ND];
 #pragma unroll
-    for (int s = 0; s < ND; ++s) Fo[s] = xv[FS[s]];
+    for (int s = 0; s < ND; ++s) Fo[s] = xv[P2<D>::fs(I, s)];
     double dno[D], dnn[D];
     dn_vertices<D>(Fo, gnA, gnV, dno);
     dn_vertices<D>(Fn, gr, gnVn, dnn);
@@ -255,7 +277,7 @@ __device__ __forceinline__ void emi_facet_p2(const MeshDev& m, const CellGeom<D>
 #pragma unroll
         for (int n = 0; n < NF; ++n) {
             const double p = P2Tab<D>::PSIE[q][n];
-            ko = fma(kv[FS[1 + n]], p, ko);
+            ko = fma(kv[P2<D>::fs(I, 1 + n)], p, ko);
             kn = fma(Kn[n], p, kn);
             jq = fma(ju[n], p, jq);
         }
@@ -273,7 +295,7 @@ __device__ __forceinline__ void emi_facet_p2(const MeshDev& m, const CellGeom<D>
         for (int mm = 0; mm < D; ++mm) T[mm] = fma(t, P2Tab<D>::LAME[q][mm], T[mm]);
     }
 #pragma unroll
-    for (int n = 0; n < NF; ++n) y[FS[1 + n]] += r[n];
+    for (int n = 0; n < NF; ++n) y[P2<D>::fs(I, 1 + n)] += r[n];
     back_project<D, I>(T, gnA, gnV, y);
 }
 
@@ -395,7 +417,6 @@ __device__ __forceinline__ void knp_facet_p2(const MeshDev& m, const CellGeom<D>
                                              const double* __restrict__ x, const double* __restrict__ phi,
                                              const double* __restrict__ Dspec, const StageP2<D>& st, double tau, double* y) {
     constexpr int NV = D + 1, ND = P2<D>::ND, NF = P2<D>::NF;
-    constexpr const int* FS = P2Tab<D>::FRAME_SLOTS[I];
     const uint32_t fb = (flags >> (8 * I)) & 0xffu;
     if (((fb >> 2) & 3u) != FK_SIPG) return;
     const int j = (int)(fb & 3u);
@@ -422,7 +443,7 @@ __device__ __forceinline__ void knp_facet_p2(const MeshDev& m, const CellGeom<D>
     {
         double Po[ND], Pn[ND];
 #pragma unroll
-        for (int s = 0; s < ND; ++s) Po[s] = pv[FS[s]];
+        for (int s = 0; s < ND; ++s) Po[s] = pv[P2<D>::fs(I, s)];
         if (MODE == 0) load_frame<D, 0, ND>(st.b + loc * ND, phi + Kp * ND, in_block, packed, Pn);
         else {
 #pragma unroll
@@ -435,7 +456,7 @@ __device__ __forceinline__ void knp_facet_p2(const MeshDev& m, const CellGeom<D>
     }
     double Fo[ND], Fn[ND];
 #pragma unroll
-    for (int s = 0; s < ND; ++s) Fo[s] = xv[FS[s]];
+    for (int s = 0; s < ND; ++s) Fo[s] = xv[P2<D>::fs(I, s)];
     if (MODE == 0) load_frame<D, 0, ND>(st.a + loc * ND, x + Kp * ND, in_block, packed, Fn);
     else {
 #pragma unroll
@@ -478,7 +499,7 @@ __device__ __forceinline__ void knp_facet_p2(const MeshDev& m, const CellGeom<D>
         for (int mm = 0; mm < D; ++mm) T[mm] = fma(t, P2Tab<D>::LAMK[q][mm], T[mm]);
     }
 #pragma unroll
-    for (int n = 0; n < NF; ++n) y[FS[1 + n]] += r[n];
+    for (int n = 0; n < NF; ++n) y[P2<D>::fs(I, 1 + n)] += r[n];
     back_project<D, I>(T, gnA, gnV, y);
 }
 
@@ -718,5 +739,143 @@ int p2_block_inverse(knp_ctx* c, int which, const double* coef, bjreal* binv) {
         else hipLaunchKernelGGL((k_p2_blockjacobi<2, false, CPB>), g, b, 0, c->stream, c->m, coef, (const double*)c->D, binv, c->p.C_phi, c->p.tau_emi, ka);
     }
     HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// FP64 MFMA probe: the one genuinely dense, cell-independent contraction of the P2 path -- the facet quadrature
+//   forward  [NQ x NF] . {jump(u), kappa, kappa'}  and  [NQ x D] . {dn u, dn u'},   pointwise flux,
+//   backward [NF x NQ] . flux  and  [D x NQ] . t
+// -- once as v_mfma_f64_16x16x4_f64 tiles (columns = 16 cell-facets per wave, the 4 lane groups hold the K index) and once
+// as the per-thread FMA chain the product kernel uses, on identical synthetic inputs [ncol][26] -> outputs [ncol][9].
+// knp_probe_facet_contraction times both; tests check that they agree.  Measured (profiles/r02_mfma_probe.md): the MFMA
+// form pads 12 x 6 / 6 x 12 / 3 x 12 to 16 x 16 x 4 tiles and runs at the same FP64 rate as the vector pipe, so it loses.
+// ------------------------------------------------------------------------------------------------------------------
+namespace {
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+struct ProbeTabs { double psi[16][8]; double lam[16][4]; double w[16]; };   // zero padded: [q][n], [q][m], [q]
+
+__global__ __launch_bounds__(256) void k_probe_valu(int64_t ncol, const double* __restrict__ in, double* __restrict__ out) {
+    constexpr int D = 3, NF = 6, NQ = P2Tab<3>::NQE;
+    const int64_t col = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= ncol) return;
+    const double* p = in + col * 26;
+    double ju[NF], ko[NF], kn[NF], dno[D], dnn[D];
+#pragma unroll
+    for (int n = 0; n < NF; ++n) { ju[n] = p[n]; ko[n] = p[6 + n]; kn[n] = p[12 + n]; }
+#pragma unroll
+    for (int m = 0; m < D; ++m) { dno[m] = p[18 + m]; dnn[m] = p[21 + m]; }
+    const double area = p[24], pen = p[25];
+    double r[NF] = {0, 0, 0, 0, 0, 0}, T[D] = {0, 0, 0};
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        double a = 0.0, b = 0.0, j = 0.0, d0 = 0.0, d1 = 0.0;
+#pragma unroll
+        for (int n = 0; n < NF; ++n) {
+            const double ps = P2Tab<3>::PSIE[q][n];
+            a = fma(ko[n], ps, a); b = fma(kn[n], ps, b); j = fma(ju[n], ps, j);
+        }
+#pragma unroll
+        for (int m = 0; m < D; ++m) { d0 = fma(dno[m], P2Tab<3>::LAME[q][m], d0); d1 = fma(dnn[m], P2Tab<3>::LAME[q][m], d1); }
+        const double w = P2Tab<3>::WE[q] * area;
+        const double flux = w * fma(pen * (a + b), j, -0.5 * fma(a, d0, b * d1));
+        const double t = -0.5 * w * a * j;
+#pragma unroll
+        for (int n = 0; n < NF; ++n) r[n] = fma(flux, P2Tab<3>::PSIE[q][n], r[n]);
+#pragma unroll
+        for (int m = 0; m < D; ++m) T[m] = fma(t, P2Tab<3>::LAME[q][m], T[m]);
+    }
+    double* o = out + col * 9;
+#pragma unroll
+    for (int n = 0; n < NF; ++n) o[n] = r[n];
+#pragma unroll
+    for (int m = 0; m < D; ++m) o[6 + m] = T[m];
+}
+
+// one wave = 16 columns; lane (g = lane >> 4, n = lane & 15): B operand element [k = g][col n], A operand element [row n][k = g],
+// C/D registers i = 0..3 hold rows g + 4 i of column n (cdna_hip_programming.md section 3, f64 layout)
+__global__ __launch_bounds__(256) void k_probe_mfma(int64_t ncol, const double* __restrict__ in, const ProbeTabs* __restrict__ tabs,
+                                                    double* __restrict__ out) {
+    const int lane = threadIdx.x & 63, g = lane >> 4, n = lane & 15;
+    const int64_t col0 = ((int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 16;
+    if (col0 >= ncol) return;                                   // whole wave
+    const int64_t col = (col0 + n < ncol) ? col0 + n : ncol - 1;
+    const double* p = in + col * 26;
+    // A operands: forward  A[q = n][k]  with k = g (step 0), 4 + g (step 1);  backward  A[m = n][q = g + 4 i]
+    const double aP0 = tabs->psi[n][g], aP1 = tabs->psi[n][4 + g], aL = tabs->lam[n][g];
+    double bP[3], bL[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { bP[i] = n < 8 ? tabs->psi[g + 4 * i][n] : 0.0; bL[i] = n < 4 ? tabs->lam[g + 4 * i][n] : 0.0; }
+    const double4_t z = {0.0, 0.0, 0.0, 0.0};
+    double4_t Dj = z, Da = z, Db = z, D0 = z, D1 = z;
+    // B operands: nodal values k = g and 4 + g of this column (k >= 6 / k >= 3 are padding)
+    Dj = __builtin_amdgcn_mfma_f64_16x16x4f64(aP0, p[g], Dj, 0, 0, 0);
+    Da = __builtin_amdgcn_mfma_f64_16x16x4f64(aP0, p[6 + g], Da, 0, 0, 0);
+    Db = __builtin_amdgcn_mfma_f64_16x16x4f64(aP0, p[12 + g], Db, 0, 0, 0);
+    const bool k1 = g < 2;
+    Dj = __builtin_amdgcn_mfma_f64_16x16x4f64(aP1, k1 ? p[4 + g] : 0.0, Dj, 0, 0, 0);
+    Da = __builtin_amdgcn_mfma_f64_16x16x4f64(aP1, k1 ? p[10 + g] : 0.0, Da, 0, 0, 0);
+    Db = __builtin_amdgcn_mfma_f64_16x16x4f64(aP1, k1 ? p[16 + g] : 0.0, Db, 0, 0, 0);
+    const bool k3 = g < 3;
+    D0 = __builtin_amdgcn_mfma_f64_16x16x4f64(aL, k3 ? p[18 + g] : 0.0, D0, 0, 0, 0);
+    D1 = __builtin_amdgcn_mfma_f64_16x16x4f64(aL, k3 ? p[21 + g] : 0.0, D1, 0, 0, 0);
+    const double area = p[24], pen = p[25];
+    double4_t R = z, T = z;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {                                // quadrature points q = g + 4 i of this column
+        const double w = tabs->w[g + 4 * i] * area;
+        const double a = Da[i], b = Db[i], j = Dj[i];
+        const double flux = w * fma(pen * (a + b), j, -0.5 * fma(a, D0[i], b * D1[i]));
+        const double t = -0.5 * w * a * j;
+        R = __builtin_amdgcn_mfma_f64_16x16x4f64(bP[i], flux, R, 0, 0, 0);
+        T = __builtin_amdgcn_mfma_f64_16x16x4f64(bL[i], t, T, 0, 0, 0);
+    }
+    if (col0 + n < ncol) {
+        double* o = out + (col0 + n) * 9;
+        o[g] = R[0];                                            // rows m = g
+        if (g < 2) o[4 + g] = R[1];                             // rows m = 4 + g
+        if (g < 3) o[6 + g] = T[0];
+    }
+}
+
+}  // namespace
+
+extern "C" int knp_probe_facet_contraction(knp_ctx* c, int variant, int64_t ncol, int reps, const double* in_host, double* out_host,
+                                           float* avg_ms) {
+    if (!c || ncol < 1 || reps < 1 || !in_host || !out_host || !avg_ms || (variant != 0 && variant != 1)) return -1;
+    double *in = nullptr, *out = nullptr;
+    ProbeTabs h{};
+    for (int q = 0; q < P2Tab<3>::NQE; ++q) {
+        for (int n = 0; n < 6; ++n) h.psi[q][n] = P2Tab<3>::PSIE[q][n];
+        for (int m = 0; m < 3; ++m) h.lam[q][m] = P2Tab<3>::LAME[q][m];
+        h.w[q] = P2Tab<3>::WE[q];
+    }
+    ProbeTabs* tabs = nullptr;
+    HIPCHK(c, hipMalloc((void**)&in, sizeof(double) * 26 * ncol));
+    HIPCHK(c, hipMalloc((void**)&out, sizeof(double) * 9 * ncol));
+    HIPCHK(c, hipMalloc((void**)&tabs, sizeof(ProbeTabs)));
+    HIPCHK(c, hipMemcpy(in, in_host, sizeof(double) * 26 * ncol, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(tabs, &h, sizeof(ProbeTabs), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemset(out, 0, sizeof(double) * 9 * ncol));
+    auto launch = [&]() {
+        if (variant == 0)
+            hipLaunchKernelGGL(k_probe_valu, dim3((unsigned)((ncol + 255) / 256)), dim3(256), 0, c->stream, ncol, (const double*)in, out);
+        else
+            hipLaunchKernelGGL(k_probe_mfma, dim3((unsigned)((ncol + 63) / 64)), dim3(256), 0, c->stream, ncol, (const double*)in,
+                               (const ProbeTabs*)tabs, out);
+    };
+    launch();
+    HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+    for (int i = 0; i < reps; ++i) launch();
+    HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+    HIPCHK(c, hipEventSynchronize(c->ev1));
+    HIPCHK(c, hipGetLastError());
+    float ms = 0.f;
+    HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    *avg_ms = ms / (float)reps;
+    HIPCHK(c, hipMemcpy(out_host, out, sizeof(double) * 9 * ncol, hipMemcpyDeviceToHost));
+    hipFree(in); hipFree(out); hipFree(tabs);
     return 0;
 }

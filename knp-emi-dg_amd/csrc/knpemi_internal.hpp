@@ -109,6 +109,10 @@ struct knp_ctx {
     int32_t* halo_send_idx = nullptr;   // device: owned cell ids to pack, grouped by peer
     double* halo_sendbuf = nullptr;
     int64_t halo_send_total = 0;
+    // optional in-solver timing of the operator applies (knp_apply_timing): event pairs recorded around every launch
+    bool time_applies = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> tev[2];   // [0] EMI, [1] KNP
+    size_t tev_used[2] = {0, 0};
     std::string err;
 };
 

@@ -55,6 +55,9 @@ SIGNATURES = {
     "knp_timer_begin": (C.c_int, [_ctxp]),
     "knp_timer_end": (C.c_int, [_ctxp, C.POINTER(C.c_float)]),
     "knp_bench_apply": (C.c_int, [_ctxp, C.c_int, C.c_int, C.POINTER(C.c_float)]),
+    "knp_probe_facet_contraction": (C.c_int, [_ctxp, C.c_int, C.c_int64, C.c_int, _f64p, _f64p, C.POINTER(C.c_float)]),
+    "knp_apply_timing": (C.c_int, [_ctxp, C.c_int]),
+    "knp_apply_timing_read": (C.c_int, [_ctxp, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
     "knp_comm_unique_id": (C.c_int, [C.c_char_p]),
     "knp_comm_init": (C.c_int, [_ctxp, C.c_int, C.c_int, C.c_char_p]),
     "knp_halo_tables": (C.c_int, [_ctxp, C.c_int, _i32p, _i64p, _i32p, _i64p, _i64p]),
@@ -402,6 +405,25 @@ class Device:
         self._chk(self.lib.knp_bench_apply(self.ctx, which, reps, C.byref(ms)), "knp_bench_apply")
         return ms.value
 
+    def apply_timing(self, enable):
+        self._chk(self.lib.knp_apply_timing(self.ctx, int(bool(enable))), "knp_apply_timing")
+
+    def apply_timing_read(self, which):
+        """(average ms, launches) of the operator applies issued inside the solves since the last read."""
+        ms, n = C.c_float(0), C.c_int(0)
+        self._chk(self.lib.knp_apply_timing_read(self.ctx, which, C.byref(ms), C.byref(n)), "knp_apply_timing_read")
+        return ms.value, n.value
+
+    def probe_facet_contraction(self, variant, inputs, reps=20):
+        """Diagnostic: the P2 facet-quadrature contraction as FMA chain (0) or FP64 MFMA tiles (1); returns (out, ms)."""
+        a = np.ascontiguousarray(inputs, dtype=np.float64)
+        assert a.ndim == 2 and a.shape[1] == 26
+        out = np.empty((a.shape[0], 9))
+        ms = C.c_float(0)
+        self._chk(self.lib.knp_probe_facet_contraction(self.ctx, int(variant), a.shape[0], int(reps), _p(a, _f64p), _p(out, _f64p),
+                                                       C.byref(ms)), "knp_probe_facet_contraction")
+        return out, ms.value
+
     # -- multi-GPU ---------------------------------------------------------------------
     def comm_init(self, rank, nranks, uid):
         self._chk(self.lib.knp_comm_init(self.ctx, rank, nranks, uid), "knp_comm_init")
@@ -524,7 +546,7 @@ def _flushing(fn):
 for _name in ("close", "set_params", "set_mms", "upload", "download", "copy_field", "update_kappa", "update_dnphi", "emi_apply",
               "knp_apply", "emi_rhs", "knp_rhs", "emi_solve", "knp_solve", "step_updates", "picard_updates", "max_abs_diff",
               "nernst", "sync", "timer_begin", "timer_end", "bench_apply", "ode_table", "ode_step", "ode_set_stimulus",
-              "amg_upload", "halo_exchange"):
+              "amg_upload", "halo_exchange", "apply_timing_read"):
     setattr(Device, _name, _flushing(getattr(Device, _name)))
 
 

@@ -203,7 +203,8 @@ def test_p2_edge_cases_and_argument_checks(hip_lib):
     assert dev.lib.knp_amg_columns(dev.ctx, 0, 2) != 0                                    # EMI hierarchy is single-column
     assert dev.lib.knp_amg_columns(dev.ctx, 1, 99) != 0
     dev.close()
-    # a degree-2 context whose tabulations were never uploaded must refuse to assemble
+    # a degree-2 context whose tabulations were never uploaded must refuse to integrate the right-hand sides (the operator
+    # applies are matrix-free and need none)
     ctx = C.c_void_p()
     from knpemidg._abi import load, _p, _f64p, _i32p, _u32p, _i8p
     lib = load()
@@ -215,7 +216,8 @@ def test_p2_edge_cases_and_argument_checks(hip_lib):
                             _p(np.ascontiguousarray(m.facet_local, dtype=np.int8), _i8p), _p(f.array().astype(np.uint32), _u32p), 1,
                             _p(mt, _u32p))
     assert rc == 0
-    assert lib.knp_update_kappa(ctx) != 0 and b"tabulation" in lib.knp_last_error(ctx)
+    assert lib.knp_update_kappa(ctx) == 0
+    assert lib.knp_emi_rhs(ctx) != 0 and b"tabulation" in lib.knp_last_error(ctx)
     lib.knp_ctx_destroy(ctx)
 
 
@@ -333,7 +335,7 @@ def test_stale_projection_result_raises(hip_lib):
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "idealized_geometries"))
     from idealized_common import make_solver
     from knpemidg.utils import pcws_constant_project, plus, minus
-    S = make_solver(dim=2, resolution=0)
+    S = make_solver(dim=2, resolution=1)
     a = pcws_constant_project(plus(S.c_prev_k.split()[0], S.n_g), S.Q)
     b = pcws_constant_project(minus(S.ion_list[-1]['c'], S.n_g), S.Q)
     va, vb = a.array(), b.array()
@@ -344,3 +346,33 @@ def test_stale_projection_result_raises(hip_lib):
     with pytest.raises(RuntimeError, match="overwritten"):
         a.array()
     S.dev.close()
+
+
+def test_fp64_mfma_probe_matches_fma_chain(hip_lib):
+    """The DG-P2 facet-quadrature contraction as v_mfma_f64_16x16x4_f64 tiles (diagnostic variant, csrc/apply_p2.hip) gives
+    the same numbers as the per-thread FMA chain of the product kernels -- and as the numpy formula -- on random inputs,
+    including a ragged column count (partial last tile)."""
+    import p2_formulation as pf
+    from knpemidg.mesh import make_mesh_2D
+    m, s, f = make_mesh_2D(0)
+    pb = ko.build_idealized(m, s.array(), f.array(), membrane_tags=(1,))
+    dev = device_for(pb)
+    rng = np.random.default_rng(7)
+    ncol = 16 * 37 + 5
+    a = rng.uniform(-1, 1, size=(ncol, 26))
+    a[:, 6:18] = rng.uniform(1, 2, size=(ncol, 12))             # kappa > 0
+    a[:, 24:] = rng.uniform(0.5, 1.5, size=(ncol, 2))
+    out0, _ = dev.probe_facet_contraction(0, a, reps=2)
+    out1, _ = dev.probe_facet_contraction(1, a, reps=2)
+    T = pf.load_tables(3)
+    ref = np.zeros((ncol, 9))
+    for q in range(len(T["WE"])):
+        psi, lam, w = T["PSIE"][q], T["LAME"][q], T["WE"][q] * a[:, 24]
+        ko_, kn_, jq = a[:, 6:12] @ psi, a[:, 12:18] @ psi, a[:, 0:6] @ psi
+        flux = w * (a[:, 25] * (ko_ + kn_) * jq - 0.5 * (ko_ * (a[:, 18:21] @ lam) + kn_ * (a[:, 21:24] @ lam)))
+        t = -0.5 * w * ko_ * jq
+        ref[:, :6] += flux[:, None] * psi[None, :]
+        ref[:, 6:] += t[:, None] * lam[None, :]
+    assert relerr(out0, ref) < 1e-13
+    assert relerr(out1, ref) < 1e-13
+    dev.close()
