@@ -27,7 +27,7 @@ from knpemidg.mesh import make_mesh_3D, make_mesh_2D           # noqa: E402
 
 STIMULUS = {"stim_amplitude": 10.0}                            # g_syn_bar, run_3D.py:148-153
 LOCATOR = lambda x: x[0] < 20.0e-6                             # noqa: E731   run_3D.py:153
-N_SAMPLE = 8192
+N_SAMPLE = 2048
 
 
 def mean_free(phi, vol):
