@@ -188,6 +188,16 @@ int knp_ode_exchange_multi(knp_ctx* ctx, int handle, int n, const int32_t* what,
 int knp_ode_set_stimulus(knp_ctx* ctx, int handle, int n_entries, const int32_t* cols, const double* values, const uint8_t* mask);
 int knp_ode_step(knp_ctx* ctx, int handle, double t0, double dt, double rtol, double atol);
 
+/* ---- host-side setup kernels (no device work): threaded sparse products of the preconditioner setup (knpemidg/amg.py), the
+ * counterpart of the BoomerAMG setup PETSc runs inside KSPSetUp (solver.py:433, 505, 688, 767).  CSR, int32 indices, fp64 values.
+ *  knp_host_spgemm: C = A B, A [n x k], B [k x m]; Cp[n+1] supplied by the caller, *Cj / *Cx allocated here (knp_host_free);
+ *                   sorted columns; nthreads <= 0 = all hardware threads; -3 if C exceeds 2^31 - 1 entries
+ *  knp_host_spmv  : y = A x */
+int knp_host_spgemm(int64_t n, int64_t m, const int32_t* Ap, const int32_t* Aj, const double* Ax, const int32_t* Bp, const int32_t* Bj,
+                    const double* Bx, int32_t* Cp, int32_t** Cj, double** Cx, int nthreads);
+int knp_host_spmv(int64_t n, const int32_t* Ap, const int32_t* Aj, const double* Ax, const double* x, double* y, int nthreads);
+void knp_host_free(void* p);
+
 /* ---- timing / sync ------------------------------------------------------------------------------ */
 int knp_sync(knp_ctx* ctx);
 int knp_timer_begin(knp_ctx* ctx);         /* records a HIP event on the context's stream */

@@ -6,6 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "knpemidg", "libknpemi_hip.so")
+HOST_SOURCES = ["host_sparse.cpp"]
 SOURCES = ["abi.hip", "apply_p1.hip", "rhs_p1.hip", "krylov.hip", "comm.hip", "amg.hip", "ode.hip", "tab_dg.hip", "apply_p2.hip"]
 
 
@@ -33,6 +34,12 @@ def build(force=False, verbose=False):
             cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
         procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
         objs.append(o)
+    # host-only setup kernels (threaded sparse products of the AMG setup): plain g++
+    for s in HOST_SOURCES:
+        o = os.path.join(CSRC, s.replace(".cpp", ".o"))
+        cmd = [os.environ.get("CXX", "g++"), "-O3", "-std=c++17", "-fPIC", "-pthread", "-c", os.path.join(CSRC, s), "-o", o]
+        procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+        objs.append(o)
     ok = True
     for s, p in procs:
         out, _ = p.communicate()
@@ -42,7 +49,7 @@ def build(force=False, verbose=False):
     if not ok:
         raise RuntimeError("hipcc failed")
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs + \
-          ["-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"]
+          ["-L/opt/rocm/lib", "-lrccl", "-lpthread", "-Wl,-rpath,/opt/rocm/lib"]
     subprocess.check_call(cmd)
     return OUT
 

@@ -58,6 +58,10 @@ SIGNATURES = {
     "knp_probe_facet_contraction": (C.c_int, [_ctxp, C.c_int, C.c_int64, C.c_int, _f64p, _f64p, C.POINTER(C.c_float)]),
     "knp_apply_timing": (C.c_int, [_ctxp, C.c_int]),
     "knp_apply_timing_read": (C.c_int, [_ctxp, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
+    "knp_host_spgemm": (C.c_int, [C.c_int64, C.c_int64, _i32p, _i32p, _f64p, _i32p, _i32p, _f64p, _i32p, C.POINTER(_i32p),
+                                  C.POINTER(_f64p), C.c_int]),
+    "knp_host_spmv": (C.c_int, [C.c_int64, _i32p, _i32p, _f64p, _f64p, _f64p, C.c_int]),
+    "knp_host_free": (None, [C.c_void_p]),
     "knp_comm_unique_id": (C.c_int, [C.c_char_p]),
     "knp_comm_init": (C.c_int, [_ctxp, C.c_int, C.c_int, C.c_char_p]),
     "knp_halo_tables": (C.c_int, [_ctxp, C.c_int, _i32p, _i64p, _i32p, _i64p, _i64p]),
@@ -101,6 +105,34 @@ def load():
 
 def _p(a, typ):
     return a.ctypes.data_as(typ) if a is not None else None
+
+
+def host_spgemm(A, B, nthreads=0):
+    """C = A @ B for scipy CSR matrices through the library's threaded Gustavson product (sorted indices)."""
+    import scipy.sparse as sp
+    lib = load()
+    A = A.tocsr(); B = B.tocsr()
+    n, m = A.shape[0], B.shape[1]
+    assert A.shape[1] == B.shape[0]
+    Ap, Aj = np.ascontiguousarray(A.indptr, dtype=np.int32), np.ascontiguousarray(A.indices, dtype=np.int32)
+    Bp, Bj = np.ascontiguousarray(B.indptr, dtype=np.int32), np.ascontiguousarray(B.indices, dtype=np.int32)
+    Ax, Bx = np.ascontiguousarray(A.data, dtype=np.float64), np.ascontiguousarray(B.data, dtype=np.float64)
+    Cp = np.empty(n + 1, dtype=np.int32)
+    cj, cx = _i32p(), _f64p()
+    rc = lib.knp_host_spgemm(n, m, _p(Ap, _i32p), _p(Aj, _i32p), _p(Ax, _f64p), _p(Bp, _i32p), _p(Bj, _i32p), _p(Bx, _f64p),
+                             _p(Cp, _i32p), C.byref(cj), C.byref(cx), int(nthreads))
+    if rc != 0:
+        raise KnpError("knp_host_spgemm failed (%d)" % rc)
+    nnz = int(Cp[-1])
+    try:
+        Cj = np.ctypeslib.as_array(cj, shape=(max(nnz, 1),))[:nnz].copy()
+        Cx = np.ctypeslib.as_array(cx, shape=(max(nnz, 1),))[:nnz].copy()
+    finally:
+        lib.knp_host_free(cj)
+        lib.knp_host_free(cx)
+    out = sp.csr_matrix((Cx, Cj, Cp), shape=(n, m))
+    out.has_sorted_indices = True
+    return out
 
 
 def morton_order(points, scale=None):

@@ -24,6 +24,32 @@ import scipy.sparse as sp
 import scipy.sparse.csgraph as csg
 
 
+def _assemble_cached(space, blk, nd):
+    """CSR matrix from per-cell dense blocks blk[c, a, b] scattered through space.dof.  The sparsity pattern (sort order of
+    the (row, col) keys and the segment starts) depends only on the dof map: computed on the first call and reused by every
+    later assembly on the same space (EMI and each KNP group, and every refresh of a lagged hierarchy)."""
+    import threading
+    lock = space.__dict__.setdefault("_pattern_lock", threading.Lock())
+    with lock:
+        pat = getattr(space, "_pattern", None)
+        if pat is None:
+            dof = space.dof.astype(np.int64)
+            key = (np.repeat(dof[:, :, None], nd, axis=2) * space.n + np.repeat(dof[:, None, :], nd, axis=1)).ravel()
+            order = np.argsort(key, kind="stable")
+            ks = key[order]
+            first = np.concatenate([[True], ks[1:] != ks[:-1]])
+            starts = np.nonzero(first)[0]
+            uk = ks[starts]
+            rows = uk // space.n
+            indptr = np.concatenate([[0], np.cumsum(np.bincount(rows, minlength=space.n))]).astype(np.int32)
+            pat = space._pattern = (order, starts, (uk % space.n).astype(np.int32), indptr)
+    order, starts, indices, indptr = pat
+    data = np.add.reduceat(blk.ravel()[order], starts)
+    A = sp.csr_matrix((data, indices, indptr), shape=(space.n, space.n))
+    A.has_sorted_indices = True
+    return A
+
+
 # ----------------------------------------------------------------------------------------------
 # conforming (membrane-broken) P1 space
 # ----------------------------------------------------------------------------------------------
@@ -62,9 +88,7 @@ class ConformingSpace:
         if mass_coef is not None:
             Mloc = (np.ones((nv, nv)) + np.eye(nv)) / ((d + 1) * (d + 2))
             blk = blk + (mass_coef * vol)[:, None, None] * Mloc[None]
-        rows = np.repeat(self.dof[:, :, None], nv, axis=2).ravel()
-        cols = np.repeat(self.dof[:, None, :], nv, axis=1).ravel()
-        A = sp.coo_matrix((blk.ravel(), (rows, cols)), shape=(self.n, self.n))
+        A = _assemble_cached(self, blk, nv)
         if membrane is not None:
             fids, C = membrane
             fcl = mesh.facet_cells[fids]
@@ -144,9 +168,7 @@ class ConformingSpaceP2:
         if mass_coef is not None:
             Mref = np.einsum("q,qa,qb->ab", w, B, B)
             blk = blk + (np.asarray(mass_coef) * vol)[:, None, None] * Mref[None]
-        rows = np.repeat(self.dof[:, :, None], nd, axis=2).ravel()
-        cols = np.repeat(self.dof[:, None, :], nd, axis=1).ravel()
-        A = sp.coo_matrix((blk.ravel(), (rows, cols)), shape=(self.n, self.n))
+        A = _assemble_cached(self, blk, nd)
         if membrane is not None:
             fids, C = membrane
             fcl = mesh.facet_cells[fids]
@@ -233,6 +255,17 @@ class Level:
     pass
 
 
+def _spgemm(A, B):
+    """Sparse product through the library's threaded Gustavson kernel (csrc/host_sparse.cpp)."""
+    from knpemidg import _abi
+    return _abi.host_spgemm(A, B)
+
+
+def _scale_rows(A, v):
+    A = A.tocsr()
+    return sp.csr_matrix((A.data * np.repeat(v, np.diff(A.indptr)), A.indices, A.indptr), shape=A.shape)
+
+
 def build_hierarchy(A, theta=0.08, max_coarse=4000, max_levels=12, cheb_degree=2, cheb_lower=0.3, psmooth=2, trunc=0.04,
                     top_interp=None, top_degree=3, top_lower=0.1, level0_degree=None):
     """Smoothed-aggregation hierarchy for an SPD (possibly singular, constants) matrix.
@@ -273,17 +306,17 @@ def build_hierarchy(A, theta=0.08, max_coarse=4000, max_levels=12, cheb_degree=2
             lv.P = P
             lv.R = P.T.tocsr()
             lv.R.sort_indices()
-            A = (lv.R @ A @ P).tocsr()
-            A.sort_indices()
+            A = _spgemm(lv.R, _spgemm(A, P))
             Bnull = np.ones(A.shape[0])          # the geometric interpolation reproduces constants exactly
             continue
         if n <= max_coarse or len(levels) >= max_levels:
             break
         # symmetric strength of connection
-        C = A.tocoo()
-        off = C.row != C.col
-        strong = off & (np.abs(C.data) >= theta * np.sqrt(np.abs(d[C.row] * d[C.col])))
-        S = sp.csr_matrix((np.ones(int(strong.sum())), (C.row[strong], C.col[strong])), shape=A.shape)
+        A.sort_indices()
+        rowid = np.repeat(np.arange(n), np.diff(A.indptr))
+        strong = (rowid != A.indices) & (np.abs(A.data) >= theta * np.sqrt(np.abs(d[rowid] * d[A.indices])))
+        S = sp.csr_matrix((np.ones(int(strong.sum())), A.indices[strong],
+                           np.concatenate([[0], np.cumsum(np.bincount(rowid[strong], minlength=n))])), shape=A.shape)
         agg, nagg = mis2_aggregate(S, seed=len(levels))
         if nagg >= n:
             break
@@ -298,17 +331,22 @@ def build_hierarchy(A, theta=0.08, max_coarse=4000, max_levels=12, cheb_degree=2
         # ~0.25 (CG on Ac: 39 -> 13 iterations at r=1) for 1.8x the operator complexity
         omega = (4.0 / 3.0) / lv.rho
         P = T
+        DA = _scale_rows(A, omega * lv.dinv)                       # omega D^-1 A, once per level
         for _ in range(psmooth):
-            P = (P - sp.diags(omega * lv.dinv) @ (A @ P)).tocsr()
+            P = (P - _spgemm(DA, P)).tocsr()
         if trunc > 0:
             # prolongator truncation: drop entries below trunc * (row maximum) and rescale every row so that the
             # coarse near-null-space vector is still interpolated to the same fine values; keeps the convergence of
             # the smoothed prolongator at less than half its operator complexity (3.84 -> 1.57 at r=1)
-            Pc = P.tocoo()
+            P.sort_indices()
+            absd = np.abs(P.data)
+            nzr = np.diff(P.indptr) > 0
             rowmax = np.zeros(n)
-            np.maximum.at(rowmax, Pc.row, np.abs(Pc.data))
-            keep = np.abs(Pc.data) >= trunc * rowmax[Pc.row]
-            Pt = sp.csr_matrix((Pc.data[keep], (Pc.row[keep], Pc.col[keep])), shape=P.shape)
+            rowmax[nzr] = np.maximum.reduceat(absd, P.indptr[:-1][nzr])
+            rowid = np.repeat(np.arange(n), np.diff(P.indptr))
+            keep = absd >= trunc * rowmax[rowid]
+            Pt = sp.csr_matrix((P.data[keep], P.indices[keep], np.concatenate([[0], np.cumsum(np.bincount(rowid[keep], minlength=n))])),
+                               shape=P.shape)
             Bc = nrm
             tgt, got = P @ Bc, Pt @ Bc
             P = (sp.diags(np.where(np.abs(got) > 1e-300, tgt / np.where(got == 0, 1.0, got), 1.0)) @ Pt).tocsr()
@@ -316,21 +354,48 @@ def build_hierarchy(A, theta=0.08, max_coarse=4000, max_levels=12, cheb_degree=2
         lv.P = P
         lv.R = P.T.tocsr()
         lv.R.sort_indices()
-        A = (lv.R @ A @ P).tocsr()
-        A.sort_indices()
+        A = _spgemm(lv.R, _spgemm(A, P))
         Bnull = nrm
     last = levels[-1]
-    # dense pseudo-inverse through the eigen-decomposition: the constant mode of the singular EMI operator reaches
-    # the coarsest level as a tiny but non-zero eigenvalue (smoothed prolongators do not reproduce constants to
-    # rounding); inverting it would put a huge indefinite component into the V-cycle, so everything below 1e-9 of
-    # the largest eigenvalue counts as null space
-    w, V = np.linalg.eigh(0.5 * (last.A.toarray() + last.A.toarray().T))
-    keep = w > 1e-9 * w.max()
-    Pi = (V[:, keep] / w[keep]) @ V[:, keep].T
-    # the device keeps the pseudo-inverse in fp32 (halves the coarse-solve traffic); symmetrise first so that the rounded
-    # operator is still exactly symmetric, and keep the rounded values here so host and device apply the same operator
-    last.pinv = (0.5 * (Pi + Pi.T)).astype(np.float32).astype(np.float64)
+    last.pinv = _coarse_pseudo_inverse(last.A, Bnull)
     return levels
+
+
+def _coarse_pseudo_inverse(A, Bnull):
+    """Dense (pseudo-)inverse of the coarsest operator, rounded to fp32 (the device stores it in fp32).
+    The constant mode of the singular EMI operator reaches the coarsest level as a tiny but non-zero eigenvalue (smoothed
+    prolongators do not reproduce constants to rounding): inverting it would put a huge component into the V-cycle.  With the
+    coarse near-null-space candidate n (carried down the hierarchy, |n| = 1) the deflated inverse
+        A^+  =  (A + s n n^T)^-1  -  n n^T / s ,      s = mean diagonal,
+    is exact for A n = 0 and costs one Cholesky-based inverse (LAPACK potrf / potri, threaded) instead of a full
+    eigen-decomposition -- 19 s -> 0.6 s for the 3 089-dof coarsest level of the r=2 mesh.  The nonsingular KNP operators
+    (mass term) take the plain inverse.  Anything else (several null vectors: subdomains without any coupling) falls back
+    to the eigen-decomposition, where everything below 1e-9 of the largest eigenvalue counts as null space."""
+    import scipy.linalg as sla
+    Ad = A.toarray()
+    Ad = 0.5 * (Ad + Ad.T)
+    N = Ad.shape[0]
+    nvec = np.asarray(Bnull, dtype=np.float64) / max(np.linalg.norm(Bnull), 1e-300)
+    s = float(np.trace(Ad)) / max(N, 1)
+    rayleigh = float(nvec @ (Ad @ nvec))
+    Pi = None
+    try:
+        if rayleigh < 1e-7 * s:                                   # (near-)singular along the candidate
+            M = Ad + s * np.outer(nvec, nvec)
+            Pi = sla.cho_solve(sla.cho_factor(M, lower=True, check_finite=False), np.eye(N), check_finite=False) - np.outer(nvec, nvec) / s
+        else:
+            Pi = sla.cho_solve(sla.cho_factor(Ad, lower=True, check_finite=False), np.eye(N), check_finite=False)
+        if not np.isfinite(Pi).all() or np.abs(Pi).max() * s > 1e10:     # another (near-)null vector is hiding in there
+            Pi = None
+    except (np.linalg.LinAlgError, sla.LinAlgError, ValueError):
+        Pi = None
+    if Pi is None:
+        w, V = np.linalg.eigh(Ad)
+        keep = w > 1e-9 * w.max()
+        Pi = (V[:, keep] / w[keep]) @ V[:, keep].T
+    # symmetrise before rounding so that the fp32 operator is still exactly symmetric; keep the rounded values here so that
+    # host and device apply the same operator
+    return (0.5 * (Pi + Pi.T)).astype(np.float32).astype(np.float64)
 
 
 def cheb_coefficients(rho, degree, lower):

@@ -257,6 +257,20 @@ class Solver:
         # direct_emi (MUMPS in the reference, solver.py:412-422) is emulated by a tightly converged PCG with the plain
         # block-Jacobi preconditioner: it stays SPD to rounding for any coefficient contrast (the MMS problem couples
         # the membrane with C_phi = 1e10), which a V-cycle does not
+        if self.use_amg and not self.direct_knp and os.environ.get("KNP_AMG_SERIAL_SETUP", "0") != "1":
+            # the KNP hierarchy depends only on the mesh, D_k and dt: build it on a host thread while this thread builds the
+            # EMI hierarchy (LAPACK and the library's threaded sparse products release the GIL); setup_solver_knp joins
+            import threading
+            self._amg_global()
+            self._knp_build = {}
+
+            def work():
+                try:
+                    self._knp_build["groups"] = self._build_amg_knp()
+                except BaseException as e:          # re-raised by setup_solver_knp
+                    self._knp_build["error"] = e
+            self._knp_thread = threading.Thread(target=work, name="knp-amg-setup")
+            self._knp_thread.start()
         if self.use_amg and not self.direct_emi:
             self._setup_amg_emi()
         return
@@ -272,6 +286,7 @@ class Solver:
         if gmesh is self.mesh:
             dev.update_kappa()
             kappa = dev.download(_abi.F_KAPPA).reshape(self.mesh.num_cells(), self.nd)
+            self._amg_kappa0 = kappa.ravel().copy()          # what the hierarchy was built from (refresh policy)
         else:
             # distributed: every rank builds the SAME global hierarchy from the tag-wise initial state (no
             # communication; the preconditioner is lagged anyway)
@@ -302,6 +317,33 @@ class Solver:
         if self.verbose:
             print(" AMG(EMI) levels:", [lv.A.shape[0] for lv in levels], "setup %.2f s" % self.amg_setup_timer)
 
+    def _maybe_refresh_amg_emi(self, niter):
+        """Refresh policy of the lagged EMI hierarchy.  The reference rebuilds BoomerAMG from the freshly assembled B_emi at
+        EVERY solve (solver.py:479, 505); here the hierarchy is built from kappa at setup time and rebuilt when it has gone
+        stale: (a) kappa has moved by more than KNP_AMG_REFRESH_KAPPA (default 25 %) anywhere since the last build (checked
+        every KNP_AMG_REFRESH_EVERY = 50 solves), or (b) the PCG iteration count has stayed above 3x its post-build level for 10 consecutive solves.
+        (The KNP hierarchies depend on the mesh, D_k and dt only -- nothing to refresh.)"""
+        if not (self.use_amg and not self.direct_emi) or getattr(self, "local_mesh", None) is not None:
+            return
+        st = self.__dict__.setdefault("_amg_refresh", {"solves": 0, "ref": None, "high": 0})
+        st["solves"] += 1
+        if st["ref"] is None and st["solves"] >= 3:
+            st["ref"] = max(1, min(self.emi_niter[-2:]))
+        stale = False
+        if st["ref"] is not None:
+            st["high"] = st["high"] + 1 if niter > 3 * st["ref"] + 2 else 0
+            stale = st["high"] >= 10
+        if st["solves"] % int(os.environ.get("KNP_AMG_REFRESH_EVERY", 50)) == 0:
+            kap, k0 = self.dev.download(_abi.F_KAPPA), self._amg_kappa0
+            lim = float(os.environ.get("KNP_AMG_REFRESH_KAPPA", 0.25))
+            stale = stale or bool(np.max(np.abs(kap - k0) / np.abs(k0)) > lim)
+        if stale:
+            if self.verbose:
+                print(" AMG(EMI): hierarchy refreshed (kappa drift / iteration count)")
+            self._setup_amg_emi()
+            self.amg_refreshes = getattr(self, "amg_refreshes", 0) + 1
+            self._amg_refresh = {"solves": 0, "ref": None, "high": 0}
+
     def setup_solver_knp(self):
         if self.use_amg and not self.direct_knp:
             self._setup_amg_knp()
@@ -331,11 +373,11 @@ class Solver:
             q[tags == int(key)] = float(value)
         return q
 
-    def _setup_amg_knp(self):
-        """Preconditioner of the KNP systems (reference: BoomerAMG on AA_knp, solver.py:688, 767): per species the
-        conforming-P1 operator  1/dt M + D_k K  (symmetric part; the drift enters only the Krylov operator)."""
+    def _build_amg_knp(self):
+        """Host part of the KNP preconditioner setup (reference: BoomerAMG on AA_knp, solver.py:688, 767): per species (or
+        per group of species with close diffusion coefficients) the conforming operator  1/dt M + D_k K  (symmetric part; the
+        drift enters only the Krylov operator) and its smoothed-aggregation hierarchy.  Returns [(members, levels)]."""
         from knpemidg import amg
-        ts = time.perf_counter()
         gmesh, gsub, gsurf = self._amg_global()
         nc = gmesh.num_cells()
         Dk = [self._by_tag(ion['D_sub'], gsub) for ion in self.ion_list[:-1]]
@@ -346,10 +388,10 @@ class Solver:
         shared = (len(Dk) > 1 and os.environ.get("KNP_AMG_SHARED", "1") == "1"
                   and all(np.all(np.abs(D[pos] / Dk[0][pos] - 1.0) < 0.25) and np.all((D > 0) == pos) for D in Dk[1:]))
         groups = [(list(range(len(Dk))), np.mean(Dk, axis=0))] if shared else [([k], D) for k, D in enumerate(Dk)]
+        out = []
         for members, D in groups:
             if self.degree_knp == 1:
                 Ac = self._cspace.stiffness(D, mass_coef=np.full(nc, 1.0 / _f(self.dt)))
-                # 10 -> 8 BiCGStab iterations once P is truncated; one Jacobi step on the finest level is enough
                 # one GPU: one Jacobi step on the finest conforming level.  With a communicator the hierarchy is replicated and
                 # the restricted residual is all-reduced: a transfer-only finest level lets that happen on level 1 (6.5x fewer
                 # bytes, no replicated level-0 SpMVs) for ~20 % more iterations
@@ -359,6 +401,21 @@ class Solver:
             else:
                 Ac = self._cspace2.stiffness(D, mass_coef=np.full(nc, 1.0 / _f(self.dt)))
                 levels = amg.build_hierarchy(Ac, psmooth=int(os.environ.get("KNP_AMG_PSMOOTH_KNP", 2)), top_interp=self._cspace2.interp)
+            out.append((members, levels))
+        return out
+
+    def _setup_amg_knp(self):
+        ts = time.perf_counter()
+        th = getattr(self, "_knp_thread", None)
+        if th is not None:
+            th.join()
+            self._knp_thread = None
+            if "error" in self._knp_build:
+                raise self._knp_build["error"]
+            groups = self._knp_build.pop("groups")
+        else:
+            groups = self._build_amg_knp()
+        for members, levels in groups:
             self.dev.amg_upload(1 + members[0], self._local_dg2cg(), levels, ncol=len(members))
             for k in members[1:]:
                 self.dev.amg_clear(1 + k)
@@ -423,6 +480,7 @@ class Solver:
             print(f"{bcolors.OKGREEN} GPU Execution time PDE solve emi: {res:.4f} seconds ({niter} its) {bcolors.ENDC}")
         self.emi_solve_timer += res
         self.emi_niter.append(niter)
+        self._maybe_refresh_amg_emi(niter)
         if self.save_solver_stats:
             if not self.direct_emi:
                 self.file_emi_niter.write("niter: %d \n" % niter)

@@ -484,3 +484,28 @@ def test_knp_hierarchy_shared_or_per_species(hip_lib, monkeypatch, shared):
         ko.solve_for_time_step(pb, direct=True)
         assert relerr(S.c.array(), pb.c) < 1e-8
     assert max(max(n) for n in S.knp_niter) < 60          # the auxiliary space is active (block-Jacobi alone needs hundreds)
+
+
+def test_amg_hierarchy_is_refreshed_when_kappa_drifts(hip_lib, monkeypatch):
+    """The reference rebuilds its AMG preconditioner at every solve (solver.py:505); this build lags it and refreshes when the
+    coefficient has drifted (Solver._maybe_refresh_amg_emi): after the concentrations are scaled by 1.6 mid-run the EMI
+    hierarchy is rebuilt from the new kappa and the solves keep converging in a handful of iterations."""
+    from common_examples import make_solver, solver_parameters, Constant
+    monkeypatch.setenv("KNP_AMG_REFRESH_EVERY", "2")
+    S = make_solver(dim=3, resolution=0, n_axons=1)
+    S._unpack_solver_params(solver_parameters(3, 0))
+    S.save_fields = S.save_solver_stats = False
+    S.splitting_scheme = True
+    S.setup_varform_emi(); S.setup_varform_knp(); S.setup_solver_emi(); S.setup_solver_knp()
+    t = Constant(0.0)
+    for k in range(4):
+        S.step_membrane_models(k); S.solve_for_time_step(k, t)
+    assert getattr(S, "amg_refreshes", 0) == 0
+    before = max(S.emi_niter)
+    for f in (S.c, S.c_prev_n, S.ion_list[-1]['c']):
+        f.set(1.6 * f.array())
+    for k in range(4, 10):
+        S.step_membrane_models(k); S.solve_for_time_step(k, t)
+    assert S.amg_refreshes >= 1
+    assert max(S.emi_niter[-3:]) <= 2 * before + 4, S.emi_niter
+    S.dev.close()
