@@ -21,7 +21,7 @@ from knpemidg.utils import pcws_constant_project, plus, minus                # n
 from knpemidg.models import mm_glial, mm_hh_emix                             # noqa: E402
 from knpemidg.h5lite import read_xdmf_mesh                                   # noqa: E402
 
-MESH_XDMF = os.path.join(os.path.dirname(os.path.dirname(HERE)), "tests", "golden", "emix_mesh", "mesh.xdmf")   # input-data fixture
+MESH_XDMF = os.path.join(HERE, "meshes", "volume_ncells_5_size_5000", "mesh.xdmf")        # the reference's bundled input mesh (data)
 # label -> subdomain: 1 = ECS -> 0; 2, 3 = neurons -> 2; 4, 5, 6 = glial cells -> 1   (run_EMIx_simulation.py:173-185)
 LABEL_TO_SUBDOMAIN = {1: 0, 2: 2, 3: 2, 4: 1, 5: 1, 6: 1}
 
@@ -103,3 +103,12 @@ def make_solver(dt=0.1, degree=1, verbose=False, mesh_tuple=None):
     S.setup_FEM_spaces()
     S.setup_membrane_model(stim, {1: mm_glial, 2: mm_hh_emix})                           # run_EMIx_simulation.py:249
     return S
+
+
+def make_distributed_solver(rank, world, local_rank, dist, dt=0.1, degree=1, mesh_tuple=None):
+    """BASELINE configs[4] on `world` GPUs: recursive-coordinate-bisection partition of the reconstruction, one ghost layer,
+    RCCL halo exchange + all-reduced Krylov reductions (knpemidg/partition.py)."""
+    from knpemidg.partition import distribute_solver
+    params, ion_list, stim = physical_setup(dt)
+    return distribute_solver(lambda: SolverEMIx(params, ion_list, degree_emi=degree, degree_knp=degree), mesh_tuple or load_mesh(),
+                             {1: mm_glial, 2: mm_hh_emix}, stim, rank, world, local_rank, dist, method="rcb")

@@ -222,6 +222,11 @@ int knp_probe_facet_contraction(knp_ctx* ctx, int variant, int64_t ncol, int rep
  * Replaces DOLFIN ghosting + PETSc VecGhost/MatMult scatters + KSP reductions (solver.py:16,529,789). */
 int knp_comm_unique_id(char* out128);
 int knp_comm_init(knp_ctx* ctx, int rank, int nranks, const char* id128);
+/* Optional second communicator (its own unique id) + stream for the halo exchanges, so that the exchange of an apply's input
+ * overlaps the launch over the interior cells; knp_set_interior declares how many leading owned cells have no ghost neighbour
+ * (checked).  Without these two calls every exchange runs on the context's stream in front of the apply. */
+int knp_comm_init_halo(knp_ctx* ctx, const char* id128);
+int knp_set_interior(knp_ctx* ctx, int64_t n_interior);
 /* send_cells: owned cell ids whose DoFs peer p needs, grouped by peer; ghosts of peer p occupy
  * cells [recv_offsets[p], recv_offsets[p]+recv_counts[p]). */
 int knp_halo_tables(knp_ctx* ctx, int npeers, const int32_t* peers, const int64_t* send_counts,

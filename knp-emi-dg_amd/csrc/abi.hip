@@ -173,6 +173,7 @@ int knp_ctx_create(knp_ctx** out, int device, int dim, int degree, int n_ions, i
 
     MeshDev& m = c->m;
     m.dim = dim; m.nv = nv; m.nc = nc; m.nc_owned = nc_owned; m.nf = nf; m.nmf = (int64_t)mf.size() / 6;
+    m.c_begin = 0; m.c_end = nc_owned; m.n_interior = nc_owned;
     std::vector<double> cpad;
     const double* csrc = coords;
     size_t cstride = dim;
@@ -383,16 +384,14 @@ int knp_emi_apply(knp_ctx* c, int fx, int fy) {
     if (!c) return -1;
     if (chk_vec(c, fx, fy, c->m.nc * c->nd)) return -1;
     Fields* f = F(c);
-    if (c->dist) { int rc = halo_exchange(c, f->f[fx], 1); if (rc) return rc; }
-    return launch_emi_apply(c, f->f[fx], f->f[KNP_F_KAPPA], f->f[fy]);
+    return dist_apply(c, 0, f->f[fx], f->f[KNP_F_KAPPA], f->f[fy]);
 }
 
 int knp_knp_apply(knp_ctx* c, int fx, int fy) {
     if (!c) return -1;
     if (chk_vec(c, fx, fy, (int64_t)c->p.n_sys * c->m.nc * c->nd)) return -1;
     Fields* f = F(c);
-    if (c->dist) { int rc = halo_exchange(c, f->f[fx], c->p.n_sys); if (rc) return rc; }
-    return launch_knp_apply(c, f->f[fx], f->f[KNP_F_DNPHI], f->f[fy]);
+    return dist_apply(c, 1, f->f[fx], f->f[KNP_F_DNPHI], f->f[fy]);
 }
 
 int knp_emi_rhs(knp_ctx* c) {
@@ -591,6 +590,20 @@ int knp_apply_timing_read(knp_ctx* c, int which, float* avg_ms, int* count) {
     *count = (int)c->tev_used[which];
     *avg_ms = *count ? (float)(sum / *count) : 0.f;
     c->tev_used[which] = 0;
+    return 0;
+}
+
+/* Owned cells [0, n_interior) of the device order have no ghost neighbour: with a communicator their part of an operator apply is
+ * launched while the halo exchange of the input vector is in flight, the remaining owned cells after it (comm.hip: dist_apply). */
+int knp_set_interior(knp_ctx* c, int64_t n_interior) {
+    if (!c) return -1;
+    if (n_interior < 0 || n_interior > c->m.nc_owned) { c->err = "set_interior: out of range"; return -1; }
+    // every owned cell below n_interior must really be interior (checked once on the host copy of the neighbour table)
+    std::vector<int32_t> nbr((size_t)c->m.nc_owned * (c->m.dim + 1));
+    HIPCHK(c, hipMemcpy(nbr.data(), c->m.nbr, sizeof(int32_t) * nbr.size(), hipMemcpyDeviceToHost));
+    for (int64_t k = 0; k < n_interior * (c->m.dim + 1); ++k)
+        if (nbr[k] >= c->m.nc_owned) { c->err = "set_interior: a cell below n_interior has a ghost neighbour"; return -1; }
+    c->m.n_interior = n_interior;
     return 0;
 }
 

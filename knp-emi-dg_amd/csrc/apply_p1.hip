@@ -38,34 +38,20 @@ template <int D, int I, int MODE>
 __device__ __forceinline__ void emi_facet(const MeshDev& m, const CellGeom<D>& K, const int* nb, uint32_t flags,
                                           const double* xv, const double* kv, double hK,
                                           const double* __restrict__ x, const double* __restrict__ kappa,
-                                          double C_phi, double tau, const StageView<D>& st, double* y) {
+                                          double C_phi, double tau, double* y) {
+    // MODE 0: apply (neighbour data gathered from global memory); MODE 1: cell-diagonal block (neighbour values 0)
     constexpr int NV = D + 1;
     const uint32_t fb = (flags >> (8 * I)) & 0xffu;
     const uint32_t kind = (fb >> 2) & 3u;
     if (kind >= FK_EXTERIOR) return;
     const int j = (int)(fb & 3u);
     const int64_t Kp = nb[I];
-    // Neighbour data: unconditional LDS read at a clamped slot + global load only for the lanes whose
-    // neighbour lives outside this workgroup (kept as two separate accesses so that the compiler emits
-    // ds_read + exec-masked global_load instead of a pointer select + flat_load).
-    const unsigned loc0 = (unsigned)(Kp - st.c0);
-    constexpr bool DIAG = (MODE == 1);
-    const bool in_block = (MODE == 2 || MODE == 4) && loc0 < st.nvalid;
-    const unsigned loc = in_block ? loc0 : 0u;
     double xn[NV];
-    if (DIAG) {
+    if (MODE == 1) {
 #pragma unroll
         for (int a = 0; a < NV; ++a) xn[a] = 0.0;
-    } else if (MODE == 0 || MODE == 3) {
-        load_nodal<D>(x, Kp, xn);
     } else {
-        double xl[NV], xg[NV];
-        lds_nodal<D>(st.x, loc, xl);
-#pragma unroll
-        for (int a = 0; a < NV; ++a) xg[a] = 0.0;
-        if (!in_block) load_nodal<D>(x, Kp, xg);
-#pragma unroll
-        for (int a = 0; a < NV; ++a) xn[a] = in_block ? xl[a] : xg[a];
+        load_nodal<D>(x, Kp, xn);
     }
     double du[D], sdu = 0.0;
 #pragma unroll
@@ -74,53 +60,18 @@ __device__ __forceinline__ void emi_facet(const MeshDev& m, const CellGeom<D>& K
         sdu += du[mm];
     }
     const double DV = (double)D * K.vol;
-    // MODE 3: per-class record  [0] vol, [1..10] G upper triangle, [11+6i .. +3] L_i, [+4] sqrt(G_ii), [+5] 2/(hK+hN_i)
-    const double sqG = (MODE == 3) ? st.rec[11 + 6 * I + 4] : ((MODE == 4) ? st.lrec[11 + 6 * I + 4] : fast_sqrt(K.G[I][I]));
+    const double sqG = fast_sqrt(K.G[I][I]);
     if (kind == FK_MEMBRANE) {
         const double w = C_phi * sqG * DV * FacetConst<D>::mass;
 #pragma unroll
         for (int mm = 0; mm < D; ++mm) y[mm + (mm >= I)] = fma(w, sdu + du[mm], y[mm + (mm >= I)]);
         return;
     }
-    double kn[NV], Xo[D], L[NV], hN = 1.0;
-    if (MODE == 3) {
-        load_nodal<D>(kappa, Kp, kn);
-#pragma unroll
-        for (int a = 0; a < NV; ++a) L[a] = st.rec[11 + 6 * I + a];
-    } else if (MODE == 4) {
-        double kl[NV], kg[NV];
-        lds_nodal<D>(st.k, loc, kl);
-#pragma unroll
-        for (int a = 0; a < NV; ++a) kg[a] = 0.0;
-        if (!in_block) load_nodal<D>(kappa, Kp, kg);
-#pragma unroll
-        for (int a = 0; a < NV; ++a) { kn[a] = in_block ? kl[a] : kg[a]; L[a] = st.lrec[11 + 6 * I + a]; }
-    } else if (MODE != 2) {
-        load_nodal<D>(kappa, Kp, kn);
-        hN = m.h[Kp];
-        load_vertex<D>(m.coords, m.cells[Kp * NV + j], Xo);
-    } else {
-        double kl[NV], kg[NV], Xl[D], Xg[D];
-        lds_nodal<D>(st.k, loc, kl);
-        const double hl = st.h[loc];
-        double hg = 0.0;
-        const lds_double* xa = st.X + (loc * NV + (in_block ? j : 0)) * D;
-#pragma unroll
-        for (int q = 0; q < D; ++q) { Xl[q] = xa[q]; Xg[q] = 0.0; }
-#pragma unroll
-        for (int a = 0; a < NV; ++a) kg[a] = 0.0;
-        if (!in_block) {
-            load_nodal<D>(kappa, Kp, kg);
-            hg = m.h[Kp];
-            load_vertex<D>(m.coords, m.cells[Kp * NV + j], Xg);
-        }
-#pragma unroll
-        for (int a = 0; a < NV; ++a) kn[a] = in_block ? kl[a] : kg[a];
-#pragma unroll
-        for (int q = 0; q < D; ++q) Xo[q] = in_block ? Xl[q] : Xg[q];
-        hN = in_block ? hl : hg;
-    }
-    if (MODE != 3 && MODE != 4) apex_bary<D>(K, Xo, L);
+    double kn[NV], Xo[D], L[NV];
+    load_nodal<D>(kappa, Kp, kn);
+    const double hN = m.h[Kp];
+    load_vertex<D>(m.coords, m.cells[Kp * NV + j], Xo);
+    apex_bary<D>(K, Xo, L);
     const double rLi = fast_rcp(L[I]);
     // s = grad u . g_i on both sides
     double s_own = 0.0;
@@ -143,8 +94,7 @@ __device__ __forceinline__ void emi_facet(const MeshDev& m, const CellGeom<D>& K
 #pragma unroll
     for (int a = 0; a < NV; ++a) y[a] = fma(K.G[a][I], q, y[a]);
     // penalty: tau/avg(h) int avg(k) jump(u) v
-    const double hinv = (MODE == 3) ? st.rec[11 + 6 * I + 5] : ((MODE == 4) ? st.lrec[11 + 6 * I + 5] : fast_rcp(0.5 * (hK + hN)));
-    const double pw = tau * hinv * sqG * DV * FacetConst<D>::trip;
+    const double pw = tau * fast_rcp(0.5 * (hK + hN)) * sqG * DV * FacetConst<D>::trip;
     double kb[D], skb = 0.0, skd = 0.0;
 #pragma unroll
     for (int mm = 0; mm < D; ++mm) {
@@ -254,7 +204,7 @@ template <int D, int MODE>
 __device__ __forceinline__ void emi_cell(const MeshDev& m, const CellGeom<D>& K, const int* nb, uint32_t flags,
                                          const double* xv, const double* kv, double hK,
                                          const double* __restrict__ x, const double* __restrict__ kappa,
-                                         double C_phi, double tau, const StageView<D>& st, double* y) {
+                                         double C_phi, double tau, double* y) {
     constexpr int NV = D + 1;
     double kbar = 0.0;
 #pragma unroll
@@ -267,88 +217,10 @@ __device__ __forceinline__ void emi_cell(const MeshDev& m, const CellGeom<D>& K,
         for (int b = 0; b < NV; ++b) s = fma(K.G[a][b], xv[b], s);
         y[a] = kbar * s;
     }
-    emi_facet<D, 0, MODE>(m, K, nb, flags, xv, kv, hK, x, kappa, C_phi, tau, st, y);
-    emi_facet<D, 1, MODE>(m, K, nb, flags, xv, kv, hK, x, kappa, C_phi, tau, st, y);
-    emi_facet<D, 2, MODE>(m, K, nb, flags, xv, kv, hK, x, kappa, C_phi, tau, st, y);
-    if (D == 3) emi_facet<D, (D == 3 ? 3 : 0), MODE>(m, K, nb, flags, xv, kv, hK, x, kappa, C_phi, tau, st, y);
-}
-
-#define EMI_BLOCK 384   // 6 wavefronts; = one 4x4x4-box Morton brick of a BoxMesh (6 tets per box)
-
-template <int D>
-__global__ __launch_bounds__(EMI_BLOCK) void k_emi_apply_staged(MeshDev m, const double* __restrict__ x,
-                                                         const double* __restrict__ kappa, double* __restrict__ y,
-                                                         double C_phi, double tau) {
-    constexpr int NV = D + 1;
-    __shared__ __attribute__((aligned(16))) double s_x[EMI_BLOCK * NV];
-    __shared__ __attribute__((aligned(16))) double s_k[EMI_BLOCK * NV];
-    __shared__ double s_h[EMI_BLOCK];
-    __shared__ double s_X[EMI_BLOCK * NV * D];
-    const int64_t c0 = xcd_block(blockIdx.x, gridDim.x) * EMI_BLOCK;
-    if (c0 >= m.nc_owned) return;
-    const int64_t c = c0 + threadIdx.x;
-    const bool valid = c < m.nc_owned;
-    int verts[NV], nb[NV];
-    uint32_t flags = 0;
-    double xv[NV], kv[NV], yv[NV], hK = 0.0, X[NV][D];
-    if (valid) {
-        load_cell_ints<D>(m.cells, c, verts);
-        load_cell_ints<D>(m.nbr, c, nb);
-        flags = m.fflag[c];
-        load_nodal<D>(x, c, xv);
-        load_nodal<D>(kappa, c, kv);
-        hK = m.h[c];
-#pragma unroll
-        for (int a = 0; a < NV; ++a) load_vertex<D>(m.coords, verts[a], X[a]);
-        const unsigned t = threadIdx.x;
-#pragma unroll
-        for (int a = 0; a < NV; ++a) {
-            s_x[t * NV + a] = xv[a];
-            s_k[t * NV + a] = kv[a];
-#pragma unroll
-            for (int q = 0; q < D; ++q) s_X[(t * NV + a) * D + q] = X[a][q];
-        }
-        s_h[t] = hK;
-    }
-    __syncthreads();
-    if (!valid) return;
-    StageView<D> st{TO_LDS(s_x), TO_LDS(s_k), TO_LDS(s_h), TO_LDS(s_X), c0, (unsigned)((m.nc_owned - c0 < EMI_BLOCK) ? (m.nc_owned - c0) : EMI_BLOCK), nullptr, nullptr};
-    CellGeom<D> K;
-    cell_geometry_from<D>(X, K);
-    emi_cell<D, 2>(m, K, nb, flags, xv, kv, hK, x, kappa, C_phi, tau, st, yv);
-    store_nodal<D>(y, c, yv);
-}
-
-// "geometry class" variant for (block-)structured meshes: cells whose own shape AND neighbour apex positions
-// coincide (up to 1e-9 of the cell size) share one precomputed 36-double record (Gram matrix, volume, per facet
-// L / sqrt(G_ii) / 2/(h+h')), read through L1 (a wavefront touches a handful of records).  No coordinate, cell
-// or apex gathers and no geometry flops remain: 118 B/cell of compulsory traffic.
-template <int D>
-__global__ __launch_bounds__(KNP_BLOCK) void k_emi_apply_cls(MeshDev m, const double* __restrict__ x,
-                                                             const double* __restrict__ kappa, double* __restrict__ y,
-                                                             double C_phi, double tau) {
-    constexpr int NV = D + 1;
-    const int64_t c = xcd_block(blockIdx.x, gridDim.x) * KNP_BLOCK + threadIdx.x;
-    if (c >= m.nc_owned) return;
-    int nb[NV];
-    load_cell_ints<D>(m.nbr, c, nb);
-    const uint32_t flags = m.fflag[c];
-    const double* rec = m.cls_table + (int64_t)m.cls[c] * KNP_CLS_STRIDE;
-    double xv[NV], kv[NV], yv[NV];
-    load_nodal<D>(x, c, xv);
-    load_nodal<D>(kappa, c, kv);
-    CellGeom<D> K;
-    K.vol = rec[0];
-    {
-        int q = 1;
-#pragma unroll
-        for (int a = 0; a < NV; ++a)
-#pragma unroll
-            for (int b = a; b < NV; ++b) { K.G[a][b] = rec[q]; K.G[b][a] = rec[q]; ++q; }
-    }
-    StageView<D> st{nullptr, nullptr, nullptr, nullptr, 0, 0u, rec, nullptr};
-    emi_cell<D, 3>(m, K, nb, flags, xv, kv, 0.0, x, kappa, C_phi, tau, st, yv);
-    store_nodal<D>(y, c, yv);
+    emi_facet<D, 0, MODE>(m, K, nb, flags, xv, kv, hK, x, kappa, C_phi, tau, y);
+    emi_facet<D, 1, MODE>(m, K, nb, flags, xv, kv, hK, x, kappa, C_phi, tau, y);
+    emi_facet<D, 2, MODE>(m, K, nb, flags, xv, kv, hK, x, kappa, C_phi, tau, y);
+    if (D == 3) emi_facet<D, (D == 3 ? 3 : 0), MODE>(m, K, nb, flags, xv, kv, hK, x, kappa, C_phi, tau, y);
 }
 
 // classed + LDS-staged: the class table and the workgroup's own x / kappa live in LDS, so in-block neighbours
@@ -363,10 +235,10 @@ __global__ __launch_bounds__(BLK) void k_emi_apply_cls_staged(MeshDev m, const d
     __shared__ __attribute__((aligned(16))) double s_x[BLK * NV];
     __shared__ __attribute__((aligned(16))) double s_k[BLK * NV];
     __shared__ __attribute__((aligned(16))) double s_tab[CLS_MAX_LDS * KNP_CLS_STRIDE];
-    const int64_t c0 = xcd_block(blockIdx.x, gridDim.x) * BLK;
-    if (c0 >= m.nc_owned) return;
+    const int64_t c0 = m.c_begin + xcd_block(blockIdx.x, gridDim.x) * BLK;
+    if (c0 >= m.c_end) return;
     const int64_t c = c0 + threadIdx.x;
-    const bool valid = c < m.nc_owned;
+    const bool valid = c < m.c_end;
     for (int i = threadIdx.x; i < m.ncls * KNP_CLS_STRIDE; i += BLK) s_tab[i] = m.cls_table[i];
     int nb[NV];
     uint32_t flags = 0;
@@ -395,7 +267,7 @@ __global__ __launch_bounds__(BLK) void k_emi_apply_cls_staged(MeshDev m, const d
             for (int b = a; b < NV; ++b) { K.G[a][b] = rec[q]; K.G[b][a] = rec[q]; ++q; }
     }
     StageView<D> st{TO_LDS(s_x), TO_LDS(s_k), nullptr, nullptr, c0,
-                    (unsigned)((m.nc_owned - c0 < BLK) ? (m.nc_owned - c0) : BLK), nullptr, rec};
+                    (unsigned)((m.c_end - c0 < BLK) ? (m.c_end - c0) : BLK), nullptr, rec};
     {
         double kbar = 0.0;
 #pragma unroll
@@ -417,13 +289,13 @@ __global__ __launch_bounds__(BLK) void k_emi_apply_cls_staged(MeshDev m, const d
 }
 
 // direct variant: every neighbour access is a global (L1/L2) gather
-template <int D, int WPE>
-__global__ __launch_bounds__(KNP_BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
+template <int D>
+__global__ __launch_bounds__(KNP_BLOCK) __attribute__((amdgpu_waves_per_eu(3, 3)))
 void k_emi_apply(MeshDev m, const double* __restrict__ x, const double* __restrict__ kappa, double* __restrict__ y,
                  double C_phi, double tau) {
     constexpr int NV = D + 1;
-    const int64_t c = xcd_block(blockIdx.x, gridDim.x) * KNP_BLOCK + threadIdx.x;
-    if (c >= m.nc_owned) return;
+    const int64_t c = m.c_begin + xcd_block(blockIdx.x, gridDim.x) * KNP_BLOCK + threadIdx.x;
+    if (c >= m.c_end) return;
     int verts[NV], nb[NV];
     load_cell_ints<D>(m.cells, c, verts);
     load_cell_ints<D>(m.nbr, c, nb);
@@ -434,7 +306,7 @@ void k_emi_apply(MeshDev m, const double* __restrict__ x, const double* __restri
     const double hK = m.h[c];
     CellGeom<D> K;
     load_cell_geometry<D>(m, verts, K);
-    emi_cell<D, 0>(m, K, nb, flags, xv, kv, hK, x, kappa, C_phi, tau, StageView<D>{nullptr, nullptr, nullptr, nullptr, 0, 0u, nullptr, nullptr}, yv);
+    emi_cell<D, 0>(m, K, nb, flags, xv, kv, hK, x, kappa, C_phi, tau, yv);
     store_nodal<D>(y, c, yv);
 }
 
@@ -481,7 +353,7 @@ __global__ __launch_bounds__(KNP_BLOCK) void k_emi_blockjacobi(MeshDev m, const 
         double e[NV], col[NV];
 #pragma unroll
         for (int a = 0; a < NV; ++a) e[a] = (a == b) ? 1.0 : 0.0;
-        emi_cell<D, 1>(m, K, nb, flags, e, kv, hK, nullptr, kappa, C_phi, tau, StageView<D>{nullptr, nullptr, nullptr, nullptr, 0, 0u, nullptr, nullptr}, col);
+        emi_cell<D, 1>(m, K, nb, flags, e, kv, hK, nullptr, kappa, C_phi, tau, col);
 #pragma unroll
         for (int a = 0; a < NV; ++a) A[a][b] = col[a];
     }
@@ -612,8 +484,8 @@ __global__ __launch_bounds__(KNP_BLOCK) void k_knp_apply(MeshDev m, const double
                                                          const double* __restrict__ Dall, double* __restrict__ yout,
                                                          KnpArgs ka) {
     constexpr int NV = D + 1;
-    const int64_t c = xcd_block(blockIdx.x, gridDim.x) * KNP_BLOCK + threadIdx.x;
-    if (c >= m.nc_owned) return;
+    const int64_t c = m.c_begin + xcd_block(blockIdx.x, gridDim.x) * KNP_BLOCK + threadIdx.x;
+    if (c >= m.c_end) return;
     int verts[NV], nb[NV];
     load_cell_ints<D>(m.cells, c, verts);
     load_cell_ints<D>(m.nbr, c, nb);
@@ -731,10 +603,10 @@ __global__ __launch_bounds__(BLK) void k_knp_apply_cls_staged(MeshDev m, const d
     __shared__ __attribute__((aligned(16))) double s_g[BLK * NV];
     __shared__ double s_D[NS * BLK];
     __shared__ __attribute__((aligned(16))) double s_tab[CLS_MAX_LDS * KNP_CLS_STRIDE];
-    const int64_t c0 = xcd_block(blockIdx.x, gridDim.x) * BLK;
-    if (c0 >= m.nc_owned) return;
+    const int64_t c0 = m.c_begin + xcd_block(blockIdx.x, gridDim.x) * BLK;
+    if (c0 >= m.c_end) return;
     const int64_t c = c0 + threadIdx.x;
-    const bool valid = c < m.nc_owned;
+    const bool valid = c < m.c_end;
     for (int i = threadIdx.x; i < m.ncls * KNP_CLS_STRIDE; i += BLK) s_tab[i] = m.cls_table[i];
     int nb[NV];
     uint32_t flags = 0;
@@ -770,7 +642,7 @@ __global__ __launch_bounds__(BLK) void k_knp_apply_cls_staged(MeshDev m, const d
             for (int b = a; b < NV; ++b) { K.G[a][b] = rec[q]; K.G[b][a] = rec[q]; ++q; }
     }
     KnpStage<D, NS, BLK> st{TO_LDS(s_x), TO_LDS(s_g), TO_LDS(s_D), rec, c0,
-                            (unsigned)((m.nc_owned - c0 < BLK) ? (m.nc_owned - c0) : BLK)};
+                            (unsigned)((m.c_end - c0 < BLK) ? (m.c_end - c0) : BLK)};
     // volume terms (same as knp_cell)
     const double mw = ka.inv_dt * K.vol / (double)((D + 1) * (D + 2));
 #pragma unroll
@@ -898,47 +770,15 @@ int launch_knp_apply(knp_ctx* c, const double* x, const double* gphi, double* y)
 
 static int emi_apply_impl(knp_ctx* c, const double* x, const double* kappa, double* y) {
     if (c->degree != 1) return p2_assembled() ? tab_apply(c, 0, x, y) : p2_emi_apply(c, x, kappa, y);
-    static const int variant = getenv("KNP_EMI_VARIANT") ? atoi(getenv("KNP_EMI_VARIANT")) : 1;
-    if (c->m.cls && c->m.dim == 3 && variant != 4) {
-        if (c->m.ncls <= CLS_MAX_LDS && variant != 5) {
-            if (variant == 6) {
-                const int64_t nblk = (((c->m.nc_owned + 383) / 384 + 7) / 8) * 8;
-                hipLaunchKernelGGL((k_emi_apply_cls_staged<3, 384>), dim3((unsigned)nblk), dim3(384), 0, c->stream, c->m, x, kappa, y,
-                                   c->p.C_phi, c->p.tau_emi);
-            } else if (variant == 7) {
-                const int64_t nblk = (((c->m.nc_owned + 511) / 512 + 7) / 8) * 8;
-                hipLaunchKernelGGL((k_emi_apply_cls_staged<3, 512>), dim3((unsigned)nblk), dim3(512), 0, c->stream, c->m, x, kappa, y,
-                                   c->p.C_phi, c->p.tau_emi);
-            } else if (variant == 8) {
-                const int64_t nblk = (((c->m.nc_owned + 127) / 128 + 7) / 8) * 8;
-                hipLaunchKernelGGL((k_emi_apply_cls_staged<3, 128>), dim3((unsigned)nblk), dim3(128), 0, c->stream, c->m, x, kappa, y,
-                                   c->p.C_phi, c->p.tau_emi);
-            } else {
-                hipLaunchKernelGGL((k_emi_apply_cls_staged<3, 256>), dim3((unsigned)grid8(c->m.nc_owned)), dim3(256), 0, c->stream,
-                                   c->m, x, kappa, y, c->p.C_phi, c->p.tau_emi);
-            }
-        } else {
-            const dim3 g((unsigned)grid8(c->m.nc_owned)), b(KNP_BLOCK);
-            hipLaunchKernelGGL(k_emi_apply_cls<3>, g, b, 0, c->stream, c->m, x, kappa, y, c->p.C_phi, c->p.tau_emi);
-        }
-    } else if (variant == 0) {
-        const int64_t nblk = (((c->m.nc_owned + EMI_BLOCK - 1) / EMI_BLOCK + 7) / 8) * 8;
-        const dim3 g((unsigned)nblk), b(EMI_BLOCK);
-        if (c->m.dim == 3)
-            hipLaunchKernelGGL(k_emi_apply_staged<3>, g, b, 0, c->stream, c->m, x, kappa, y, c->p.C_phi, c->p.tau_emi);
-        else
-            hipLaunchKernelGGL(k_emi_apply_staged<2>, g, b, 0, c->stream, c->m, x, kappa, y, c->p.C_phi, c->p.tau_emi);
-    } else {
-        const dim3 g((unsigned)grid8(c->m.nc_owned)), b(KNP_BLOCK);
-        if (c->m.dim == 2)
-            hipLaunchKernelGGL((k_emi_apply<2, 4>), g, b, 0, c->stream, c->m, x, kappa, y, c->p.C_phi, c->p.tau_emi);
-        else if (variant == 2)
-            hipLaunchKernelGGL((k_emi_apply<3, 4>), g, b, 0, c->stream, c->m, x, kappa, y, c->p.C_phi, c->p.tau_emi);
-        else if (variant == 3)
-            hipLaunchKernelGGL((k_emi_apply<3, 2>), g, b, 0, c->stream, c->m, x, kappa, y, c->p.C_phi, c->p.tau_emi);
-        else
-            hipLaunchKernelGGL((k_emi_apply<3, 3>), g, b, 0, c->stream, c->m, x, kappa, y, c->p.C_phi, c->p.tau_emi);
-    }
+    const int64_t n = c->m.c_end - c->m.c_begin;
+    if (n <= 0) return 0;
+    const dim3 g((unsigned)grid8(n)), b(KNP_BLOCK);
+    if (c->m.cls && c->m.dim == 3 && c->m.ncls <= CLS_MAX_LDS)
+        hipLaunchKernelGGL((k_emi_apply_cls_staged<3, 256>), g, b, 0, c->stream, c->m, x, kappa, y, c->p.C_phi, c->p.tau_emi);
+    else if (c->m.dim == 3)
+        hipLaunchKernelGGL(k_emi_apply<3>, g, b, 0, c->stream, c->m, x, kappa, y, c->p.C_phi, c->p.tau_emi);
+    else
+        hipLaunchKernelGGL(k_emi_apply<2>, g, b, 0, c->stream, c->m, x, kappa, y, c->p.C_phi, c->p.tau_emi);
     HIPCHK(c, hipGetLastError());
     return 0;
 }
@@ -954,10 +794,11 @@ static KnpArgs make_knp_args(knp_ctx* c) {
 }
 
 template <int D> static int knp_apply_dispatch(knp_ctx* c, const double* x, const double* gphi, double* y) {
-    const dim3 g((unsigned)grid8(c->m.nc_owned)), b(KNP_BLOCK);
+    const int64_t n = c->m.c_end - c->m.c_begin;
+    if (n <= 0) return 0;
+    const dim3 g((unsigned)grid8(n)), b(KNP_BLOCK);
     const KnpArgs ka = make_knp_args(c);
-    static const int variant = getenv("KNP_KNP_VARIANT") ? atoi(getenv("KNP_KNP_VARIANT")) : 0;
-    if (D == 3 && c->m.cls && c->m.ncls <= CLS_MAX_LDS && variant == 0 && c->p.n_sys <= 3) {
+    if (D == 3 && c->m.cls && c->m.ncls <= CLS_MAX_LDS && c->p.n_sys <= 3) {
         switch (c->p.n_sys) {
             case 1: hipLaunchKernelGGL((k_knp_apply_cls_staged<3, 1, 256>), g, b, 0, c->stream, c->m, x, gphi, c->D, y, ka); break;
             case 2: hipLaunchKernelGGL((k_knp_apply_cls_staged<3, 2, 256>), g, b, 0, c->stream, c->m, x, gphi, c->D, y, ka); break;

@@ -374,10 +374,10 @@ __global__ __launch_bounds__(BLK) void k_emi_apply_p2(MeshDev m, const double* _
     __shared__ __attribute__((aligned(16))) double s_x[BLK * ND];
     __shared__ __attribute__((aligned(16))) double s_k[BLK * ND];
     __shared__ __attribute__((aligned(16))) double s_tab[CLS ? CLS_MAX_P2 * KNP_CLS_STRIDE : 2];
-    const int64_t c0 = xcd_block(blockIdx.x, gridDim.x) * BLK;
-    if (c0 >= m.nc_owned) return;
+    const int64_t c0 = m.c_begin + xcd_block(blockIdx.x, gridDim.x) * BLK;
+    if (c0 >= m.c_end) return;
     const int64_t c = c0 + threadIdx.x;
-    const bool valid = c < m.nc_owned;
+    const bool valid = c < m.c_end;
     if (CLS)
         for (int i = threadIdx.x; i < m.ncls * KNP_CLS_STRIDE; i += BLK) s_tab[i] = m.cls_table[i];
     int nb[NV];
@@ -399,7 +399,7 @@ __global__ __launch_bounds__(BLK) void k_emi_apply_p2(MeshDev m, const double* _
     const lds_double* rec = TO_LDS(s_tab) + cls * KNP_CLS_STRIDE;
     CellGeom<D> K;
     cell_geometry_p2<D, CLS>(m, c, rec, K);
-    StageP2<D> st{TO_LDS(s_x), TO_LDS(s_k), c0, (unsigned)((m.nc_owned - c0 < BLK) ? (m.nc_owned - c0) : BLK)};
+    StageP2<D> st{TO_LDS(s_x), TO_LDS(s_k), c0, (unsigned)((m.c_end - c0 < BLK) ? (m.c_end - c0) : BLK)};
     emi_cell_p2<D, CLS, 0>(m, K, rec, c, nb, flags, xv, kv, x, kappa, st, C_phi, tau, yv);
     store_cellvec<ND>(y, c, yv);
 }
@@ -576,13 +576,13 @@ __global__ __launch_bounds__(BLK) void k_knp_apply_p2(MeshDev m, const double* _
     __shared__ __attribute__((aligned(16))) double s_x[BLK * ND];
     __shared__ __attribute__((aligned(16))) double s_p[BLK * ND];
     __shared__ __attribute__((aligned(16))) double s_tab[CLS ? CLS_MAX_P2 * KNP_CLS_STRIDE : 2];
-    const int64_t c0 = xcd_block(blockIdx.x, gridDim.x) * BLK;
-    if (c0 >= m.nc_owned) return;
+    const int64_t c0 = m.c_begin + xcd_block(blockIdx.x, gridDim.x) * BLK;
+    if (c0 >= m.c_end) return;
     const int sp = blockIdx.y;
     const double* x = x_all + (int64_t)sp * m.nc * ND;
     const double* Dspec = Dall + (int64_t)sp * m.nc;
     const int64_t c = c0 + threadIdx.x;
-    const bool valid = c < m.nc_owned;
+    const bool valid = c < m.c_end;
     if (CLS)
         for (int i = threadIdx.x; i < m.ncls * KNP_CLS_STRIDE; i += BLK) s_tab[i] = m.cls_table[i];
     int nb[NV];
@@ -605,7 +605,7 @@ __global__ __launch_bounds__(BLK) void k_knp_apply_p2(MeshDev m, const double* _
     const lds_double* rec = TO_LDS(s_tab) + cls * KNP_CLS_STRIDE;
     CellGeom<D> K;
     cell_geometry_p2<D, CLS>(m, c, rec, K);
-    StageP2<D> st{TO_LDS(s_x), TO_LDS(s_p), c0, (unsigned)((m.nc_owned - c0 < BLK) ? (m.nc_owned - c0) : BLK)};
+    StageP2<D> st{TO_LDS(s_x), TO_LDS(s_p), c0, (unsigned)((m.c_end - c0 < BLK) ? (m.c_end - c0) : BLK)};
     knp_cell_p2<D, CLS, 0>(m, K, rec, c, nb, flags, xv, pv, Dc, ka.z[sp] * ka.psi, ka.inv_dt, x, phi, Dspec, st, ka.tau, yv);
     store_cellvec<ND>(y_all + (int64_t)sp * m.nc * ND, c, yv);
 }
@@ -699,7 +699,8 @@ static KnpP2Args knp_p2_args(knp_ctx* c) {
 
 int p2_emi_apply(knp_ctx* c, const double* x, const double* kappa, double* y) {
     const bool cls = c->m.cls && c->m.dim == 3 && c->m.ncls <= CLS_MAX_P2;
-    const dim3 g(grid8_for(c->m.nc_owned, P2_BLK)), b(P2_BLK);
+    if (c->m.c_end <= c->m.c_begin) return 0;
+    const dim3 g(grid8_for(c->m.c_end - c->m.c_begin, P2_BLK)), b(P2_BLK);
     if (c->m.dim == 3) {
         if (cls) hipLaunchKernelGGL((k_emi_apply_p2<3, P2_BLK, true>), g, b, 0, c->stream, c->m, x, kappa, y, c->p.C_phi, c->p.tau_emi);
         else hipLaunchKernelGGL((k_emi_apply_p2<3, P2_BLK, false>), g, b, 0, c->stream, c->m, x, kappa, y, c->p.C_phi, c->p.tau_emi);
@@ -712,7 +713,8 @@ int p2_emi_apply(knp_ctx* c, const double* x, const double* kappa, double* y) {
 
 int p2_knp_apply(knp_ctx* c, const double* x, const double* phi, double* y) {
     const bool cls = c->m.cls && c->m.dim == 3 && c->m.ncls <= CLS_MAX_P2;
-    const dim3 g(grid8_for(c->m.nc_owned, P2_BLK), (unsigned)c->p.n_sys), b(P2_BLK);
+    if (c->m.c_end <= c->m.c_begin) return 0;
+    const dim3 g(grid8_for(c->m.c_end - c->m.c_begin, P2_BLK), (unsigned)c->p.n_sys), b(P2_BLK);
     const KnpP2Args ka = knp_p2_args(c);
     if (c->m.dim == 3) {
         if (cls) hipLaunchKernelGGL((k_knp_apply_p2<3, P2_BLK, true>), g, b, 0, c->stream, c->m, x, phi, (const double*)c->D, y, ka);

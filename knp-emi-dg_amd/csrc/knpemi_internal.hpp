@@ -28,6 +28,8 @@ enum : uint32_t { FK_SIPG = 0u, FK_MEMBRANE = 1u, FK_EXTERIOR = 2u, FK_INACTIVE 
 struct MeshDev {
     int dim = 0;
     int64_t nv = 0, nc = 0, nc_owned = 0, nf = 0, nmf = 0;
+    int64_t c_begin = 0, c_end = 0;   // cell range of the operator-apply launches: [0, nc_owned), or the interior / boundary part of it
+    int64_t n_interior = 0;           // owned cells [0, n_interior) have no ghost neighbour (device order: interior first)
     double* coords = nullptr;      // [nv][4] in 3D (padded), [nv][2] in 2D
     int32_t* cells = nullptr;      // [nc][dim+1]
     double* h = nullptr;           // [nc] cell diameters (UFL CellDiameter: longest edge)
@@ -101,7 +103,10 @@ struct knp_ctx {
     std::vector<hipEvent_t> aux_events;
     hipEvent_t fork_event = nullptr;
     // distributed
-    void* comm = nullptr;          // ncclComm_t
+    void* comm = nullptr;          // ncclComm_t: reductions + serial halo exchanges, on the context's stream
+    void* comm_halo = nullptr;     // ncclComm_t of the overlapped halo exchanges, on halo_stream
+    hipStream_t halo_stream = nullptr;
+    hipEvent_t halo_ready = nullptr, halo_done = nullptr;
     int rank = 0, nranks = 1;
     bool dist = false;             // communicator active: halo exchanges + all-reduced reductions
     std::vector<int> halo_peer;
@@ -159,6 +164,9 @@ int p2_knp_apply(knp_ctx* c, const double* x, const double* phi, double* y);
 int p2_block_inverse(knp_ctx* c, int which, const double* coef, bjreal* binv);
 
 int halo_exchange(knp_ctx* c, double* v, int nfields);
+// y = A x on the owned cells with the halo exchange of x folded in (which: 0 = EMI, 1 = KNP): without a communicator a plain
+// launch; with one, interior cells are computed while the exchange is in flight on the halo stream / communicator (comm.hip)
+int dist_apply(knp_ctx* c, int which, double* x, const double* coef, double* y);
 
 int64_t grid_for(int64_t n);
 int launch_nernst_only(knp_ctx* c, const double* cc, const double* celim, double* E);

@@ -576,8 +576,7 @@ static inline int next_chunk(int it, int maxit, int check_every, int predicted) 
 template <int NV, bool EMI>
 static int bj_cheb2(knp_ctx* c, const VecDims& d, const KrylovVecs& kv, const double* r, double* y, bool use_status = true) {
     int rc;
-    if (c->dist && (rc = halo_exchange(c, y, d.nsys))) return rc;
-    if ((rc = EMI ? launch_emi_apply(c, y, kv.coef, kv.tmp) : launch_knp_apply(c, y, kv.coef, kv.tmp))) return rc;
+    if ((rc = dist_apply(c, EMI ? 0 : 1, y, kv.coef, kv.tmp))) return rc;
     static const double lmin_frac = getenv("KNP_BJ_LMIN") ? atof(getenv("KNP_BJ_LMIN")) : 0.05;   // measured best over 30 steps at r=2 (0.03..0.06)
     const double lmax = kv.bj_lmax, lmin = lmin_frac * lmax;
     const double theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin), sigma = theta / delta, rho0 = 1.0 / sigma;
@@ -605,8 +604,7 @@ static int bj_lambda_max_impl(knp_ctx* c, KrylovVecs& kv, int iters, double* out
     if ((rc = max_abs_diff(c, kv.v, kv.z, ns, &nv))) return rc;
     if (!(nv > 0.0)) { *out = 0.0; return 0; }
     for (int it = 0; it < iters; ++it) {
-        if (c->dist && (rc = halo_exchange(c, kv.v, ns))) return rc;
-        if ((rc = EMI ? launch_emi_apply(c, kv.v, kv.coef, kv.w) : launch_knp_apply(c, kv.v, kv.coef, kv.w))) return rc;
+        if ((rc = dist_apply(c, EMI ? 0 : 1, kv.v, kv.coef, kv.w))) return rc;
         for (int s = 0; s < ns; ++s)
             hipLaunchKernelGGL(k_bj_apply<NV>, dim3(g.x), b, 0, c->stream, d, kv.binv + (int64_t)s * c->m.nc * NV * NV,
                                (const double*)(kv.w + (int64_t)s * stride), kv.y + (int64_t)s * stride);
@@ -637,8 +635,7 @@ static int pcg_impl(knp_ctx* c, KrylovVecs& kv, double rtol, double atol, int ma
     VecDims d{c->m.nc_owned, c->m.nc, 1};
     const dim3 g((unsigned)grid_for(c->m.nc_owned)), b(KNP_BLOCK);
     int rc;
-    if (c->dist && (rc = halo_exchange(c, kv.x, 1))) return rc;
-    if ((rc = launch_emi_apply(c, kv.x, kv.coef, kv.w))) return rc;
+    if ((rc = dist_apply(c, 0, kv.x, kv.coef, kv.w))) return rc;
     AmgHierarchy* H = (c->amg.size() && c->amg[0].ready) ? &c->amg[0] : nullptr;
     hipLaunchKernelGGL(k_cg_init<NV>, g, b, 0, c->stream, d, kv.b, kv.w, kv.binv, kv.r, kv.z, kv.p, c->partial);
     if (H) {
@@ -664,8 +661,7 @@ static int pcg_impl(knp_ctx* c, KrylovVecs& kv, double rtol, double atol, int ma
     while (!hs[0] && it < maxit) {
         const int chunk = next_chunk(it, maxit, check_every, c->last_it_emi);
         for (int k = 0; k < chunk; ++k) {
-            if (c->dist && (rc = halo_exchange(c, kv.p, 1))) return rc;
-            if ((rc = launch_emi_apply(c, kv.p, kv.coef, kv.w))) return rc;
+            if ((rc = dist_apply(c, 0, kv.p, kv.coef, kv.w))) return rc;
             hipLaunchKernelGGL(k_dot2<NV>, dim3(g.x, 1), b, 0, c->stream, d, kv.p, kv.w, (const double*)nullptr,
                                (const double*)nullptr, c->partial, c->status);
             if ((rc = finalize(c, OP_CG_ALPHA, 1, 1, rtol, atol, 0))) return rc;
@@ -784,8 +780,7 @@ static int bicgstab_impl(knp_ctx* c, KrylovVecs& kv, double rtol, double atol, i
     VecDims d{c->m.nc_owned, c->m.nc, ns};
     const dim3 g((unsigned)grid_for(c->m.nc_owned), (unsigned)ns), b(KNP_BLOCK);
     int rc;
-    if (c->dist && (rc = halo_exchange(c, kv.x, ns))) return rc;
-    if ((rc = launch_knp_apply(c, kv.x, kv.coef, kv.w))) return rc;
+    if ((rc = dist_apply(c, 1, kv.x, kv.coef, kv.w))) return rc;
     hipLaunchKernelGGL(k_bi_init<NV>, g, b, 0, c->stream, d, kv.b, kv.w, kv.r, kv.rhat, kv.p, kv.v, c->partial);
     if ((rc = finalize(c, OP_BI_INIT, ns, 2, rtol, atol, min_it))) return rc;
     int hs[2 * KNP_MAX_SYS];
@@ -798,16 +793,14 @@ static int bicgstab_impl(knp_ctx* c, KrylovVecs& kv, double rtol, double atol, i
             hipLaunchKernelGGL(k_bi_p<NV>, g, b, 0, c->stream, d, c->scal, c->status, kv.r, kv.v, kv.binv, kv.p, kv.y);
             if (kv.bj_lmax > 0.0 && (rc = bj_cheb2<NV, false>(c, d, kv, kv.p, kv.y))) return rc;
             if ((rc = knp_coarse_correction<NV>(c, d, kv.p, kv.y))) return rc;
-            if (c->dist && (rc = halo_exchange(c, kv.y, ns))) return rc;
-            if ((rc = launch_knp_apply(c, kv.y, kv.coef, kv.v))) return rc;
+            if ((rc = dist_apply(c, 1, kv.y, kv.coef, kv.v))) return rc;
             hipLaunchKernelGGL(k_dot2<NV>, g, b, 0, c->stream, d, kv.rhat, kv.v, (const double*)nullptr, (const double*)nullptr,
                                c->partial, c->status);
             if ((rc = finalize(c, OP_BI_ALPHA, ns, 1, rtol, atol, min_it))) return rc;
             hipLaunchKernelGGL(k_bi_s<NV>, g, b, 0, c->stream, d, c->scal, c->status, kv.v, kv.binv, kv.r, kv.z);
             if (kv.bj_lmax > 0.0 && (rc = bj_cheb2<NV, false>(c, d, kv, kv.r, kv.z))) return rc;
             if ((rc = knp_coarse_correction<NV>(c, d, kv.r, kv.z))) return rc;
-            if (c->dist && (rc = halo_exchange(c, kv.z, ns))) return rc;
-            if ((rc = launch_knp_apply(c, kv.z, kv.coef, kv.w))) return rc;
+            if ((rc = dist_apply(c, 1, kv.z, kv.coef, kv.w))) return rc;
             hipLaunchKernelGGL(k_dot2<NV>, g, b, 0, c->stream, d, kv.w, kv.r, kv.w, kv.w, c->partial, c->status);
             if ((rc = finalize(c, OP_BI_OMEGA, ns, 2, rtol, atol, min_it))) return rc;
             hipLaunchKernelGGL(k_bi_x<NV>, g, b, 0, c->stream, d, c->scal, c->status, kv.y, kv.z, kv.w, kv.rhat, kv.x, kv.r,

@@ -64,6 +64,8 @@ SIGNATURES = {
     "knp_host_free": (None, [C.c_void_p]),
     "knp_comm_unique_id": (C.c_int, [C.c_char_p]),
     "knp_comm_init": (C.c_int, [_ctxp, C.c_int, C.c_int, C.c_char_p]),
+    "knp_comm_init_halo": (C.c_int, [_ctxp, C.c_char_p]),
+    "knp_set_interior": (C.c_int, [_ctxp, C.c_int64]),
     "knp_halo_tables": (C.c_int, [_ctxp, C.c_int, _i32p, _i64p, _i32p, _i64p, _i64p]),
     "knp_halo_exchange": (C.c_int, [_ctxp, C.c_int]),
     "knp_ode_create": (C.c_int, [_ctxp, C.c_int, C.c_int64, _i32p, C.c_int, C.c_int, _f64p, _f64p]),
@@ -232,10 +234,21 @@ class Device:
         # device cell numbering: owned cells along a Morton curve, ghosts keep their (peer-grouped) places
         order = np.arange(nc, dtype=np.int64)
         scale = None
+        self.n_interior = n_own
         if reorder and nc:
             xc = mesh.coords[mesh.cells]
             scale = np.maximum(np.median(xc.max(axis=1) - xc.min(axis=1), axis=0), 1e-300)
             order[:n_own] = morton_order(mesh.cell_midpoints()[:n_own], scale)
+            if n_own < nc:
+                # a partition: owned cells without a ghost neighbour first (their part of an apply runs while the halo
+                # exchange is in flight), the cells on the cut after them; both groups along the Morton curve
+                fcs = np.asarray(mesh.facet_cells)
+                cut = fcs[(fcs[:, 1] >= 0) & ((fcs[:, 0] >= n_own) != (fcs[:, 1] >= n_own))]
+                on_cut = np.zeros(nc, dtype=bool)
+                on_cut[cut.ravel()] = True
+                o = order[:n_own]
+                order[:n_own] = np.concatenate([o[~on_cut[o]], o[on_cut[o]]])
+                self.n_interior = int((~on_cut[:n_own]).sum())
         rank = np.empty(nc, dtype=np.int64)
         rank[order] = np.arange(nc)
         self.cell_order, self.cell_rank = order, rank            # device -> caller, caller -> device
@@ -269,6 +282,8 @@ class Device:
             msg = self.lib.knp_last_error(None)
             self.ctx = None
             raise KnpError("knp_ctx_create failed (%d): %s" % (rc, msg.decode() if msg else "?"))
+        if self.n_interior != n_own:
+            self._chk(self.lib.knp_set_interior(self.ctx, self.n_interior), "knp_set_interior")
         self.n_geometry_classes = 0
         self.nranks = 1
         self.degree = int(degree)
@@ -457,9 +472,14 @@ class Device:
         return out, ms.value
 
     # -- multi-GPU ---------------------------------------------------------------------
-    def comm_init(self, rank, nranks, uid):
+    def comm_init(self, rank, nranks, uid, uid_halo=None):
         self._chk(self.lib.knp_comm_init(self.ctx, rank, nranks, uid), "knp_comm_init")
         self.nranks = int(nranks)
+        if uid_halo is not None:
+            self._chk(self.lib.knp_comm_init_halo(self.ctx, uid_halo), "knp_comm_init_halo")
+
+    def set_interior(self, n_interior):
+        self._chk(self.lib.knp_set_interior(self.ctx, int(n_interior)), "knp_set_interior")
 
     def halo_tables(self, peers, send_lists, recv_offsets, recv_counts):
         peers = np.ascontiguousarray(peers, dtype=np.int32)
@@ -578,7 +598,7 @@ def _flushing(fn):
 for _name in ("close", "set_params", "set_mms", "upload", "download", "copy_field", "update_kappa", "update_dnphi", "emi_apply",
               "knp_apply", "emi_rhs", "knp_rhs", "emi_solve", "knp_solve", "step_updates", "picard_updates", "max_abs_diff",
               "nernst", "sync", "timer_begin", "timer_end", "bench_apply", "ode_table", "ode_step", "ode_set_stimulus",
-              "amg_upload", "halo_exchange", "apply_timing_read"):
+              "amg_upload", "halo_exchange", "apply_timing_read", "comm_init", "set_interior"):
     setattr(Device, _name, _flushing(getattr(Device, _name)))
 
 

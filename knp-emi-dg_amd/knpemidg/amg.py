@@ -24,6 +24,23 @@ import scipy.sparse as sp
 import scipy.sparse.csgraph as csg
 
 
+def _cell_gram(space):
+    """(vol [nc], G [nc, nv, nv] = grad lambda_a . grad lambda_b) of every cell, computed once per space."""
+    geo = getattr(space, "_gram", None)
+    if geo is None:
+        mesh = space.mesh
+        d = mesh.gdim
+        x = mesh.coords[mesh.cells]
+        J = (x[:, 1:, :] - x[:, :1, :]).transpose(0, 2, 1)
+        vol = np.abs(np.linalg.det(J)) / {2: 2.0, 3: 6.0}[d]
+        Jinv = np.linalg.inv(J)
+        g = np.empty((x.shape[0], d + 1, d))
+        g[:, 1:, :] = Jinv
+        g[:, 0, :] = -Jinv.sum(axis=1)
+        geo = space._gram = (vol, np.einsum("cad,cbd->cab", g, g))
+    return geo
+
+
 def _assemble_cached(space, blk, nd):
     """CSR matrix from per-cell dense blocks blk[c, a, b] scattered through space.dof.  The sparsity pattern (sort order of
     the (row, col) keys and the segment starts) depends only on the dof map: computed on the first call and reused by every
@@ -73,15 +90,7 @@ class ConformingSpace:
         coef_nodal [nc, nd] (kappa) or [nc] (D); membrane = (facet ids, cell_e, cell_i, C)."""
         mesh = self.mesh
         d = mesh.gdim
-        x = mesh.coords[mesh.cells]
-        J = (x[:, 1:, :] - x[:, :1, :]).transpose(0, 2, 1)
-        det = np.linalg.det(J)
-        vol = np.abs(det) / {2: 2.0, 3: 6.0}[d]
-        Jinv = np.linalg.inv(J)
-        g = np.empty((x.shape[0], d + 1, d))
-        g[:, 1:, :] = Jinv
-        g[:, 0, :] = -Jinv.sum(axis=1)
-        G = np.einsum("cad,cbd->cab", g, g)
+        vol, G = _cell_gram(self)
         cbar = coef_nodal.mean(axis=1) if np.ndim(coef_nodal) == 2 else np.asarray(coef_nodal)
         blk = (vol * cbar)[:, None, None] * G
         nv = d + 1
@@ -149,22 +158,17 @@ class ConformingSpaceP2:
         from knpemidg.quadrature import simplex_rule
         mesh = self.cs.mesh
         d = mesh.gdim
-        x = mesh.coords[mesh.cells]
-        J = (x[:, 1:, :] - x[:, :1, :]).transpose(0, 2, 1)
-        vol = np.abs(np.linalg.det(J)) / {2: 2.0, 3: 6.0}[d]
-        Jinv = np.linalg.inv(J)
-        g = np.empty((x.shape[0], d + 1, d))
-        g[:, 1:, :] = Jinv
-        g[:, 0, :] = -Jinv.sum(axis=1)
-        Gl = np.einsum("cld,cmd->clm", g, g)                                  # grad lambda_l . grad lambda_m
+        vol, Gl = _cell_gram(self.cs)                                         # grad lambda_l . grad lambda_m
         nd = self.dof.shape[1]
         bary, w = simplex_rule(d, 4)
         B, dB = dgtab.tabulate(2, bary)
         coef = np.asarray(coef, dtype=np.float64)
         kq = coef @ B.T if coef.ndim == 2 else np.repeat(coef[:, None], len(w), axis=1)      # [nc, q]
-        # blk[c, a, b] = vol sum_q w kq dB[q,a,l] dB[q,b,m] Gl[c,l,m]
-        T = np.einsum("q,qal,qbm->qablm", w, dB, dB)
-        blk = np.einsum("cq,qablm,clm->cab", kq, T, Gl) * vol[:, None, None]
+        # blk[c, a, b] = vol sum_q w kq dB[q,a,l] Gl[c,l,m] dB[q,b,m]: per point two batched small products
+        blk = np.zeros((Gl.shape[0], nd, nd))
+        for q in range(len(w)):
+            Y = Gl @ dB[q].T                                                  # [nc, nv, nd]
+            blk += (w[q] * kq[:, q] * vol)[:, None, None] * (dB[q][None] @ Y)
         if mass_coef is not None:
             Mref = np.einsum("q,qa,qb->ab", w, B, B)
             blk = blk + (np.asarray(mass_coef) * vol)[:, None, None] * Mref[None]

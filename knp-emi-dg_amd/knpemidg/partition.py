@@ -20,17 +20,47 @@ import numpy as np
 from knpemidg.mesh import Mesh, MeshFunction
 
 
+def rcb_owner(points, world):
+    """Recursive coordinate bisection of `points` [n, d] into `world` parts of (almost) equal size: split the longest axis of
+    the current box at the position that divides the cells in proportion to the ranks on either side.  Deterministic, so
+    every rank computes the same partition without communication (no METIS in this environment)."""
+    pts = np.asarray(points, dtype=np.float64)
+    owner = np.empty(len(pts), dtype=np.int32)
+
+    def split(idx, r0, nr):
+        if nr == 1:
+            owner[idx] = r0
+            return
+        p = pts[idx]
+        axis = int(np.argmax(p.max(axis=0) - p.min(axis=0)))
+        nl = nr // 2
+        k = (len(idx) * nl) // nr
+        order = idx[np.argsort(p[:, axis], kind="stable")]
+        split(order[:k], r0, nl)
+        split(order[k:], r0 + nl, nr - nl)
+    split(np.arange(len(pts)), 0, int(world))
+    return owner
+
+
 class Partition:
-    def __init__(self, mesh, world, axis=0):
+    """method "slab": contiguous chunks of the cells sorted by centroid coordinate `axis` (idealized BoxMesh geometries: <= 2
+    peers per rank); "rcb": recursive coordinate bisection (unstructured meshes, e.g. the EMIx reconstruction)."""
+
+    def __init__(self, mesh, world, axis=0, method="slab"):
         self.mesh = mesh
         self.world = int(world)
         nc = mesh.num_cells()
-        cm = mesh.cell_midpoints()[:, axis]
-        order = np.argsort(cm, kind="stable")
-        owner = np.empty(nc, dtype=np.int32)
-        bounds = [(nc * r) // self.world for r in range(self.world + 1)]
-        for r in range(self.world):
-            owner[order[bounds[r]:bounds[r + 1]]] = r
+        if method == "rcb":
+            owner = rcb_owner(mesh.cell_midpoints(), self.world)
+        elif method == "slab":
+            cm = mesh.cell_midpoints()[:, axis]
+            order = np.argsort(cm, kind="stable")
+            owner = np.empty(nc, dtype=np.int32)
+            bounds = [(nc * r) // self.world for r in range(self.world + 1)]
+            for r in range(self.world):
+                owner[order[bounds[r]:bounds[r + 1]]] = r
+        else:
+            raise ValueError("partition method must be 'slab' or 'rcb'")
         self.owner = owner
         fc = mesh.facet_cells
         it = fc[:, 1] >= 0
@@ -119,34 +149,17 @@ class LocalMesh:
         return arr
 
 
-def make_distributed_solver(dim, resolution, rank, world, local_rank, dist, n_axons=4, degree=1, dt=1.0e-4,
-                            solver_cls=None, mesh_tuple=None):
-    """The idealized-geometry solver on `world` GPUs: every rank builds the global mesh (cheap: numpy),
-    keeps its slab + ghosts, creates its device context and joins the RCCL communicator."""
-    import os
-    import sys
-    ex = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "examples",
-                      "idealized_geometries")
-    if ex not in sys.path:
-        sys.path.insert(0, ex)
-    from idealized_common import SolverIdealized, physical_setup
-    from knpemidg.mesh import make_mesh_2D, make_mesh_3D
-    from knpemidg.models import mm_hh, mm_hh_no_stim
+def distribute_solver(solver_factory, mesh_tuple, ode_models, stim_params, rank, world, local_rank, dist, method="rcb"):
+    """Any `Solver` subclass on `world` GPUs of one node.  `solver_factory()` returns a fresh, un-set-up solver (its params and
+    ion list inside); `mesh_tuple` = (mesh, subdomains, surfaces) of the GLOBAL mesh, which every rank holds (host memory only);
+    `ode_models` = {membrane facet tag: ODE module}.  Every rank keeps its part + one ghost layer, creates its device context,
+    joins the two RCCL communicators (reductions / halo exchanges) and receives its halo tables."""
     from knpemidg import _abi
-
-    if mesh_tuple is None:
-        mesh_tuple = make_mesh_3D(resolution, n_axons=n_axons) if dim == 3 else make_mesh_2D(resolution)
     mesh, subdomains, surfaces = mesh_tuple
-    if dim == 3:
-        ode_models = {1: mm_hh, 2: mm_hh_no_stim} if n_axons > 1 else {1: mm_hh}
-    else:
-        ode_models = {1: mm_hh}
-    part = Partition(mesh, world)
+    part = Partition(mesh, world, method=method)
     loc = part.local(rank)
     sub_l, surf_l = loc.localize(subdomains, surfaces, ode_models.keys())
-    params, ion_list, stim_params = physical_setup(dt)
-    cls = solver_cls or SolverIdealized
-    S = cls(params, ion_list, degree_emi=degree, degree_knp=degree)
+    S = solver_factory()
     S.verbose = False
     S.device_index = local_rank
     S.nc_owned = loc.nc_owned
@@ -157,9 +170,34 @@ def make_distributed_solver(dim, resolution, rank, world, local_rank, dist, n_ax
     S.setup_parameters()
     S.setup_FEM_spaces()
     S.setup_membrane_model(stim_params, ode_models)
-    # RCCL communicator: rank 0 creates the id, torch.distributed carries it to the others
-    uid = [_abi.comm_unique_id() if rank == 0 else None]
+    # RCCL communicators: rank 0 creates the ids, torch.distributed carries them to the others
+    uid = [(_abi.comm_unique_id(), _abi.comm_unique_id()) if rank == 0 else None]
     dist.broadcast_object_list(uid, src=0)
-    S.dev.comm_init(rank, world, uid[0])
+    S.dev.comm_init(rank, world, uid[0][0], uid_halo=uid[0][1])
     S.dev.halo_tables(loc.peers, loc.send_lists, loc.recv_offsets, loc.recv_counts)
     return S
+
+
+def make_distributed_solver(dim, resolution, rank, world, local_rank, dist, n_axons=4, degree=1, dt=1.0e-4,
+                            solver_cls=None, mesh_tuple=None):
+    """The idealized-geometry solver on `world` GPUs (x-slab partition of the BoxMesh: 2 peers per rank, each one xGMI hop)."""
+    import os
+    import sys
+    ex = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "examples",
+                      "idealized_geometries")
+    if ex not in sys.path:
+        sys.path.insert(0, ex)
+    from idealized_common import SolverIdealized, physical_setup
+    from knpemidg.mesh import make_mesh_2D, make_mesh_3D
+    from knpemidg.models import mm_hh, mm_hh_no_stim
+
+    if mesh_tuple is None:
+        mesh_tuple = make_mesh_3D(resolution, n_axons=n_axons) if dim == 3 else make_mesh_2D(resolution)
+    if dim == 3:
+        ode_models = {1: mm_hh, 2: mm_hh_no_stim} if n_axons > 1 else {1: mm_hh}
+    else:
+        ode_models = {1: mm_hh}
+    params, ion_list, stim_params = physical_setup(dt)
+    cls = solver_cls or SolverIdealized
+    return distribute_solver(lambda: cls(params, ion_list, degree_emi=degree, degree_knp=degree), mesh_tuple, ode_models,
+                             stim_params, rank, world, local_rank, dist, method="slab")

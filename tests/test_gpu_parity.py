@@ -180,7 +180,7 @@ def test_gpu_matches_golden(hip_lib, name):
 
 
 @pytest.mark.parametrize("world,p", [(2, 1), (3, 1), (2, 2)])
-def test_partitioned_kernels_on_one_gpu(hip_lib, world, p):
+def test_partitioned_kernels_on_one_gpu(hip_lib, monkeypatch, world, p):
     """Owned+ghost sub-meshes on the device: every rank's context (all living on this one GPU, ghosts filled
     from the global arrays = what the RCCL halo exchange delivers) must reproduce the owned rows of the
     global oracle results.  Exercises nc_owned < nc in every kernel; RCCL itself needs >= 2 GPUs."""
@@ -198,7 +198,7 @@ def test_partitioned_kernels_on_one_gpu(hip_lib, world, p):
     q = copy.deepcopy(pbg)
     ko.update_phi_M(q); ko.update_c_elim(q)
     Eg = np.stack([ko.nernst(q, k) for k in range(3)])
-    part = Partition(m, world)
+    part = Partition(m, world, method="slab" if world == 2 else "rcb")
     for rank in range(world):
         loc = part.local(rank)
         sub_l, surf_l = loc.localize(s, f, (1,))
@@ -209,14 +209,19 @@ def test_partitioned_kernels_on_one_gpu(hip_lib, world, p):
         for name in pbg.I_ch:
             pbl.I_ch[name] = pbg.I_ch[name][loc.facets_global]
         dev = device_for(pbl, nc_owned=no)
+        assert 0 < dev.n_interior < no                        # device order: interior cells first, cells on the cut after them
         push_state(dev, pbl)
         dev.update_kappa(); dev.update_dnphi()
-        dev.upload(A.F_X, x[0][cg]); dev.emi_apply(A.F_X, A.F_Y)
-        y = dev.download(A.F_Y, 0, pbl.ndof).reshape(-1, pbl.nd)
-        assert relerr(y[:no], yg[cg[:no]]) < TOL
-        dev.upload(A.F_X, x[:, cg]); dev.knp_apply(A.F_X, A.F_Y)
-        y = dev.download(A.F_Y).reshape(pbg.N_ions, -1, pbl.nd)
-        assert relerr(y[:, :no], yk[:, cg[:no]]) < TOL
+        for split in ("0", "1"):                              # one launch / interior + boundary launches (the overlapped form)
+            monkeypatch.setenv("KNP_FORCE_SPLIT", split)
+            dev.upload(A.F_Y, np.zeros(dev.size(A.F_Y)))
+            dev.upload(A.F_X, x[0][cg]); dev.emi_apply(A.F_X, A.F_Y)
+            y = dev.download(A.F_Y, 0, pbl.ndof).reshape(-1, pbl.nd)
+            assert relerr(y[:no], yg[cg[:no]]) < TOL
+            dev.upload(A.F_X, x[:, cg]); dev.knp_apply(A.F_X, A.F_Y)
+            y = dev.download(A.F_Y).reshape(pbg.N_ions, -1, pbl.nd)
+            assert relerr(y[:, :no], yk[:, cg[:no]]) < TOL
+        monkeypatch.delenv("KNP_FORCE_SPLIT")
         dev.emi_rhs(); dev.knp_rhs()
         assert relerr(dev.download(A.F_B_EMI).reshape(-1, pbl.nd)[:no], bg.reshape(-1, pbg.nd)[cg[:no]]) < TOL
         assert relerr(dev.download(A.F_B_KNP).reshape(pbg.N_ions, -1, pbl.nd)[:, :no], bk[:, cg[:no]]) < TOL
@@ -228,6 +233,51 @@ def test_partitioned_kernels_on_one_gpu(hip_lib, world, p):
         assert relerr(dev.download(A.F_E).reshape(3, -1)[:, lmem], Eg[:, pos]) < 1e-12
         assert relerr(dev.download(A.F_C_ELIM).reshape(-1, pbl.nd), q.c_elim[cg]) < 1e-14
         dev.close()
+
+
+def test_partitioned_emix_mesh_on_one_gpu(hip_lib, monkeypatch):
+    """BASELINE configs[4] mesh (121 617 unstructured tets) cut into 4 parts by recursive coordinate bisection: a rank's owned +
+    ghost context (ghost values as the halo exchange delivers them) reproduces the owned rows of the single-context applies,
+    in one launch and as interior + boundary launches."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "emix_simulations"))
+    from emix_common import load_mesh
+    from knpemidg import _abi as A
+    from knpemidg.partition import Partition
+    m, s, f = load_mesh()
+    rng = np.random.default_rng(5)
+    nc = m.num_cells()
+    D = np.full((3, nc), 1.5e-8)
+    x = rng.uniform(-1, 1, size=(2, nc, 4))
+    cc = 100.0 * (1 + 0.01 * rng.uniform(-1, 1, size=(2, nc, 4)))
+    ce = 100.0 * (1 + 0.01 * rng.uniform(-1, 1, size=(nc, 4)))
+    phi = 50.0 * rng.uniform(-1, 1, size=(nc, 4))
+
+    def context(mesh, sub, surf, n_own, sel):
+        dev = A.Device(mesh, sub, surf, (1, 2), 3, nc_owned=n_own)
+        dev.set_params(2.0, 0.1, 96485e3, 8.314e3, 300e3, 20.0, 60.0, 60.0, [1.0, -1.0, 1.0], D[:, sel])
+        dev.upload(A.F_C, cc[:, sel]); dev.upload(A.F_C_ELIM, ce[sel]); dev.upload(A.F_PHI, phi[sel])
+        dev.update_kappa(); dev.update_dnphi()
+        dev.upload(A.F_X, x[:, sel])
+        dev.emi_apply(A.F_X, A.F_Y)
+        ye = dev.download(A.F_Y, 0, len(sel) * 4).reshape(-1, 4)
+        dev.knp_apply(A.F_X, A.F_Y)
+        yk = dev.download(A.F_Y).reshape(2, -1, 4)
+        return dev, ye, yk
+    dev, ye, yk = context(m, s.array(), f.array(), None, np.arange(nc))
+    dev.close()
+    part = Partition(m, 4, method="rcb")
+    for rank in (0, 3):
+        loc = part.local(rank)
+        sub_l, surf_l = loc.localize(s, f, (1, 2))
+        cg, no = loc.cells_global, loc.nc_owned
+        for split in ("0", "1"):
+            monkeypatch.setenv("KNP_FORCE_SPLIT", split)
+            dl, yel, ykl = context(loc.mesh, sub_l.array(), surf_l.array(), no, cg)
+            assert 0 < dl.n_interior < no
+            assert relerr(yel[:no], ye[cg[:no]]) < TOL and relerr(ykl[:, :no], yk[:, cg[:no]]) < TOL
+            dl.close()
+    monkeypatch.delenv("KNP_FORCE_SPLIT")
 
 
 def test_unstructured_geometry_uses_coordinate_kernels(hip_lib):

@@ -160,7 +160,7 @@ def test_h5lite_reads_the_emix_mesh():
     import os
     from knpemidg.h5lite import read_xdmf_mesh, H5File
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    d = os.path.join(root, "tests", "golden", "emix_mesh")
+    d = os.path.join(root, "examples", "emix_simulations", "meshes", "volume_ncells_5_size_5000")
     coords, cells, attrs = read_xdmf_mesh(os.path.join(d, "mesh.xdmf"))
     assert coords.shape == (22419, 3) and coords.dtype == np.float64
     assert cells.shape == (121617, 4) and cells.min() == 0 and cells.max() == 22418

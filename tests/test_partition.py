@@ -10,17 +10,30 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_partition_tables_are_consistent():
+def _emix_mesh():
+    sys.path.insert(0, os.path.join(ROOT, "knp-emi-dg_amd"))
+    sys.path.insert(0, os.path.join(ROOT, "examples", "emix_simulations"))
+    from emix_common import load_mesh
+    return load_mesh()
+
+
+@pytest.mark.parametrize("case", ["idealized-slab", "idealized-rcb", "emix-rcb"])
+def test_partition_tables_are_consistent(case):
+    """Product host path of the multi-GPU run: partition -> local meshes -> halo tables, for x-slabs of the idealized BoxMesh
+    and for the recursive coordinate bisection used on unstructured meshes (BASELINE configs[4], the EMIx reconstruction)."""
+    sys.path.insert(0, os.path.join(ROOT, "knp-emi-dg_amd"))
     from knpemidg.mesh import make_mesh_3D
     from knpemidg.partition import Partition
-    m, s, f = make_mesh_3D(0, n_axons=1)
-    for world in (2, 3, 8):
-        part = Partition(m, world)
+    m, s, f = _emix_mesh() if case.startswith("emix") else make_mesh_3D(0, n_axons=1)
+    method = case.split("-")[1]
+    mtags = (1, 2) if case.startswith("emix") else (1,)
+    for world in ((2, 3, 8) if method == "slab" else (2, 4, 8)):
+        part = Partition(m, world, method=method)
         locs = [part.local(r) for r in range(world)]
         assert sum(l.nc_owned for l in locs) == m.num_cells()
-        assert max(l.nc_owned for l in locs) - min(l.nc_owned for l in locs) <= 1
+        assert max(l.nc_owned for l in locs) - min(l.nc_owned for l in locs) <= (1 if method == "slab" else world)
         for r, l in enumerate(locs):
-            assert len(l.peers) <= 2                          # x-slabs
+            assert len(l.peers) <= (2 if method == "slab" else world - 1)
             for q, sl, ro, rc in zip(l.peers, l.send_lists, l.recv_offsets, l.recv_counts):
                 lq = locs[q]
                 i = lq.peers.index(r)
@@ -33,14 +46,21 @@ def test_partition_tables_are_consistent():
             glob_int = (m.facet_cells[m.cell_facets[l.owned]][:, :, 1] >= 0)
             loc_int = (nb[cf][:, :, 1] >= 0)
             assert np.array_equal(glob_int, loc_int)
-            sub_l, surf_l = l.localize(s, f, (1,))
+            sub_l, surf_l = l.localize(s, f, mtags)
             assert np.array_equal(sub_l.array(), s.array()[l.cells_global])
             # membrane facets kept == those touching an owned cell
-            mem = np.nonzero(surf_l.array() == 1)[0]
+            mem = np.nonzero(np.isin(surf_l.array(), mtags))[0]
             assert ((nb[mem, 0] < l.nc_owned) | (nb[mem, 1] < l.nc_owned)).all()
+        # every membrane facet of the global mesh is kept by at least one rank (and by two when it lies on a cut)
+        gmem = np.nonzero((m.facet_cells[:, 1] >= 0) & np.isin(f.array(), mtags))[0]
+        seen = np.zeros(m.num_facets(), dtype=np.int64)
+        for l in locs:
+            _, surf_l = l.localize(s, f, mtags)
+            seen[l.facets_global[np.isin(surf_l.array(), mtags)]] += 1
+        assert (seen[gmem] >= 1).all() and seen.max() <= 2
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, method="slab"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     for p in (os.path.join(ROOT, "knp-emi-dg_amd"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
@@ -58,7 +78,7 @@ def _worker(rank, world, port, q):
         yg = (Ag @ x[0].ravel()).reshape(-1, pbg.nd)
         yk = [(ko.assemble_knp(pbg, k) @ x[k].ravel()).reshape(-1, pbg.nd) for k in range(pbg.N_ions)]
         bk = [ko.knp_rhs(pbg, k).reshape(-1, pbg.nd) for k in range(pbg.N_ions)]
-        loc = Partition(m, world).local(rank)
+        loc = Partition(m, world, method=method).local(rank)
         sub_l, surf_l = loc.localize(s, f, (1,))
         pbl = ko.build_idealized(loc.mesh, sub_l.array(), surf_l.array(), membrane_tags=(1,))
         cg = loc.cells_global
@@ -99,13 +119,13 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_halo_exchange_gloo(world):
+@pytest.mark.parametrize("world,method", [(2, "slab"), (3, "slab"), (4, "rcb"), (8, "rcb")])
+def test_halo_exchange_gloo(world, method):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29500 + (os.getpid() % 2000) + world
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, method)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=300) for _ in procs]
