@@ -1,9 +1,13 @@
-"""Minimal read-only HDF5 subset reader (no h5py in this environment).
+"""Minimal HDF5 subset reader and writer (no h5py in this environment).
 
 Enough of the format for the mesh files the reference ships next to its XDMF descriptors
 (reference: examples/emix-simulations/run_EMIx_simulation.py:162-168 reads them through dolfin's XDMFFile):
 superblock version 0, version-1 object headers, symbol-table groups, contiguous or chunked datasets with version-1
 chunk B-trees, fixed-point / IEEE float types, deflate (+ shuffle) filters.  Everything else raises.
+
+`H5Writer` writes the same subset (nested symbol-table groups, contiguous datasets) for the result files of
+`Solver.init_h5_savefile / save_h5` (reference: src/knpemidg/solver.py:1214-1242: /mesh, /subdomains, /surfaces and the time series
+/concentrations/vector_n, /elim_concentration/vector_n, /potential/vector_n).
 """
 import struct
 import zlib
@@ -35,10 +39,20 @@ class H5File:
             raise H5Error("root group without cached symbol table")
         btree, heap = struct.unpack_from("<QQ", b, ste + 24)
         self.datasets = {}
+        self._walk("", btree, heap)
+
+    def _walk(self, prefix, btree, heap):
+        """Collect every object below a group: name -> object header address (nested groups as 'a/b/c')."""
+        b = self.buf
         heap_data = self._local_heap(heap)
         for name_off, ohdr in self._group_entries(btree):
             end = b.index(b"\0", heap_data + name_off)
-            self.datasets[b[heap_data + name_off:end].decode()] = ohdr
+            name = prefix + b[heap_data + name_off:end].decode()
+            sub = [d for t, d in self._messages(ohdr) if t == 0x11]
+            if sub:
+                self._walk(name + "/", *struct.unpack_from("<QQ", sub[0], 0))
+            else:
+                self.datasets[name] = ohdr
 
     # -- groups ------------------------------------------------------------------------------------
     def _local_heap(self, addr):
@@ -83,6 +97,7 @@ class H5File:
         return out
 
     def read(self, name):
+        name = name.lstrip("/")
         if name not in self.datasets:
             raise KeyError(name)
         shape = dtype = layout = None
@@ -189,3 +204,136 @@ def read_xdmf_mesh(xdmf_path):
     if coords is None or cells is None:
         raise H5Error("XDMF file without geometry / topology")
     return coords, cells, attrs
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# writer
+# ------------------------------------------------------------------------------------------------------------------
+class H5Writer:
+    """Streams datasets to disk as they arrive (raw data appended to the file) and writes all metadata -- nested groups as
+    version-1 B-tree / local heap / symbol-table nodes, version-1 object headers with dataspace, datatype, fill-value and
+    contiguous-layout messages -- when the file is closed.  Superblock version 0, little endian, 8-byte offsets."""
+
+    _K_LEAF = 4096                     # symbols per symbol-table node <= 2 K: one node per group (time series of any length)
+
+    def __init__(self, path):
+        self.path = path
+        self.fh = open(path, "wb")
+        self.fh.write(b"\0" * 96)      # superblock, patched on close
+        self.items = {}                # path -> (offset, shape, dtype)
+
+    def write(self, name, array):
+        a = np.ascontiguousarray(array)
+        if a.dtype.kind not in "iuf" or a.dtype.itemsize not in (1, 2, 4, 8):
+            raise H5Error("dtype %s not supported" % a.dtype)
+        a = a.astype(a.dtype.newbyteorder("<"), copy=False)
+        name = name.strip("/")
+        if name in self.items or not name:
+            raise H5Error("dataset %r already written" % name)
+        self._align()
+        off = self.fh.tell()
+        self.fh.write(a.tobytes())
+        self.items[name] = (off, a.shape, a.dtype)
+
+    def _align(self):
+        pad = (-self.fh.tell()) % 8
+        if pad:
+            self.fh.write(b"\0" * pad)
+
+    def _put(self, blob):
+        self._align()
+        off = self.fh.tell()
+        self.fh.write(blob)
+        return off
+
+    @staticmethod
+    def _msg(mtype, data):
+        data = data + b"\0" * ((-len(data)) % 8)
+        return struct.pack("<HHB3x", mtype, len(data), 0) + data
+
+    def _object_header(self, msgs):
+        body = b"".join(msgs)
+        return struct.pack("<BxHII4x", 1, len(msgs), 1, len(body)) + body
+
+    def _dataset_header(self, off, shape, dtype):
+        n = int(np.prod(shape)) * dtype.itemsize if len(shape) else dtype.itemsize
+        space = struct.pack("<BBB5x", 1, len(shape), 0) + b"".join(struct.pack("<Q", int(d)) for d in shape)
+        if dtype.kind == "f":
+            bits = dtype.itemsize * 8
+            mant, expo = (52, 11) if bits == 64 else (23, 8)
+            dt = struct.pack("<BBBBI", 0x11, 0x20, bits - 1, 0, dtype.itemsize) + \
+                struct.pack("<HHBBBBI", 0, bits, mant, expo, 0, mant, (1 << (expo - 1)) - 1)
+        else:
+            dt = struct.pack("<BBBBI", 0x10, 0x08 if dtype.kind == "i" else 0x00, 0, 0, dtype.itemsize) + \
+                struct.pack("<HH", 0, dtype.itemsize * 8)
+        fill = struct.pack("<BBBB", 2, 2, 0, 0)
+        layout = struct.pack("<BBQQ", 3, 1, off if n else _UNDEF, n)
+        return self._object_header([self._msg(0x01, space), self._msg(0x03, dt), self._msg(0x05, fill), self._msg(0x08, layout)])
+
+    def _write_group(self, tree):
+        """tree: {name: subtree dict | (off, shape, dtype)}.  Returns (object header address, btree address, heap address)."""
+        names = sorted(tree, key=lambda s: s.encode())
+        if len(names) > 2 * self._K_LEAF:
+            raise H5Error("too many entries in one group")
+        entries = []
+        for nm in names:
+            node = tree[nm]
+            if isinstance(node, dict):
+                oh, bt, hp = self._write_group(node)
+                entries.append((nm, oh, 1, struct.pack("<QQ", bt, hp)))
+            else:
+                entries.append((nm, self._put(self._dataset_header(*node)), 0, b"\0" * 16))
+        heap = bytearray(8)                                         # offset 0: the empty name
+        offs = []
+        for nm, *_ in entries:
+            offs.append(len(heap))
+            raw = nm.encode() + b"\0"
+            heap += raw + b"\0" * ((-len(raw)) % 8)
+        heap += b"\0" * 16                                          # a free block keeps library writers happy
+        heap_data = self._put(bytes(heap))
+        heap_addr = self._put(b"HEAP" + struct.pack("<B3xQQQ", 0, len(heap), len(heap) - 16, heap_data))
+        # the free block header inside the data segment: next free = 1 (none), size
+        self.fh.seek(heap_data + len(heap) - 16)
+        self.fh.write(struct.pack("<QQ", 1, 16))
+        self.fh.seek(0, 2)
+        snod = b"SNOD" + struct.pack("<BxH", 1, len(entries))
+        for (nm, oh, cache, scratch), o in zip(entries, offs):
+            snod += struct.pack("<QQI4x", o, oh, cache) + scratch
+        snod += b"\0" * (40 * (2 * self._K_LEAF - len(entries)))
+        snod_addr = self._put(snod)
+        K_INT = 16
+        bt = b"TREE" + struct.pack("<BBHQQ", 0, 0, 1, _UNDEF, _UNDEF) + struct.pack("<QQQ", 0, snod_addr, offs[-1] if offs else 0)
+        bt += b"\0" * (16 * (2 * K_INT - 1))
+        bt_addr = self._put(bt)
+        oh_addr = self._put(self._object_header([self._msg(0x11, struct.pack("<QQ", bt_addr, heap_addr))]))
+        return oh_addr, bt_addr, heap_addr
+
+    def close(self):
+        if self.fh is None:
+            return
+        tree = {}
+        for name, item in self.items.items():
+            node = tree
+            parts = name.split("/")
+            for part in parts[:-1]:
+                node = node.setdefault(part, {})
+                if not isinstance(node, dict):
+                    raise H5Error("%r is both a dataset and a group" % part)
+            node[parts[-1]] = item
+        oh, bt, hp = self._write_group(tree)
+        self._align()
+        eof = self.fh.tell()
+        sb = b"\x89HDF\r\n\x1a\n" + struct.pack("<BBBBBBBBHHI", 0, 0, 0, 0, 0, 8, 8, 0, self._K_LEAF, 16, 0)
+        sb += struct.pack("<QQQQ", 0, _UNDEF, eof, _UNDEF)
+        sb += struct.pack("<QQI4xQQ", 0, oh, 1, bt, hp)
+        assert len(sb) == 96
+        self.fh.seek(0)
+        self.fh.write(sb)
+        self.fh.close()
+        self.fh = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()

@@ -680,22 +680,46 @@ class Solver:
                 f.close()
 
     # ------------------------------------------------------------------ field output (solver.py:1214-1242)
-    # The reference writes a DOLFIN HDF5 time series; without h5py the same datasets go to .npz snapshots.
+    # One HDF5 file `<filename>.h5` with the reference's dataset names (written by knpemidg.h5lite.H5Writer; no h5py here):
+    #   /mesh/coordinates, /mesh/topology, /subdomains/values, /surfaces/values (+ /surfaces/topology: facet vertices),
+    #   /concentrations/vector_n, /elim_concentration/vector_n, /potential/vector_n   (n = 0: initial state, then every sf-th step)
+    # plus this build's DG dof layout per field (cell_dofs / x_cell_dofs as DOLFIN stores them): dof(c, j) = c nd + j, species-major
+    # for the mixed concentration function.  A distributed run writes one file per rank (`..._rank<r>.h5`) holding its owned +
+    # ghost cells and /cells_global, the local -> global cell map.
     def init_h5_savefile(self, filename):
+        from knpemidg.h5lite import H5Writer
         self.h5_idx = 0
-        self._h5_prefix = filename
         os.makedirs(os.path.dirname(filename) or ".", exist_ok=True)
-        np.savez(filename + "_mesh.npz", coords=self.mesh.coords, cells=self.mesh.cells,
-                 subdomains=self.subdomains.array(), surfaces=self.surfaces.array(), facets=self.mesh.facets)
+        loc = getattr(self, "local_mesh", None)
+        rank_sfx = "" if loc is None else "_rank%d" % getattr(self.dev, "rank", loc.rank)
+        self.h5_path = filename + rank_sfx + ".h5"
+        w = self.h5_file = H5Writer(self.h5_path)
+        w.write("/mesh/coordinates", self.mesh.coords)
+        w.write("/mesh/topology", self.mesh.cells.astype(np.int64))
+        w.write("/subdomains/values", np.asarray(self.subdomains.array()).astype(np.uint64))
+        w.write("/surfaces/values", np.asarray(self.surfaces.array()).astype(np.uint64))
+        w.write("/surfaces/topology", self.mesh.facets.astype(np.int64))
+        if loc is not None:
+            w.write("/cells_global", loc.cells_global.astype(np.int64))
+        nc, nd = self.mesh.num_cells(), self.nd
+        base = (np.arange(nc)[:, None] * nd + np.arange(nd)[None, :]).astype(np.int64)
+        for name, ncomp in (("concentrations", self.N_ions), ("elim_concentration", 1), ("potential", 1)):
+            dofs = np.concatenate([base + k * nc * nd for k in range(ncomp)], axis=1)
+            w.write("/%s/cell_dofs" % name, dofs.ravel())
+            w.write("/%s/x_cell_dofs" % name, (np.arange(nc + 1) * dofs.shape[1]).astype(np.int64))
+            w.write("/%s/cells" % name, np.arange(nc, dtype=np.int64))
         self._write_snapshot()
 
     def _write_snapshot(self):
-        np.savez(self._h5_prefix + "_%05d.npz" % self.h5_idx, concentrations=self.c.array(),
-                 elim_concentration=self.ion_list[-1]['c'].array(), potential=self.phi.array())
+        w = self.h5_file
+        w.write("/concentrations/vector_%d" % self.h5_idx, self.c.array().ravel())
+        w.write("/elim_concentration/vector_%d" % self.h5_idx, self.ion_list[-1]['c'].array().ravel())
+        w.write("/potential/vector_%d" % self.h5_idx, self.phi.array().ravel())
 
     def save_h5(self):
         self.h5_idx += 1
         self._write_snapshot()
 
     def close_h5(self):
+        self.h5_file.close()
         return

@@ -509,3 +509,26 @@ def test_amg_hierarchy_is_refreshed_when_kappa_drifts(hip_lib, monkeypatch):
     assert S.amg_refreshes >= 1
     assert max(S.emi_niter[-3:]) <= 2 * before + 4, S.emi_niter
     S.dev.close()
+
+
+def test_result_file_has_the_reference_datasets(hip_lib, tmp_path):
+    """solve_system_active(..., save_fields=True) writes `<filename>results.h5` with the reference's dataset names
+    (solver.py:1214-1242): mesh, subdomains, surfaces and one vector_n per saved step for concentrations, eliminated
+    concentration and potential; the last snapshot equals the solver's final fields."""
+    from common_examples import make_solver, solver_parameters, Constant
+    from knpemidg.h5lite import H5File
+    S = make_solver(dim=2, resolution=0)
+    t = Constant(0.0)
+    prefix = str(tmp_path / "out") + "/"
+    S.solve_system_active(3e-4, t, solver_parameters(2, 0), filename=prefix, save_fields=True, save_solver_stats=True)
+    f = H5File(prefix + "results.h5")
+    for name in ("mesh/coordinates", "mesh/topology", "subdomains/values", "surfaces/values", "concentrations/vector_0",
+                 "concentrations/vector_3", "elim_concentration/vector_3", "potential/vector_3", "potential/cell_dofs"):
+        assert name in f.datasets, name
+    assert "potential/vector_4" not in f.datasets
+    assert np.array_equal(f.read("mesh/topology"), S.mesh.cells)
+    assert np.array_equal(f.read("concentrations/vector_3"), S.c.array().ravel())
+    assert np.array_equal(f.read("potential/vector_3"), S.phi.array().ravel())
+    assert np.array_equal(f.read("surfaces/values"), S.surfaces.array())
+    assert os.path.exists(prefix + "solver/emi_niter_0.txt")
+    S.dev.close()

@@ -241,3 +241,71 @@ def test_conforming_p2_auxiliary_space_is_galerkin():
     mids = np.stack([0.5 * (x[:, a] + x[:, b]) for a, b in c2.edges], axis=1) @ np.array([1.0, -2.0, 0.5])
     v2 = c2.interp @ v1
     assert np.abs(v2[c2.dof[:, 4:]] - mids).max() < 1e-12 * np.abs(lin).max()
+
+
+def test_h5_writer_round_trip_and_libhdf5(tmp_path):
+    """Result-file writer (knpemidg.h5lite.H5Writer: nested groups, contiguous datasets) read back by the package's own reader
+    and -- where a libhdf5 is installed -- by the real HDF5 library through ctypes."""
+    import ctypes as C
+    import glob
+    from knpemidg.h5lite import H5Writer, H5File
+    rng = np.random.default_rng(0)
+    data = {"/mesh/coordinates": rng.standard_normal((1000, 3)), "/mesh/topology": rng.integers(0, 1000, size=(500, 4)).astype(np.int64),
+            "/subdomains/values": rng.integers(0, 5, size=500).astype(np.uint64), "/f32": np.arange(5, dtype=np.float32),
+            "/i32": np.arange(-3, 4, dtype=np.int32)}
+    for n in range(40):
+        data["/potential/vector_%d" % n] = rng.standard_normal(77)
+    path = str(tmp_path / "t.h5")
+    with H5Writer(path) as w:
+        for k, v in data.items():
+            w.write(k, v)
+    f = H5File(path)
+    assert sorted(f.datasets) == sorted(k.lstrip("/") for k in data)
+    for k, v in data.items():
+        got = f.read(k)
+        assert got.dtype == v.dtype and np.array_equal(got, v)
+    libs = sorted(glob.glob("/opt/conda/lib/libhdf5.so*") + glob.glob("/usr/lib/x86_64-linux-gnu/libhdf5*.so*"))
+    if not libs:
+        pytest.skip("no libhdf5 on this machine for the cross-check")
+    lib = C.CDLL(libs[0])
+    lib.H5open()
+    hid = C.c_int64
+    lib.H5Fopen.restype = hid; lib.H5Fopen.argtypes = [C.c_char_p, C.c_uint, hid]
+    lib.H5Dopen2.restype = hid; lib.H5Dopen2.argtypes = [hid, C.c_char_p, hid]
+    lib.H5Dget_space.restype = hid; lib.H5Dget_space.argtypes = [hid]
+    lib.H5Sget_simple_extent_ndims.argtypes = [hid]
+    lib.H5Sget_simple_extent_dims.argtypes = [hid, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    lib.H5Dread.argtypes = [hid, hid, hid, hid, hid, C.c_void_p]
+    fid = lib.H5Fopen(path.encode(), 0, 0)
+    assert fid >= 0
+    native = {np.dtype(np.float64): "H5T_NATIVE_DOUBLE_g", np.dtype(np.float32): "H5T_NATIVE_FLOAT_g", np.dtype(np.int64): "H5T_NATIVE_INT64_g",
+              np.dtype(np.uint64): "H5T_NATIVE_UINT64_g", np.dtype(np.int32): "H5T_NATIVE_INT32_g"}
+    for k in ("/mesh/coordinates", "/mesh/topology", "/subdomains/values", "/f32", "/i32", "/potential/vector_39"):
+        d = lib.H5Dopen2(fid, k.encode(), 0)
+        assert d >= 0, k
+        sp = lib.H5Dget_space(d)
+        nd = lib.H5Sget_simple_extent_ndims(sp)
+        dims = (C.c_uint64 * nd)()
+        lib.H5Sget_simple_extent_dims(sp, dims, None)
+        a = np.empty(tuple(dims), dtype=data[k].dtype)
+        assert lib.H5Dread(d, hid.in_dll(lib, native[data[k].dtype]).value, 0, 0, 0, a.ctypes.data) >= 0
+        assert np.array_equal(a, data[k]), k
+
+
+def test_dolfin_xml_mesh_round_trip(tmp_path):
+    """DOLFIN XML mesh / MeshFunction files (run_3D.py:166-168) written and read back: coordinates, connectivity, cell tags and
+    facet tags keyed by (cell, local facet) land on the same entities."""
+    from knpemidg.mesh import make_mesh_3D, make_mesh_2D
+    from knpemidg import mesh_io
+    from common import small_3d
+    for mt in (small_3d((6, 3, 3)), make_mesh_2D(0)):
+        m, s, f = mt
+        mesh_io.write_dolfin_xml_mesh(m, str(tmp_path / "mesh.xml"))
+        mesh_io.write_dolfin_xml_meshfunction(m, s, str(tmp_path / "sub.xml"))
+        mesh_io.write_dolfin_xml_meshfunction(m, f, str(tmp_path / "surf.xml"))
+        m2 = mesh_io.read_dolfin_xml_mesh(str(tmp_path / "mesh.xml"))
+        assert np.array_equal(m2.cells, m.cells) and np.allclose(m2.coords, m.coords, rtol=1e-15, atol=0)
+        assert np.array_equal(m2.facet_cells, m.facet_cells)
+        s2 = mesh_io.read_dolfin_xml_meshfunction(m2, str(tmp_path / "sub.xml"))
+        f2 = mesh_io.read_dolfin_xml_meshfunction(m2, str(tmp_path / "surf.xml"))
+        assert np.array_equal(s2.array(), s.array()) and np.array_equal(f2.array(), f.array())
