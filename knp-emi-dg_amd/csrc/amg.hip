@@ -36,64 +36,118 @@ int up_csr(knp_ctx* c, CsrDev& M, int64_t nrows, int64_t ncols, const int32_t* r
 
 void free_csr(CsrDev& M) { hipFree(M.rowptr); hipFree(M.col); hipFree(M.val); M = CsrDev(); }
 
-// partial dot product of CSR row `row` with x over this lane's entries (lane, lane+G, ...). The loop is unrolled so
-// that up to 4 (col, val, x[col]) chains are in flight per lane: these kernels are latency-bound (a row has 15..100
-// entries), not bandwidth-bound, and a rolled loop serialises one memory round trip per iteration.
-template <int G>
-__device__ __forceinline__ double row_dot(const CsrDev& A, int64_t row, int lane, const double* __restrict__ x) {
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+// partial dot products of CSR row `row` with NC vectors x + j * xstride over this lane's entries (lane, lane+G, ...).  The loop is
+// unrolled so that 2 (col, val) pairs x NC gathers are in flight per lane: these kernels are latency-bound (a row has 15..100
+// entries), not bandwidth-bound.  NC = 2 carries both KNP species of a shared hierarchy through ONE pass over the matrix
+// (indices and fp32 values are read once instead of once per column).
+template <int G, int NC>
+__device__ __forceinline__ void row_dot(const CsrDev& A, int64_t row, int lane, const double* __restrict__ x, int64_t xstride, double* out) {
+    constexpr int U = NC == 1 ? 4 : 2;                    // (col, val) pairs in flight per lane
+    double s[U][NC];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int j = 0; j < NC; ++j) s[u][j] = 0.0;
     if (row < A.nrows) {
         const int e = A.rowptr[row + 1];
         int k = A.rowptr[row] + lane;
-        for (; k + 3 * G < e; k += 4 * G) {
-            const int c0 = A.col[k], c1 = A.col[k + G], c2 = A.col[k + 2 * G], c3 = A.col[k + 3 * G];
-            const double v0 = A.val[k], v1 = A.val[k + G], v2 = A.val[k + 2 * G], v3 = A.val[k + 3 * G];   // float -> double
-            s0 = fma(v0, x[c0], s0);
-            s1 = fma(v1, x[c1], s1);
-            s2 = fma(v2, x[c2], s2);
-            s3 = fma(v3, x[c3], s3);
-        }
-        if (k + G < e) {
-            const int c0 = A.col[k], c1 = A.col[k + G];
-            const double v0 = A.val[k], v1 = A.val[k + G];
-            s0 = fma(v0, x[c0], s0);
-            s1 = fma(v1, x[c1], s1);
-            k += 2 * G;
-        }
-        if (k < e) s2 = fma(A.val[k], x[A.col[k]], s2);
-    }
-    double s = (s0 + s1) + (s2 + s3);
+        for (; k + (U - 1) * G < e; k += U * G) {
+            int cc[U];
+            double vv[U];
 #pragma unroll
-    for (int off = G / 2; off > 0; off >>= 1) s += __shfl_down(s, off, G);
-    return s;
+            for (int u = 0; u < U; ++u) { cc[u] = A.col[k + u * G]; vv[u] = A.val[k + u * G]; }      // float -> double
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int j = 0; j < NC; ++j) s[u][j] = fma(vv[u], x[cc[u] + j * xstride], s[u][j]);
+        }
+#pragma unroll
+        for (int u = 0; u < U - 1; ++u) {
+            if (k < e) {
+                const int c0 = A.col[k];
+                const double v0 = A.val[k];
+#pragma unroll
+                for (int j = 0; j < NC; ++j) s[u][j] = fma(v0, x[c0 + j * xstride], s[u][j]);
+                k += G;
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+        double t = U == 4 ? (s[0][j] + s[1][j]) + (s[2 % U][j] + s[3 % U][j]) : s[0][j] + s[1][j];
+#pragma unroll
+        for (int off = G / 2; off > 0; off >>= 1) t += __shfl_down(t, off, G);
+        out[j] = t;
+    }
 }
 
-// y = A x (MODE 0) | y = b - A x (MODE 1) | y += A x (MODE 2); G lanes cooperate on one row
-template <int MODE, int G>
+// y = A x (MODE 0) | y = b - A x (MODE 1) | y += A x (MODE 2); G lanes cooperate on one row; NC columns per thread, the rest of the
+// right-hand-side columns along grid.y
+template <int MODE, int G, int NC>
 __global__ __launch_bounds__(256) void k_csr(CsrDev A, const double* __restrict__ x, const double* __restrict__ b,
                                              double* __restrict__ y) {
-    x += (int64_t)blockIdx.y * A.ncols;
-    y += (int64_t)blockIdx.y * A.nrows;
-    if (MODE == 1) b += (int64_t)blockIdx.y * A.nrows;
+    x += (int64_t)blockIdx.y * NC * A.ncols;
+    y += (int64_t)blockIdx.y * NC * A.nrows;
+    if (MODE == 1) b += (int64_t)blockIdx.y * NC * A.nrows;
     const int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) / G;
     const int lane = threadIdx.x % G;
-    const double s = row_dot<G>(A, row, lane, x);
+    double s[NC];
+    row_dot<G, NC>(A, row, lane, x, A.ncols, s);
     if (row < A.nrows && lane == 0) {
-        if (MODE == 0) y[row] = s;
-        else if (MODE == 1) y[row] = b[row] - s;
-        else y[row] += s;
+#pragma unroll
+        for (int j = 0; j < NC; ++j) {
+            const int64_t o = row + (int64_t)j * A.nrows;
+            if (MODE == 0) y[o] = s[j];
+            else if (MODE == 1) y[o] = b[o] - s[j];
+            else y[o] += s[j];
+        }
+    }
+}
+
+#define LAUNCH_BY_DENSITY(KERN, A, ...)                                                                                       \
+    do {                                                                                                                      \
+        const double avg_ = (A).nrows ? (double)(A).nnz / (double)(A).nrows : 0.0;                                            \
+        const bool two_ = (s_ncol % 2) == 0;                                                                                  \
+        const unsigned gy_ = (unsigned)(two_ ? s_ncol / 2 : s_ncol);                                                          \
+        if (avg_ <= 12.0) {                                                                                                   \
+            const dim3 g_((unsigned)(((A).nrows + 255) / 256), gy_);                                                          \
+            if (two_) hipLaunchKernelGGL((KERN<1, 2>), g_, dim3(256), 0, c->stream, __VA_ARGS__);                             \
+            else hipLaunchKernelGGL((KERN<1, 1>), g_, dim3(256), 0, c->stream, __VA_ARGS__);                                  \
+        } else if (avg_ <= 96.0) {                                                                                            \
+            const dim3 g_((unsigned)(((A).nrows * 8 + 255) / 256), gy_);                                                      \
+            if (two_) hipLaunchKernelGGL((KERN<8, 2>), g_, dim3(256), 0, c->stream, __VA_ARGS__);                             \
+            else hipLaunchKernelGGL((KERN<8, 1>), g_, dim3(256), 0, c->stream, __VA_ARGS__);                                  \
+        } else {                                                                                                              \
+            const dim3 g_((unsigned)(((A).nrows * 64 + 255) / 256), gy_);                                                     \
+            if (two_) hipLaunchKernelGGL((KERN<64, 2>), g_, dim3(256), 0, c->stream, __VA_ARGS__);                            \
+            else hipLaunchKernelGGL((KERN<64, 1>), g_, dim3(256), 0, c->stream, __VA_ARGS__);                                 \
+        }                                                                                                                     \
+    } while (0)
+
+template <int MODE> struct CsrKern {
+    template <int G, int NC> static void launch(knp_ctx* c, const dim3& g, const CsrDev& A, const double* x, const double* b, double* y, hipStream_t st) {
+        hipLaunchKernelGGL((k_csr<MODE, G, NC>), g, dim3(256), 0, st, A, x, b, y);
+    }
+};
+
+template <int MODE> void launch_csr_on(knp_ctx* c, const CsrDev& A, const double* x, const double* b, double* y, hipStream_t st) {
+    const double avg = A.nrows ? (double)A.nnz / (double)A.nrows : 0.0;
+    const bool two = (s_ncol % 2) == 0;
+    const unsigned gy = (unsigned)(two ? s_ncol / 2 : s_ncol);
+    if (avg <= 12.0) {
+        const dim3 g((unsigned)((A.nrows + 255) / 256), gy);
+        if (two) CsrKern<MODE>::template launch<1, 2>(c, g, A, x, b, y, st); else CsrKern<MODE>::template launch<1, 1>(c, g, A, x, b, y, st);
+    } else if (avg <= 96.0) {
+        const dim3 g((unsigned)((A.nrows * 8 + 255) / 256), gy);
+        if (two) CsrKern<MODE>::template launch<8, 2>(c, g, A, x, b, y, st); else CsrKern<MODE>::template launch<8, 1>(c, g, A, x, b, y, st);
+    } else {
+        const dim3 g((unsigned)((A.nrows * 64 + 255) / 256), gy);
+        if (two) CsrKern<MODE>::template launch<64, 2>(c, g, A, x, b, y, st); else CsrKern<MODE>::template launch<64, 1>(c, g, A, x, b, y, st);
     }
 }
 
 template <int MODE> void launch_csr(knp_ctx* c, const CsrDev& A, const double* x, const double* b, double* y) {
-    const double avg = A.nrows ? (double)A.nnz / (double)A.nrows : 0.0;
-    if (avg <= 12.0) {
-        hipLaunchKernelGGL((k_csr<MODE, 1>), GRIDX((A.nrows + 255) / 256), dim3(256), 0, c->stream, A, x, b, y);
-    } else if (avg <= 96.0) {
-        hipLaunchKernelGGL((k_csr<MODE, 8>), GRIDX((A.nrows * 8 + 255) / 256), dim3(256), 0, c->stream, A, x, b, y);
-    } else {
-        hipLaunchKernelGGL((k_csr<MODE, 64>), GRIDX((A.nrows * 64 + 255) / 256), dim3(256), 0, c->stream, A, x, b, y);
-    }
+    launch_csr_on<MODE>(c, A, x, b, y, c->stream);
 }
 
 // first Chebyshev update:  d = dinv r / theta ;  x = d (zero guess) or x += d
@@ -112,80 +166,88 @@ __global__ void k_cheb_first(int64_t n, const double* __restrict__ dinv, const d
 }
 
 // non-zero guess, fused:  r = b - A x ;  d = dinv r / theta ;  xout = x + d     (xout != x: neighbours still read x)
-template <int G>
+template <int G, int NC>
 __global__ __launch_bounds__(256) void k_cheb_first_res(CsrDev A, const double* __restrict__ dinv, const double* __restrict__ b,
                                                         const double* __restrict__ x, double inv_theta, double* __restrict__ r,
                                                         double* __restrict__ d, double* __restrict__ xout) {
-    const int64_t o = (int64_t)blockIdx.y * A.nrows;
+    const int64_t o = (int64_t)blockIdx.y * NC * A.nrows;
     b += o; x += o; r += o; d += o; xout += o;
     const int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) / G;
     const int lane = threadIdx.x % G;
-    const double s = row_dot<G>(A, row, lane, x);
+    double s[NC];
+    row_dot<G, NC>(A, row, lane, x, A.nrows, s);
     if (row < A.nrows && lane == 0) {
-        const double rn = b[row] - s;
-        const double v = dinv[row] * rn * inv_theta;
-        r[row] = rn;
-        d[row] = v;
-        xout[row] = x[row] + v;
+        const double di = dinv[row];
+#pragma unroll
+        for (int j = 0; j < NC; ++j) {
+            const int64_t q = row + (int64_t)j * A.nrows;
+            const double rn = b[q] - s[j];
+            const double v = di * rn * inv_theta;
+            r[q] = rn;
+            d[q] = v;
+            xout[q] = x[q] + v;
+        }
     }
 }
 
 // fused step:  r -= A d_in ;  d_out = c1 d_in + c2 dinv r ;  x += d_out        (G lanes per row)
-template <int G>
+template <int G, int NC>
 __global__ __launch_bounds__(256) void k_cheb_step(CsrDev A, const double* __restrict__ dinv, const double* __restrict__ din,
                                                    double c1, double c2, double* __restrict__ r, double* __restrict__ dout,
                                                    double* __restrict__ x) {
-    const int64_t o = (int64_t)blockIdx.y * A.nrows;
+    const int64_t o = (int64_t)blockIdx.y * NC * A.nrows;
     din += o; r += o; dout += o; x += o;
     const int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) / G;
     const int lane = threadIdx.x % G;
-    const double s = row_dot<G>(A, row, lane, din);
+    double s[NC];
+    row_dot<G, NC>(A, row, lane, din, A.nrows, s);
     if (row < A.nrows && lane == 0) {
-        const double rn = r[row] - s;
-        const double dn = fma(c1, din[row], c2 * dinv[row] * rn);
-        r[row] = rn;
-        dout[row] = dn;
-        x[row] += dn;
+        const double di = dinv[row];
+#pragma unroll
+        for (int j = 0; j < NC; ++j) {
+            const int64_t q = row + (int64_t)j * A.nrows;
+            const double rn = r[q] - s[j];
+            const double dn = fma(c1, din[q], c2 * di * rn);
+            r[q] = rn;
+            dout[q] = dn;
+            x[q] += dn;
+        }
     }
 }
 
 void launch_cheb_step(knp_ctx* c, const CsrDev& A, const double* dinv, const double* din, double c1, double c2, double* r,
                       double* dout, double* x) {
-    const double avg = A.nrows ? (double)A.nnz / (double)A.nrows : 0.0;
-    if (avg <= 12.0)
-        hipLaunchKernelGGL((k_cheb_step<1>), GRIDX((A.nrows + 255) / 256), dim3(256), 0, c->stream, A, dinv, din, c1, c2, r, dout, x);
-    else if (avg <= 96.0)
-        hipLaunchKernelGGL((k_cheb_step<8>), GRIDX((A.nrows * 8 + 255) / 256), dim3(256), 0, c->stream, A, dinv, din, c1, c2, r, dout, x);
-    else
-        hipLaunchKernelGGL((k_cheb_step<64>), GRIDX((A.nrows * 64 + 255) / 256), dim3(256), 0, c->stream, A, dinv, din, c1, c2, r, dout, x);
+    LAUNCH_BY_DENSITY(k_cheb_step, A, A, dinv, din, c1, c2, r, dout, x);
 }
 
 // dense y = M b on the coarsest level (n up to a few thousand): one workgroup per row, 4 independent loads in flight per
 // lane; M is the pseudo-inverse stored in fp32 (preconditioner data: half the bytes, still an exactly symmetric
 // operator because symmetric entries round identically), accumulation in fp64, fixed reduction tree.
-__global__ __launch_bounds__(256) void k_dense_mv(int n, const float* __restrict__ M, const double* __restrict__ b,
+__global__ __launch_bounds__(256) void k_dense_mv(int n, int ncol, const float* __restrict__ M, const double* __restrict__ b,
                                                   double* __restrict__ y) {
-    __shared__ double part[4];
+    // one workgroup per row; all right-hand-side columns (<= KNP_MAX_SYS) share one pass over the fp32 row
+    __shared__ double part[4][KNP_MAX_SYS];
     const int row = blockIdx.x;
-    b += (int64_t)blockIdx.y * n;
-    y += (int64_t)blockIdx.y * n;
     const float* __restrict__ Mr = M + (int64_t)row * n;
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-    int k = threadIdx.x;
-    for (; k + 768 < n; k += 1024) {
-        const float m0 = Mr[k], m1 = Mr[k + 256], m2 = Mr[k + 512], m3 = Mr[k + 768];
-        s0 = fma((double)m0, b[k], s0);
-        s1 = fma((double)m1, b[k + 256], s1);
-        s2 = fma((double)m2, b[k + 512], s2);
-        s3 = fma((double)m3, b[k + 768], s3);
-    }
-    for (; k < n; k += 256) s0 = fma((double)Mr[k], b[k], s0);
-    double s = (s0 + s1) + (s2 + s3);
+    double s[KNP_MAX_SYS];
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    for (int c = 0; c < KNP_MAX_SYS; ++c) s[c] = 0.0;
+    for (int k = threadIdx.x; k < n; k += 256) {
+        const double m = (double)Mr[k];
+#pragma unroll
+        for (int c = 0; c < KNP_MAX_SYS; ++c)
+            if (c < ncol) s[c] = fma(m, b[(int64_t)c * n + k], s[c]);
+    }
+#pragma unroll
+    for (int c = 0; c < KNP_MAX_SYS; ++c) {
+        if (c >= ncol) break;
+        double v = s[c];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6][c] = v;
+    }
     __syncthreads();
-    if (threadIdx.x == 0) y[row] = (part[0] + part[1]) + (part[2] + part[3]);
+    if ((int)threadIdx.x < ncol) y[(int64_t)threadIdx.x * n + row] = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
 }
 
 // rc[v] = sum over the DG dofs mapped to conforming dof v (CSR list, fixed order -> deterministic)
@@ -219,13 +281,7 @@ static void smooth(knp_ctx* c, AmgLevel& L, bool zero_guess) {
         hipLaunchKernelGGL(k_cheb_first, GRIDX(g), dim3(256), 0, c->stream, L.n, L.dinv, L.b, 1.0 / theta, L.r, L.d0, L.x);
     } else {
         // x lives in L.x; the fused kernel writes the updated iterate to L.d1 (free at this point), then swap
-        const double avg = L.A.nrows ? (double)L.A.nnz / (double)L.A.nrows : 0.0;
-        if (avg <= 12.0)
-            hipLaunchKernelGGL((k_cheb_first_res<1>), GRIDX((L.n + 255) / 256), dim3(256), 0, c->stream, L.A, L.dinv, L.b, L.x, 1.0 / theta, L.r, L.d0, L.d1);
-        else if (avg <= 96.0)
-            hipLaunchKernelGGL((k_cheb_first_res<8>), GRIDX((L.n * 8 + 255) / 256), dim3(256), 0, c->stream, L.A, L.dinv, L.b, L.x, 1.0 / theta, L.r, L.d0, L.d1);
-        else
-            hipLaunchKernelGGL((k_cheb_first_res<64>), GRIDX((L.n * 64 + 255) / 256), dim3(256), 0, c->stream, L.A, L.dinv, L.b, L.x, 1.0 / theta, L.r, L.d0, L.d1);
+        LAUNCH_BY_DENSITY(k_cheb_first_res, L.A, L.A, L.dinv, L.b, L.x, 1.0 / theta, L.r, L.d0, L.d1);
         double* t = L.x; L.x = L.d1; L.d1 = t;
     }
     double* din = L.d0;
@@ -255,7 +311,7 @@ static int amg_vcycle_eager(knp_ctx* c, AmgHierarchy& H) {
         launch_csr<0>(c, L.R, L.r, nullptr, H.levels[l + 1].b);      // b_{l+1} = R r
     }
     AmgLevel& C = H.levels[nl - 1];
-    hipLaunchKernelGGL(k_dense_mv, GRIDX(C.n), dim3(256), 0, c->stream, (int)C.n, (const float*)H.pinv, C.b, C.x);
+    hipLaunchKernelGGL(k_dense_mv, dim3((unsigned)C.n), dim3(256), 0, c->stream, (int)C.n, H.ncol, (const float*)H.pinv, C.b, C.x);
     for (int l = nl - 2; l >= 0; --l) {
         AmgLevel& L = H.levels[l];
         if (L.cheb_degree == 0) {
@@ -316,10 +372,7 @@ int amg_restrict_from_dg(knp_ctx* c, AmgHierarchy& H, const double* r_dg, hipStr
     // and the all-reduce moves the 6.5x shorter level-1 vector (29 k instead of 188 k doubles at r=2).
     if (H.levels.size() > 1 && H.levels[0].cheb_degree == 0) {
         AmgLevel& L = H.levels[0];
-        const double avg = L.R.nrows ? (double)L.R.nnz / (double)L.R.nrows : 0.0;
-        if (avg <= 12.0) hipLaunchKernelGGL((k_csr<0, 1>), GRIDX((L.R.nrows + 255) / 256), dim3(256), 0, st, L.R, (const double*)L.b, (const double*)nullptr, H.levels[1].b);
-        else if (avg <= 96.0) hipLaunchKernelGGL((k_csr<0, 8>), GRIDX((L.R.nrows * 8 + 255) / 256), dim3(256), 0, st, L.R, (const double*)L.b, (const double*)nullptr, H.levels[1].b);
-        else hipLaunchKernelGGL((k_csr<0, 64>), GRIDX((L.R.nrows * 64 + 255) / 256), dim3(256), 0, st, L.R, (const double*)L.b, (const double*)nullptr, H.levels[1].b);
+        launch_csr_on<0>(c, L.R, L.b, nullptr, H.levels[1].b, st);
         if (c->dist) return allreduce_red(c, H.levels[1].b, (int)(H.levels[1].n * H.ncol));
         return 0;
     }
