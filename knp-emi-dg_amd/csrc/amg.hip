@@ -223,31 +223,45 @@ void launch_cheb_step(knp_ctx* c, const CsrDev& A, const double* dinv, const dou
 // dense y = M b on the coarsest level (n up to a few thousand): one workgroup per row, 4 independent loads in flight per
 // lane; M is the pseudo-inverse stored in fp32 (preconditioner data: half the bytes, still an exactly symmetric
 // operator because symmetric entries round identically), accumulation in fp64, fixed reduction tree.
-__global__ __launch_bounds__(256) void k_dense_mv(int n, int ncol, const float* __restrict__ M, const double* __restrict__ b,
+template <int NC>
+__global__ __launch_bounds__(256) void k_dense_mv(int n, const float* __restrict__ M, const double* __restrict__ b,
                                                   double* __restrict__ y) {
-    // one workgroup per row; all right-hand-side columns (<= KNP_MAX_SYS) share one pass over the fp32 row
-    __shared__ double part[4][KNP_MAX_SYS];
+    // one workgroup per row, 4 independent row segments in flight per lane; NC right-hand-side columns share the pass over the fp32
+    // row (further columns along grid.y)
+    __shared__ double part[4][NC];
     const int row = blockIdx.x;
+    b += (int64_t)blockIdx.y * NC * n;
+    y += (int64_t)blockIdx.y * NC * n;
     const float* __restrict__ Mr = M + (int64_t)row * n;
-    double s[KNP_MAX_SYS];
+    double s[4][NC];
 #pragma unroll
-    for (int c = 0; c < KNP_MAX_SYS; ++c) s[c] = 0.0;
-    for (int k = threadIdx.x; k < n; k += 256) {
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int j = 0; j < NC; ++j) s[u][j] = 0.0;
+    int k = threadIdx.x;
+    for (; k + 768 < n; k += 1024) {
+        float m[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) m[u] = Mr[k + 256 * u];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int j = 0; j < NC; ++j) s[u][j] = fma((double)m[u], b[(int64_t)j * n + k + 256 * u], s[u][j]);
+    }
+    for (; k < n; k += 256) {
         const double m = (double)Mr[k];
 #pragma unroll
-        for (int c = 0; c < KNP_MAX_SYS; ++c)
-            if (c < ncol) s[c] = fma(m, b[(int64_t)c * n + k], s[c]);
+        for (int j = 0; j < NC; ++j) s[0][j] = fma(m, b[(int64_t)j * n + k], s[0][j]);
     }
 #pragma unroll
-    for (int c = 0; c < KNP_MAX_SYS; ++c) {
-        if (c >= ncol) break;
-        double v = s[c];
+    for (int j = 0; j < NC; ++j) {
+        double v = (s[0][j] + s[1][j]) + (s[2][j] + s[3][j]);
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-        if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6][c] = v;
+        if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6][j] = v;
     }
     __syncthreads();
-    if ((int)threadIdx.x < ncol) y[(int64_t)threadIdx.x * n + row] = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+    if ((int)threadIdx.x < NC) y[(int64_t)threadIdx.x * n + row] = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
 }
 
 // rc[v] = sum over the DG dofs mapped to conforming dof v (CSR list, fixed order -> deterministic)
@@ -311,7 +325,10 @@ static int amg_vcycle_eager(knp_ctx* c, AmgHierarchy& H) {
         launch_csr<0>(c, L.R, L.r, nullptr, H.levels[l + 1].b);      // b_{l+1} = R r
     }
     AmgLevel& C = H.levels[nl - 1];
-    hipLaunchKernelGGL(k_dense_mv, dim3((unsigned)C.n), dim3(256), 0, c->stream, (int)C.n, H.ncol, (const float*)H.pinv, C.b, C.x);
+    if (H.ncol % 2 == 0)
+        hipLaunchKernelGGL(k_dense_mv<2>, dim3((unsigned)C.n, (unsigned)(H.ncol / 2)), dim3(256), 0, c->stream, (int)C.n, (const float*)H.pinv, C.b, C.x);
+    else
+        hipLaunchKernelGGL(k_dense_mv<1>, dim3((unsigned)C.n, (unsigned)H.ncol), dim3(256), 0, c->stream, (int)C.n, (const float*)H.pinv, C.b, C.x);
     for (int l = nl - 2; l >= 0; --l) {
         AmgLevel& L = H.levels[l];
         if (L.cheb_degree == 0) {
