@@ -227,10 +227,12 @@ def main():
     traffic = traffic_emi = None
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-        if pmc.get(emi_name, {}).get("cells_per_launch") == nc_local:
-            traffic_emi = pmc[emi_name]["traffic_bytes"]
-        if pmc.get(knp_name, {}).get("cells_per_launch") == nc_local:
-            traffic = pmc[knp_name]["traffic_bytes"]
+        for key, rec in pmc.items():
+            if isinstance(rec, dict) and rec.get("cells_per_launch") == nc_local:
+                if key.split(":")[0] == emi_name:
+                    traffic_emi = rec["traffic_bytes"]
+                if key.split(":")[0] == knp_name:
+                    traffic = rec["traffic_bytes"]
     except (OSError, ValueError):
         pass
 
