@@ -226,7 +226,7 @@ __device__ __forceinline__ void emi_cell(const MeshDev& m, const CellGeom<D>& K,
 // classed + LDS-staged: the class table and the workgroup's own x / kappa live in LDS, so in-block neighbours
 // (~83 % under the Morton ordering) cost ds_reads instead of per-lane L1 gathers (the texture addresser, not HBM,
 // is what saturates first in the direct variants: TA_BUSY ~75-90 %).
-#define CLS_MAX_LDS 64
+#define CLS_MAX_LDS 32
 template <int D, int BLK>
 __global__ __launch_bounds__(BLK) void k_emi_apply_cls_staged(MeshDev m, const double* __restrict__ x,
                                                               const double* __restrict__ kappa, double* __restrict__ y,
