@@ -36,8 +36,15 @@ def cpu_baseline(resolution=1):
     auxiliary-space operator the GPU applies (block-Jacobi + V-cycle of the product's smoothed-aggregation hierarchy,
     oracle/cpu_precond.py), so that iteration counts are comparable.  Reports assemble time, solve time and iterations separately,
     the three quantities the reference logs per step (solver.py:499-525, 745-784).  kind = "port": FEniCS itself is not
-    installable here; the sparse kernels are scipy's (single-threaded), dense LAPACK may use more cores."""
+    installable here (BASELINE.md section 2); scipy's sparse kernels are single-threaded and BLAS / LAPACK are pinned to one thread (threadpoolctl), so `cores` = 1;
+    `host_cores` records what the box has."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    from threadpoolctl import threadpool_limits
+    with threadpool_limits(limits=1):                 # BLAS / LAPACK pinned to one thread: `cores` = 1 is what really ran
+        return _cpu_baseline_one_core(resolution)
+
+
+def _cpu_baseline_one_core(resolution):
     import scipy.sparse.linalg as spla
     import knpemi_oracle as ko
     import membrane_oracle as mo
@@ -103,7 +110,7 @@ def cpu_baseline(resolution=1):
             "sample": "ONE splitting step on the 4-axon mesh r=%d (%d tets, %d P1-DG DoFs), %.1f s: assemble CSR %.1f s + "
                       "scipy CG rtol 1e-5 (%d its) / GMRES(30) rtol 1e-7 (%s its) %.1f s, preconditioned with the product's "
                       "auxiliary-space AMG hierarchy applied in numpy (its one-off setup, %.1f s, is not in the step), membrane "
-                      "ODEs by LSODA %.1f s; single-threaded scipy / numpy kernels on a %d-core host; CPU restatement, not FEniCS"
+                      "ODEs by LSODA %.1f s; one thread (scipy sparse kernels, BLAS pinned) on a %d-core host; CPU restatement, not FEniCS"
                       % (resolution, m.num_cells(), dofs, step, t_ass_emi + t_ass_knp, it_emi[0], it_knp, t_sol_emi + t_sol_knp,
                          t_setup, t_ode, os.cpu_count() or 0)}
 
