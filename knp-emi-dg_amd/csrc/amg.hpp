@@ -26,6 +26,16 @@ struct AmgHierarchy {
     int64_t ncg = 0;
     int32_t* dg2cg = nullptr;       // [nc*nd] conforming dof of every DG dof
     int32_t *cg_ptr = nullptr, *cg_idx = nullptr;   // CSR list: conforming dof -> DG dofs (owned cells only)
+    // tile-wise restriction (amg.hip: k_restrict_tiles / k_restrict_sum): every tile of consecutive owned cells sums, per conforming
+    // dof it touches (a "slot"), the tile's DG values out of LDS; the slots of one conforming dof are then added in fixed order
+    int tile_cells = 0;
+    int64_t ntiles = 0, nslots = 0;
+    int32_t *tile_off = nullptr;    // [ntiles + 1] first slot of every tile
+    int32_t *slot_ptr = nullptr;    // [nslots + 1] CSR over slot_idx
+    uint16_t* slot_idx = nullptr;   // [nc_owned * nd] tile-local DG dof index, grouped by slot
+    int32_t *part_ptr = nullptr, *part_idx = nullptr;   // CSR: conforming dof -> its slots
+    double* part = nullptr;         // [ncol][nslots] per-tile partial sums
+    int part_cols = 0;
     std::vector<AmgLevel> levels;
     float* pinv = nullptr;          // dense pseudo-inverse of the coarsest level (fp32 storage)
     void* graph_exec = nullptr;     // hipGraphExec_t of one V-cycle (fixed kernel sequence on fixed buffers)
