@@ -27,31 +27,37 @@ struct Fields {
     double* tmp_emi = nullptr;
     double bj_lmax_emi = 0.0;
     int bj_lmax_emi_age = 0;
-    bool have_hist_emi = false, have_hist_knp = false;
+    int nh_emi = 0, nh_knp = 0;            // valid history entries of the extrapolated initial guesses
 };
 
-// x <- 2 x - h ; h <- x (old)      [first == 1: only h <- x]
-__global__ void k_extrapolate_guess(int64_t n, int first, double* __restrict__ x, double* __restrict__ h) {
+// initial guess from the last solutions: nh = number of valid history entries (h1 = previous, h2 = the one before)
+//   nh = 0: h1 <- x;   nh = 1 or order 1: x <- 2 x - h1;   nh = 2 and order 2: x <- 3 x - 3 h1 + h2;   then h2 <- h1, h1 <- x(old)
+__global__ void k_extrapolate_guess(int64_t n, int nh, int order, double* __restrict__ x, double* __restrict__ h1, double* __restrict__ h2) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const double xv = x[i];
-    if (!first) x[i] = 2.0 * xv - h[i];
-    h[i] = xv;
+    const double a = h1[i];
+    if (nh >= 2 && order >= 2) x[i] = 3.0 * (xv - a) + h2[i];
+    else if (nh >= 1) x[i] = 2.0 * xv - a;
+    h2[i] = a;
+    h1[i] = xv;
 }
 
 // The reference starts every Krylov solve from the previous time step's solution (KSP initial guess non-zero, solver.py:444, 701).
-// This path starts from the linear extrapolation 2 x_{k-1} - x_{k-2} of the last two solutions instead (same converged solution,
-// better starting point): at r=2 over 20 steps through the stimulus onset KNP needs 7.4 instead of 9.05 BiCGStab iterations per
-// step and EMI 4.25 instead of 4.55 PCG iterations (-11 % per step).  KNP_EXTRAPOLATE=0 restores the reference's guess.
-static int extrapolate_guess(knp_ctx* c, double* x, double** hist, bool* have, int64_t n, bool emi) {
+// This path starts from an extrapolation of the last solutions instead (same converged solution, better starting point): linear
+// (2 x_{k-1} - x_{k-2}) by default; at r=2 over 20 steps through the stimulus onset KNP needs 7.4 instead of 9.05 BiCGStab iterations
+// per step and EMI 4.25 instead of 4.55 PCG iterations (-11 % per step).  KNP_EXTRAPOLATE=0 restores the reference's guess;
+// KNP_EXTRAPOLATE_ORDER=2 uses three solutions (quadratic).  A state upload invalidates the history.
+static int extrapolate_guess(knp_ctx* c, double* x, double** hist, int* nh, int64_t n, bool emi) {
     // KNP_EXTRAPOLATE = 1: both solves, 2: EMI only, 3: KNP only
     static const int mode = getenv("KNP_EXTRAPOLATE") ? atoi(getenv("KNP_EXTRAPOLATE")) : 1;
+    static const int order = getenv("KNP_EXTRAPOLATE_ORDER") ? atoi(getenv("KNP_EXTRAPOLATE_ORDER")) : 1;
     const bool on = mode == 1 || (mode == 2 && emi) || (mode == 3 && !emi);
     if (!on || c->p.splitting == 2) return 0;
-    if (!*hist) HIPCHK(c, hipMalloc((void**)hist, sizeof(double) * n));
-    hipLaunchKernelGGL(k_extrapolate_guess, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, n, *have ? 0 : 1, x, *hist);
+    if (!*hist) HIPCHK(c, hipMalloc((void**)hist, sizeof(double) * 2 * n));
+    hipLaunchKernelGGL(k_extrapolate_guess, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, n, *nh, order, x, *hist, *hist + n);
     HIPCHK(c, hipGetLastError());
-    *have = true;
+    if (*nh < 2) ++*nh;
     return 0;
 }
 
@@ -345,6 +351,8 @@ int knp_upload(knp_ctx* c, int field, const double* src, int64_t offset, int64_t
     HIPCHK(c, hipStreamSynchronize(c->stream));
     // a caller-supplied state may be far from the one the lagged block-Jacobi inverses were built for
     if (field == KNP_F_C || field == KNP_F_C_ELIM || field == KNP_F_PHI || field == KNP_F_KAPPA) reset_lagged(F(c));
+    if (field == KNP_F_PHI) F(c)->nh_emi = 0;          // a caller-supplied state is not a point of the solution history
+    if (field == KNP_F_C) F(c)->nh_knp = 0;
     return 0;
 }
 
@@ -419,7 +427,7 @@ int knp_emi_solve(knp_ctx* c, double rtol, double atol, int maxit, int check_eve
     if (f->bj_age_emi % (bj_lag > 0 ? bj_lag : 1) == 0) rc = launch_emi_blockjacobi(c, f->f[KNP_F_KAPPA], f->binv_emi);
     ++f->bj_age_emi;
     if (rc) return rc;
-    if ((rc = extrapolate_guess(c, f->f[KNP_F_PHI], &f->hist_emi, &f->have_hist_emi, f->n[KNP_F_PHI], true))) return rc;
+    if ((rc = extrapolate_guess(c, f->f[KNP_F_PHI], &f->hist_emi, &f->nh_emi, f->n[KNP_F_PHI], true))) return rc;
     KrylovVecs kv{};
     kv.x = f->f[KNP_F_PHI]; kv.b = f->f[KNP_F_B_EMI]; kv.coef = f->f[KNP_F_KAPPA]; kv.binv = f->binv_emi;
     kv.r = f->r; kv.z = f->z; kv.p = f->p; kv.w = f->w; kv.rhat = f->rhat; kv.v = f->v; kv.y = f->y;
@@ -456,7 +464,7 @@ int knp_knp_solve(knp_ctx* c, double rtol, double atol, int maxit, int min_it, i
     if (f->bj_age_knp % (bj_lag > 0 ? bj_lag : 1) == 0) rc = launch_knp_blockjacobi(c, f->f[KNP_F_DNPHI], f->binv_knp);
     ++f->bj_age_knp;
     if (rc) return rc;
-    if ((rc = extrapolate_guess(c, f->f[KNP_F_C], &f->hist_knp, &f->have_hist_knp, f->n[KNP_F_C], false))) return rc;
+    if ((rc = extrapolate_guess(c, f->f[KNP_F_C], &f->hist_knp, &f->nh_knp, f->n[KNP_F_C], false))) return rc;
     KrylovVecs kv{};
     kv.x = f->f[KNP_F_C]; kv.b = f->f[KNP_F_B_KNP]; kv.coef = f->f[KNP_F_DNPHI]; kv.binv = f->binv_knp;
     kv.r = f->r; kv.z = f->z; kv.p = f->p; kv.w = f->w; kv.rhat = f->rhat; kv.v = f->v; kv.y = f->y;

@@ -37,6 +37,12 @@ int up_csr(knp_ctx* c, CsrDev& M, int64_t nrows, int64_t ncols, const int32_t* r
 
 void free_csr(CsrDev& M) { hipFree(M.rowptr); hipFree(M.col); hipFree(M.val); M = CsrDev(); }
 
+// rows with up to this many entries on average get 4 lanes (KNP_AMG_G4; 12 = never; 40: -1.3 % per step at r=2 P1, -1 % for P2 at r=1)
+static double g4_limit() {
+    static const double v = getenv("KNP_AMG_G4") ? atof(getenv("KNP_AMG_G4")) : 40.0;
+    return v;
+}
+
 // partial dot products of CSR row `row` with NC vectors x + j * xstride over this lane's entries (lane, lane+G, ...).  The loop is
 // unrolled so that 2 (col, val) pairs x NC gathers are in flight per lane: these kernels are latency-bound (a row has 15..100
 // entries), not bandwidth-bound.  NC = 2 carries both KNP species of a shared hierarchy through ONE pass over the matrix
@@ -114,6 +120,10 @@ __global__ __launch_bounds__(256) void k_csr(CsrDev A, const double* __restrict_
             const dim3 g_((unsigned)(((A).nrows + 255) / 256), gy_);                                                          \
             if (two_) hipLaunchKernelGGL((KERN<1, 2>), g_, dim3(256), 0, c->stream, __VA_ARGS__);                             \
             else hipLaunchKernelGGL((KERN<1, 1>), g_, dim3(256), 0, c->stream, __VA_ARGS__);                                  \
+        } else if (avg_ <= g4_limit()) {                                                                                      \
+            const dim3 g_((unsigned)(((A).nrows * 4 + 255) / 256), gy_);                                                      \
+            if (two_) hipLaunchKernelGGL((KERN<4, 2>), g_, dim3(256), 0, c->stream, __VA_ARGS__);                             \
+            else hipLaunchKernelGGL((KERN<4, 1>), g_, dim3(256), 0, c->stream, __VA_ARGS__);                                  \
         } else if (avg_ <= 96.0) {                                                                                            \
             const dim3 g_((unsigned)(((A).nrows * 8 + 255) / 256), gy_);                                                      \
             if (two_) hipLaunchKernelGGL((KERN<8, 2>), g_, dim3(256), 0, c->stream, __VA_ARGS__);                             \
@@ -138,6 +148,9 @@ template <int MODE> void launch_csr_on(knp_ctx* c, const CsrDev& A, const double
     if (avg <= 12.0) {
         const dim3 g((unsigned)((A.nrows + 255) / 256), gy);
         if (two) CsrKern<MODE>::template launch<1, 2>(c, g, A, x, b, y, st); else CsrKern<MODE>::template launch<1, 1>(c, g, A, x, b, y, st);
+    } else if (avg <= g4_limit()) {
+        const dim3 g((unsigned)((A.nrows * 4 + 255) / 256), gy);
+        if (two) CsrKern<MODE>::template launch<4, 2>(c, g, A, x, b, y, st); else CsrKern<MODE>::template launch<4, 1>(c, g, A, x, b, y, st);
     } else if (avg <= 96.0) {
         const dim3 g((unsigned)((A.nrows * 8 + 255) / 256), gy);
         if (two) CsrKern<MODE>::template launch<8, 2>(c, g, A, x, b, y, st); else CsrKern<MODE>::template launch<8, 1>(c, g, A, x, b, y, st);

@@ -271,7 +271,7 @@ def _scale_rows(A, v):
 
 
 def build_hierarchy(A, theta=0.08, max_coarse=4000, max_levels=12, cheb_degree=2, cheb_lower=0.3, psmooth=2, trunc=0.04,
-                    top_interp=None, top_degree=3, top_lower=0.1, level0_degree=None):
+                    top_interp=None, top_degree=2, top_lower=0.1, level0_degree=None):
     """Smoothed-aggregation hierarchy for an SPD (possibly singular, constants) matrix.
     Each level: A (csr), dinv, rho = spectral radius estimate of D^-1 A, P (csr, to the next level).
     Last level: dense pseudo-inverse.  top_interp: geometric prolongator of the first level (conforming P1 -> P2,
@@ -301,8 +301,9 @@ def build_hierarchy(A, theta=0.08, max_coarse=4000, max_levels=12, cheb_degree=2
         levels.append(lv)
         n = A.shape[0]
         if top_interp is not None and len(levels) == 1:
-            # the conforming-P2 level is smoothed harder (degree 3 on [0.1 rho, rho]): P2 stiffness + mass matrices have a
-            # wider Jacobi-scaled spectrum than P1 (KNP BiCGStab 16 -> 11 iterations at r=1, 32 -> 24 ms/step)
+            # the conforming-P2 level is smoothed on [0.1 rho, rho] (P2 stiffness + mass matrices have a wider Jacobi-scaled
+            # spectrum than P1).  Degree 3 was the best with the assembled applies of round 1; with the matrix-free applies the
+            # V-cycle is 55 % of a P2 step and degree 2 wins: KNP 10.2 -> 11.7 iterations, 11.7 -> 11.3 ms/step at r=1
             lv.cheb_degree = int(os.environ.get("KNP_AMG_TOPDEGREE", top_degree or cheb_degree))
             lv.cheb_lower = float(os.environ.get("KNP_AMG_TOPLOWER", top_lower or cheb_lower))
             P = top_interp.tocsr().astype(np.float64)
