@@ -184,6 +184,7 @@ def main():
         S.step_membrane_models(k); S.solve_for_time_step(k, t); k += 1
     barrier()
     progress("warm-up done")
+    t_ready = time.perf_counter() - t_setup
     t0 = time.perf_counter()
     for _ in range(args.steps):
         ts = time.perf_counter()
@@ -243,6 +244,8 @@ def main():
     except (OSError, ValueError):
         pass
 
+    progress("timed region: %.2f ms/step; a %d-step run of examples/idealized-geometries/run_3D.py:60-62 at this rate + the %.1f s of setup "
+             "above = %.1f s end to end" % (ms_per_step, 200, t_ready, t_ready + 0.2 * ms_per_step))
     if rank == 0:
         out = {
             "metric": "DoF-updates/sec per PDE timestep", "value": dofs * args.steps / elapsed, "unit": "DoF/s",
