@@ -213,6 +213,35 @@ int knp_ctx_create(knp_ctx** out, int device, int dim, int degree, int n_ions, i
     rc |= dev_alloc_copy(c, &m.fflag, fflag.data(), fflag.size());
     rc |= dev_alloc_copy(c, &m.cfacet, cfacet.data(), cfacet.size());
     rc |= dev_alloc_copy(c, &m.mf, mf.data(), mf.size());
+    if (dim == 3 && degree == 1 && nc_owned > 0 && nc < (int64_t(1) << 29)) {
+        // halo-staged applies: per block of 256 consecutive cells, the coupled (SIPG / membrane) neighbours outside the block
+        const int64_t B = KNP_HALO_BLK, nblk = (nc_owned + B - 1) / B;
+        std::vector<int32_t> hcnt(nblk, 0);
+        std::vector<std::vector<int32_t>> lists((size_t)nblk);
+        std::vector<uint16_t> hloc((size_t)nc_owned * 4, 0);
+        int hmax = 0;
+        for (int64_t b = 0; b < nblk; ++b) {
+            auto& L = lists[(size_t)b];
+            for (int64_t k = b * B; k < std::min(nc_owned, (b + 1) * B); ++k)
+                for (int a = 0; a < 4; ++a) {
+                    const uint32_t kind = (fb[k * 4 + a] >> 2) & 3u;
+                    const int64_t nbk = nbr[k * 4 + a];
+                    if (kind >= FK_EXTERIOR || nbk < 0) continue;
+                    if (nbk / B == b) { hloc[k * 4 + a] = (uint16_t)(nbk - b * B); continue; }
+                    hloc[k * 4 + a] = (uint16_t)(B + L.size());
+                    L.push_back((int32_t)(nbk * 4 + (fb[k * 4 + a] & 3u)));
+                }
+            hmax = std::max(hmax, (int)L.size());
+        }
+        const int hs = ((hmax + 7) / 8) * 8;
+        if (hs > 0 && hs <= B) {                                   // one list entry per thread of the block
+            std::vector<int32_t> hsrc((size_t)nblk * hs, -1);
+            for (int64_t b = 0; b < nblk; ++b) std::copy(lists[(size_t)b].begin(), lists[(size_t)b].end(), hsrc.begin() + b * hs);
+            rc |= dev_alloc_copy(c, &m.hb_src, hsrc.data(), hsrc.size());
+            rc |= dev_alloc_copy(c, &m.hb_loc, hloc.data(), hloc.size());
+            m.hb_stride = hs;
+        }
+    }
     if (rc) { g_err = c->err; delete c; return -2; }
 
     Fields* fl = new Fields();
@@ -260,7 +289,9 @@ void knp_ctx_destroy(knp_ctx* c) {
         delete fl;
         g_fields.erase(c);
     }
+    hipFree(c->m.hb_src); hipFree(c->m.hb_loc);
     hipFree(c->m.cls); hipFree(c->m.cls_table); hipFree(c->m.coords); hipFree(c->m.h); hipFree(c->m.cells); hipFree(c->m.nbr); hipFree(c->m.fflag); hipFree(c->m.cfacet); hipFree(c->m.mf);
+    hipFree(c->mat); hipFree(c->nmat4); hipFree(c->dtab);
     hipFree(c->D); hipFree(c->rho); hipFree(c->fsrc); hipFree(c->mms_C); hipFree(c->extra_emi); hipFree(c->extra_knp); hipFree(c->partial); hipFree(c->scal); hipFree(c->status);
     hipFree(c->halo_send_idx); hipFree(c->halo_sendbuf);
     if (c->pinned) hipHostFree(c->pinned);
@@ -288,6 +319,40 @@ int knp_set_params(knp_ctx* c, double C_M, double dt, double Fc, double R, doubl
     }
     if (!(dt > 0.0)) { c->err = "dt must be positive"; return -1; }
     HIPCHK(c, hipMemcpy(c->D, D, sizeof(double) * p.n_ions * c->m.nc, hipMemcpyHostToDevice));
+    c->nmat = 0;
+    if (c->m.dim == 3 && c->degree == 1 && c->m.hb_stride) {
+        // material ids: distinct coefficient tuples (D_0 .. D_{n_ions-1}) over the cells, in order of first appearance
+        const int64_t nc = c->m.nc;
+        const int ni = p.n_ions;
+        std::vector<uint8_t> mat((size_t)nc);
+        std::vector<double> tab((size_t)ni * KNP_MAX_MAT, 0.0);
+        int nm = 0;
+        bool ok = true;
+        for (int64_t k = 0; k < nc && ok; ++k) {
+            int id = -1;
+            for (int q = nm - 1; q >= 0 && id < 0; --q) {           // neighbours in the cell order mostly share the material: newest first
+                bool same = true;
+                for (int i = 0; i < ni && same; ++i) same = tab[(size_t)i * KNP_MAX_MAT + q] == D[(int64_t)i * nc + k];
+                if (same) id = q;
+            }
+            if (id < 0) {
+                if (nm == KNP_MAX_MAT) { ok = false; break; }
+                for (int i = 0; i < ni; ++i) tab[(size_t)i * KNP_MAX_MAT + nm] = D[(int64_t)i * nc + k];
+                id = nm++;
+            }
+            mat[k] = (uint8_t)id;
+        }
+        if (ok) {
+            if (!c->mat) HIPCHK(c, hipMalloc((void**)&c->mat, (size_t)nc));
+            if (!c->nmat4) HIPCHK(c, hipMalloc((void**)&c->nmat4, (size_t)nc * 4));
+            if (!c->dtab) HIPCHK(c, hipMalloc((void**)&c->dtab, sizeof(double) * KNP_MAX_IONS * KNP_MAX_MAT));
+            HIPCHK(c, hipMemcpy(c->mat, mat.data(), (size_t)nc, hipMemcpyHostToDevice));
+            HIPCHK(c, hipMemcpy(c->dtab, tab.data(), sizeof(double) * tab.size(), hipMemcpyHostToDevice));
+            c->nmat = nm;
+            int rcm = launch_neighbour_materials(c);
+            if (rcm) return rcm;
+        }
+    }
     if (rho) HIPCHK(c, hipMemcpy(c->rho, rho, sizeof(double) * c->m.nc, hipMemcpyHostToDevice));
     else HIPCHK(c, hipMemset(c->rho, 0, sizeof(double) * c->m.nc));
     if (fsrc) {

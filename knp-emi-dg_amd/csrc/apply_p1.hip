@@ -668,6 +668,385 @@ __global__ __launch_bounds__(BLK) void k_knp_apply_cls_staged(MeshDev m, const d
     for (int k = 0; k < NS; ++k) store_nodal<D>(yout + (int64_t)k * m.nc * NV, c, y[k]);
 }
 
+// ---- halo-staged persistent variants (3D P1, structured meshes) -------------------------------------------------------
+// Measured on the staged kernels above (tools/pmc_apply.sh, profiles/r02_pmc_apply_halo.md): 60 % of the wave cycles are
+// spent parked, and a probe with the facet arithmetic removed still takes 85 % of the time -- the kernels are bound by their
+// memory phase, which is a CHAIN of dependent round trips (topology -> neighbour rows, inside the facet loop for the 17 %
+// of the facets whose neighbour lies outside the workgroup's 256 cells).  Here
+//   * the out-of-block neighbours of every 256-cell block are known in advance (MeshDev::hb_src / hb_loc, built once from
+//     the topology): own records and halo records are loaded before the single barrier and the facet loop reads LDS only
+//     (one uniform path, the facet-vertex permutation folded into the per-lane LDS address, no register selects);
+//   * a workgroup walks several blocks of its XCD's chunk and fetches the NEXT block's halo list while it works on the
+//     current one, so that a block's loads -- own and halo -- are one round trip;
+//   * LDS is component-major ([component][entry]: consecutive cells on consecutive banks; the row-major layout of the
+//     staged kernels spends 70 % of its LDS cycles in bank conflicts), the class table has an odd stride;
+//   * D is read through a material table when the cells carry few distinct coefficient tuples (knp_set_params).
+// LDS entries [0,256) = the block's cells, [256, 256+nh) = halo entries (one per out-of-block coupled facet).
+#define HALO_FT 24       // per-class facet record kept in LDS: 4 x (L[4], sqrt(G_ii), 2/(h+h'))
+#define HALO_FTS 25      // its LDS stride (odd: lanes of different classes land on different banks)
+
+// vol + Gram matrix of the cell's class, straight from the (L1/L2-resident) table into registers
+__device__ __forceinline__ void load_class_gram(const double* __restrict__ table, unsigned cls, CellGeom<3>& K) {
+    const double* rec = table + (size_t)cls * KNP_CLS_STRIDE;
+    K.vol = rec[0];
+    int q = 1;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = a; b < 4; ++b) { K.G[a][b] = rec[q]; K.G[b][a] = rec[q]; ++q; }
+}
+
+// the blocks of one workgroup: XCD x (= blockIdx.x & 7, round-robin dispatch) owns one contiguous eighth of the block range,
+// its workgroups take every nslot-th block of it
+struct HaloWalk {
+    int64_t b_lo, rb, last, nslot;
+    __device__ __forceinline__ HaloWalk(const MeshDev& m) {
+        b_lo = m.c_begin / KNP_HALO_BLK;
+        const int64_t nblk = (m.c_end - 1) / KNP_HALO_BLK - b_lo + 1;
+        const int64_t chunk = (nblk + 7) >> 3;
+        const int64_t first = (int64_t)(blockIdx.x & 7u) * chunk;
+        last = first + chunk < nblk ? first + chunk : nblk;
+        nslot = gridDim.x >> 3;
+        rb = first + (blockIdx.x >> 3);
+    }
+};
+
+// s_D: MAT ? [NS][KNP_MAX_MAT] coefficient table indexed by the neighbour's material id dsel : [NS][ent] staged values
+template <int NS, bool MAT, int I>
+__device__ __forceinline__ void knp_facet_halo(const CellGeom<3>& K, uint32_t flags, unsigned loc, unsigned dsel, const double (*xv)[4],
+                                               const double* gp, const double* Dk, const KnpArgs& ka, const lds_double* s_x,
+                                               const lds_double* s_g, const lds_double* s_D, const lds_double* ft, unsigned ent,
+                                               double (*y)[4]) {
+    constexpr int D = 3, NV = 4;
+    const uint32_t fb = (flags >> (8 * I)) & 0xffu;
+    if (((fb >> 2) & 3u) != FK_SIPG) return;
+    const unsigned j = fb & 3u;
+    double L[NV];
+#pragma unroll
+    for (int a = 0; a < NV; ++a) L[a] = ft[6 * I + a];
+    const double sqG = ft[6 * I + 4], hinv = ft[6 * I + 5];
+    const double gp_nb = s_g[loc < KNP_HALO_BLK ? j * KNP_HALO_BLK + loc : loc + (KNP_HALO_BLK * NV - KNP_HALO_BLK)];
+    const double rLi = fast_rcp(L[I]);
+    const double DV = (double)D * K.vol;
+    const double up_own = fmax(-gp[I], 0.0) * DV;
+    const double up_nb = fmax(-gp_nb, 0.0) * DV * (-L[I]);
+    const double penA = ka.tau * hinv * sqG * DV;
+    const double gr = K.G[I][I] * rLi;
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+        const lds_double* xl = s_x + (unsigned)k * NV * ent + loc;                  // component-major: [k][a][entry]
+        const double xap = xl[j * ent];
+        double xf[D];
+#pragma unroll
+        for (int mm = 0; mm < D; ++mm) xf[mm] = xl[(mm + (mm >= (int)j ? 1 : 0)) * ent];
+        const double Dn = MAT ? s_D[(unsigned)k * KNP_MAX_MAT + dsel] : s_D[(unsigned)k * ent + loc];
+        double s_own = 0.0;
+#pragma unroll
+        for (int a = 0; a < NV; ++a) s_own = fma(xv[k][a], K.G[a][I], s_own);
+        double s_nb = xap * gr;
+#pragma unroll
+        for (int mm = 0; mm < D; ++mm) s_nb = fma(xf[mm], fma(-L[mm + (mm >= I)], gr, K.G[mm + (mm >= I)][I]), s_nb);
+        const double zp = ka.z[k] * ka.psi;
+        const double c_own = penA * Dk[k] - zp * Dk[k] * up_own;
+        const double c_nb = penA * Dn - zp * Dn * up_nb;
+        double sdu = 0.0, w[D], sw = 0.0;
+#pragma unroll
+        for (int mm = 0; mm < D; ++mm) {
+            const double xo = xv[k][mm + (mm >= I)];
+            sdu += xo - xf[mm];
+            w[mm] = fma(c_own, xo, -c_nb * xf[mm]);
+            sw += w[mm];
+        }
+        const double t1 = 0.5 * K.vol * fma(Dk[k], s_own, Dn * s_nb);
+        const double t2 = 0.5 * Dk[k] * K.vol * sdu;
+#pragma unroll
+        for (int a = 0; a < NV; ++a) y[k][a] = fma(K.G[a][I], t2, y[k][a]);
+#pragma unroll
+        for (int mm = 0; mm < D; ++mm)
+            y[k][mm + (mm >= I)] += t1 + FacetConst<D>::mass * (sw + w[mm]);
+    }
+}
+
+// PROBE (tools/apply_only.py experiments only): 1 = memory phase without the facet arithmetic, 2 = additionally without halo loads
+template <int NS, bool MAT, int PROBE = 0>
+__global__ __launch_bounds__(KNP_HALO_BLK) void k_knp_apply_halo(MeshDev m, const double* __restrict__ x,
+                                                                 const double* __restrict__ gphi,
+                                                                 const double* __restrict__ Dall, double* __restrict__ yout,
+                                                                 KnpArgs ka, unsigned ent, const uint8_t* __restrict__ mat,
+                                                                 const uint8_t* __restrict__ nmat4, const double* __restrict__ dtab) {
+    constexpr int NV = 4, BLK = KNP_HALO_BLK;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double* s_x = smem;                                   // [NS][4][ent]
+    double* s_g = s_x + NS * ent * NV;                    // [4][256] own gphi, then [ent - 256] the halo's one component
+    double* s_D = s_g + BLK * NV + (ent - BLK);           // MAT: [NS][KNP_MAX_MAT] coefficient table ; else [NS][ent]
+    double* s_ft = s_D + (MAT ? NS * KNP_MAX_MAT : NS * ent);   // [ncls][25]
+    const unsigned t = threadIdx.x;
+    HaloWalk w(m);
+    if (w.rb >= w.last) return;
+    for (int i = t; i < m.ncls * HALO_FT; i += BLK) s_ft[(i / HALO_FT) * HALO_FTS + (i % HALO_FT)] = m.cls_table[(i / HALO_FT) * KNP_CLS_STRIDE + 11 + (i % HALO_FT)];
+    if (MAT && t < NS * KNP_MAX_MAT) s_D[t] = dtab[t];
+    const bool hl = (int)t < m.hb_stride && PROBE != 2;
+    int src = hl ? m.hb_src[(w.b_lo + w.rb) * m.hb_stride + t] : -1;
+    for (; w.rb < w.last; w.rb += w.nslot) {
+        const int64_t c = (w.b_lo + w.rb) * BLK + t;
+        const bool valid = c >= m.c_begin && c < m.c_end;
+        const bool stage = c < m.nc;
+        double xv[NS][NV], y[NS][NV], gp[NV], Dk[NS];
+        if (stage) {
+            load_nodal<3>(gphi, c, gp);
+#pragma unroll
+            for (int k = 0; k < NS; ++k) {
+                load_nodal<3>(x + (int64_t)k * m.nc * NV, c, xv[k]);
+                if (!MAT) Dk[k] = Dall[(int64_t)k * m.nc + c];
+            }
+        }
+        // this thread's halo entry: the list was fetched while the previous block was being worked on
+        double2 hq[NS][2];
+        double hg = 0.0, hD[NS];
+        if (src >= 0) {
+            const int64_t Kp = src >> 2;
+            hg = gphi[Kp * NV + (src & 3)];
+#pragma unroll
+            for (int k = 0; k < NS; ++k) {
+                const double2* px = reinterpret_cast<const double2*>(x + (int64_t)k * m.nc * NV + Kp * NV);
+                hq[k][0] = px[0];
+                hq[k][1] = px[1];
+                if (!MAT) hD[k] = Dall[(int64_t)k * m.nc + Kp];
+            }
+        }
+        const int src_next = (hl && w.rb + w.nslot < w.last) ? m.hb_src[(w.b_lo + w.rb + w.nslot) * m.hb_stride + t] : -1;
+        uint32_t flags = 0, nm = 0;
+        unsigned cls = 0, mymat = 0;
+        uint2 lw = make_uint2(0u, 0u);
+        CellGeom<3> K;
+        if (valid) {
+            flags = m.fflag[c];
+            cls = m.cls[c];
+            lw = *reinterpret_cast<const uint2*>(m.hb_loc + c * NV);
+            if (MAT) {
+                mymat = mat[c];
+                nm = *reinterpret_cast<const uint32_t*>(nmat4 + c * NV);
+            }
+            load_class_gram(m.cls_table, cls, K);
+        }
+        if (stage) {
+#pragma unroll
+            for (int k = 0; k < NS; ++k) {
+                if (!MAT) s_D[(unsigned)k * ent + t] = Dk[k];
+#pragma unroll
+                for (int a = 0; a < NV; ++a) s_x[((unsigned)k * NV + a) * ent + t] = xv[k][a];
+            }
+#pragma unroll
+            for (int a = 0; a < NV; ++a) s_g[a * BLK + t] = gp[a];
+        }
+        if (src >= 0) {
+            s_g[BLK * NV + t] = hg;
+#pragma unroll
+            for (int k = 0; k < NS; ++k) {
+                double* dst = s_x + (unsigned)k * NV * ent + BLK + t;
+                dst[0] = hq[k][0].x; dst[ent] = hq[k][0].y; dst[2 * ent] = hq[k][1].x; dst[3 * ent] = hq[k][1].y;
+                if (!MAT) s_D[(unsigned)k * ent + BLK + t] = hD[k];
+            }
+        }
+        __syncthreads();
+        if (valid) {
+            if (MAT) {
+#pragma unroll
+                for (int k = 0; k < NS; ++k) Dk[k] = TO_LDS(s_D)[k * KNP_MAX_MAT + mymat];
+            }
+            const lds_double* ft = TO_LDS(s_ft) + cls * HALO_FTS;
+            const double mw = ka.inv_dt * K.vol / 20.0;
+#pragma unroll
+            for (int k = 0; k < NS; ++k) {
+                double sx = 0.0;
+#pragma unroll
+                for (int a = 0; a < NV; ++a) sx += xv[k][a];
+                const double drift = ka.z[k] * ka.psi * Dk[k] * K.vol * sx / (double)NV;
+                const double dv = Dk[k] * K.vol;
+#pragma unroll
+                for (int a = 0; a < NV; ++a) {
+                    double s = 0.0;
+#pragma unroll
+                    for (int bb = 0; bb < NV; ++bb) s = fma(K.G[a][bb], xv[k][bb], s);
+                    y[k][a] = fma(mw, sx + xv[k][a], fma(dv, s, drift * gp[a]));
+                }
+            }
+            if (PROBE >= 1) {
+#pragma unroll
+                for (int k = 0; k < NS; ++k) {
+                    y[k][0] += TO_LDS(s_x)[(unsigned)k * NV * ent + (lw.x & 0xffffu)] + TO_LDS(s_x)[(unsigned)k * NV * ent + (lw.x >> 16)];
+                    y[k][1] += TO_LDS(s_x)[(unsigned)k * NV * ent + (lw.y & 0xffffu)] + TO_LDS(s_g)[(lw.y >> 16)] + ft[flags & 7u] + (double)nm;
+                }
+            } else {
+                knp_facet_halo<NS, MAT, 0>(K, flags, lw.x & 0xffffu, nm & 0xffu, xv, gp, Dk, ka, TO_LDS(s_x), TO_LDS(s_g), TO_LDS(s_D), ft, ent, y);
+                knp_facet_halo<NS, MAT, 1>(K, flags, lw.x >> 16, (nm >> 8) & 0xffu, xv, gp, Dk, ka, TO_LDS(s_x), TO_LDS(s_g), TO_LDS(s_D), ft, ent, y);
+                knp_facet_halo<NS, MAT, 2>(K, flags, lw.y & 0xffffu, (nm >> 16) & 0xffu, xv, gp, Dk, ka, TO_LDS(s_x), TO_LDS(s_g), TO_LDS(s_D), ft, ent, y);
+                knp_facet_halo<NS, MAT, 3>(K, flags, lw.y >> 16, nm >> 24, xv, gp, Dk, ka, TO_LDS(s_x), TO_LDS(s_g), TO_LDS(s_D), ft, ent, y);
+            }
+#pragma unroll
+            for (int k = 0; k < NS; ++k) store_nodal<3>(yout + (int64_t)k * m.nc * NV, c, y[k]);
+        }
+        __syncthreads();                   // the next block overwrites the staging
+        src = src_next;
+    }
+}
+
+// material id of the neighbour behind every facet (once per knp_set_params)
+__global__ void k_neighbour_materials(int64_t nc, const int32_t* __restrict__ nbr, const uint8_t* __restrict__ mat, uint8_t* __restrict__ nmat4) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nc * 4) return;
+    const int32_t nb = nbr[i];
+    nmat4[i] = nb >= 0 ? mat[nb] : (uint8_t)0;
+}
+
+template <int I>
+__device__ __forceinline__ void emi_facet_halo(const CellGeom<3>& K, uint32_t flags, unsigned loc, const double* xv, const double* kv,
+                                               double C_phi, double tau, const lds_double* s_x, const lds_double* s_k,
+                                               const lds_double* ft, unsigned ent, double* y) {
+    constexpr int D = 3, NV = 4;
+    const uint32_t fb = (flags >> (8 * I)) & 0xffu;
+    const uint32_t kind = (fb >> 2) & 3u;
+    if (kind >= FK_EXTERIOR) return;
+    const unsigned j = fb & 3u;
+    const lds_double* xl = s_x + loc;                         // component-major: [a][entry]
+    const lds_double* kl = s_k + loc;
+    double xf[D], knf[D];
+    const double xap = xl[j * ent];
+#pragma unroll
+    for (int mm = 0; mm < D; ++mm) {
+        const unsigned o = (mm + (mm >= (int)j ? 1 : 0)) * ent;
+        xf[mm] = xl[o];
+        knf[mm] = kl[o];
+    }
+    double du[D], sdu = 0.0;
+#pragma unroll
+    for (int mm = 0; mm < D; ++mm) {
+        du[mm] = xv[mm + (mm >= I)] - xf[mm];
+        sdu += du[mm];
+    }
+    const double DV = (double)D * K.vol;
+    const double sqG = ft[6 * I + 4];
+    if (kind == FK_MEMBRANE) {
+        const double w = C_phi * sqG * DV * FacetConst<D>::mass;
+#pragma unroll
+        for (int mm = 0; mm < D; ++mm) y[mm + (mm >= I)] = fma(w, sdu + du[mm], y[mm + (mm >= I)]);
+        return;
+    }
+    double L[NV];
+#pragma unroll
+    for (int a = 0; a < NV; ++a) L[a] = ft[6 * I + a];
+    const double gr = K.G[I][I] * fast_rcp(L[I]);
+    double s_own = 0.0, s_nb = xap * gr;
+#pragma unroll
+    for (int a = 0; a < NV; ++a) s_own = fma(xv[a], K.G[a][I], s_own);
+#pragma unroll
+    for (int mm = 0; mm < D; ++mm) s_nb = fma(xf[mm], fma(-L[mm + (mm >= I)], gr, K.G[mm + (mm >= I)][I]), s_nb);
+    double kf[D], sk = 0.0, skn = 0.0, q = 0.0;
+#pragma unroll
+    for (int mm = 0; mm < D; ++mm) {
+        kf[mm] = kv[mm + (mm >= I)];
+        sk += kf[mm];
+        skn += knf[mm];
+        q = fma(kf[mm], sdu + du[mm], q);
+    }
+    const double hm = 0.5 * DV * FacetConst<D>::mass;
+    q *= hm;
+#pragma unroll
+    for (int a = 0; a < NV; ++a) y[a] = fma(K.G[a][I], q, y[a]);
+    const double pw = tau * ft[6 * I + 5] * sqG * DV * FacetConst<D>::trip;
+    double kb[D], skb = 0.0, skd = 0.0;
+#pragma unroll
+    for (int mm = 0; mm < D; ++mm) {
+        kb[mm] = 0.5 * (kf[mm] + knf[mm]);
+        skb += kb[mm];
+        skd = fma(kb[mm], du[mm], skd);
+    }
+    const double base = fma(skb, sdu, skd);
+#pragma unroll
+    for (int mm = 0; mm < D; ++mm) {
+        const double t1 = hm * fma(s_own, sk + kf[mm], s_nb * (skn + knf[mm]));
+        const double t3 = pw * (base + fma(kb[mm], sdu, du[mm] * fma(2.0, kb[mm], skb)));
+        y[mm + (mm >= I)] += t1 + t3;
+    }
+}
+
+__global__ __launch_bounds__(KNP_HALO_BLK) void k_emi_apply_halo(MeshDev m, const double* __restrict__ x,
+                                                                 const double* __restrict__ kappa, double* __restrict__ y,
+                                                                 double C_phi, double tau, unsigned ent) {
+    constexpr int NV = 4, BLK = KNP_HALO_BLK;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double* s_x = smem;                    // [4][ent]
+    double* s_k = s_x + ent * NV;          // [4][ent]
+    double* s_ft = s_k + ent * NV;         // [ncls][25]
+    const unsigned t = threadIdx.x;
+    HaloWalk w(m);
+    if (w.rb >= w.last) return;
+    for (int i = t; i < m.ncls * HALO_FT; i += BLK) s_ft[(i / HALO_FT) * HALO_FTS + (i % HALO_FT)] = m.cls_table[(i / HALO_FT) * KNP_CLS_STRIDE + 11 + (i % HALO_FT)];
+    const bool hl = (int)t < m.hb_stride;
+    int src = hl ? m.hb_src[(w.b_lo + w.rb) * m.hb_stride + t] : -1;
+    for (; w.rb < w.last; w.rb += w.nslot) {
+        const int64_t c = (w.b_lo + w.rb) * BLK + t;
+        const bool valid = c >= m.c_begin && c < m.c_end;
+        const bool stage = c < m.nc;
+        double xv[NV], kv[NV], yv[NV];
+        if (stage) {
+            load_nodal<3>(x, c, xv);
+            load_nodal<3>(kappa, c, kv);
+        }
+        double2 hx[2], hk[2];
+        if (src >= 0) {
+            const int64_t Kp = src >> 2;
+            const double2* px = reinterpret_cast<const double2*>(x + Kp * NV);
+            const double2* pk = reinterpret_cast<const double2*>(kappa + Kp * NV);
+            hx[0] = px[0]; hx[1] = px[1];
+            hk[0] = pk[0]; hk[1] = pk[1];
+        }
+        const int src_next = (hl && w.rb + w.nslot < w.last) ? m.hb_src[(w.b_lo + w.rb + w.nslot) * m.hb_stride + t] : -1;
+        uint32_t flags = 0;
+        unsigned cls = 0;
+        uint2 lw = make_uint2(0u, 0u);
+        CellGeom<3> K;
+        if (valid) {
+            flags = m.fflag[c];
+            cls = m.cls[c];
+            lw = *reinterpret_cast<const uint2*>(m.hb_loc + c * NV);
+            load_class_gram(m.cls_table, cls, K);
+        }
+        if (stage) {
+#pragma unroll
+            for (int a = 0; a < NV; ++a) { s_x[a * ent + t] = xv[a]; s_k[a * ent + t] = kv[a]; }
+        }
+        if (src >= 0) {
+            double* dx = s_x + BLK + t;
+            double* dk = s_k + BLK + t;
+            dx[0] = hx[0].x; dx[ent] = hx[0].y; dx[2 * ent] = hx[1].x; dx[3 * ent] = hx[1].y;
+            dk[0] = hk[0].x; dk[ent] = hk[0].y; dk[2 * ent] = hk[1].x; dk[3 * ent] = hk[1].y;
+        }
+        __syncthreads();
+        if (valid) {
+            const lds_double* ft = TO_LDS(s_ft) + cls * HALO_FTS;
+            double kbar = 0.0;
+#pragma unroll
+            for (int a = 0; a < NV; ++a) kbar += kv[a];
+            kbar *= K.vol / (double)NV;
+#pragma unroll
+            for (int a = 0; a < NV; ++a) {
+                double sa = 0.0;
+#pragma unroll
+                for (int bb = 0; bb < NV; ++bb) sa = fma(K.G[a][bb], xv[bb], sa);
+                yv[a] = kbar * sa;
+            }
+            emi_facet_halo<0>(K, flags, lw.x & 0xffffu, xv, kv, C_phi, tau, TO_LDS(s_x), TO_LDS(s_k), ft, ent, yv);
+            emi_facet_halo<1>(K, flags, lw.x >> 16, xv, kv, C_phi, tau, TO_LDS(s_x), TO_LDS(s_k), ft, ent, yv);
+            emi_facet_halo<2>(K, flags, lw.y & 0xffffu, xv, kv, C_phi, tau, TO_LDS(s_x), TO_LDS(s_k), ft, ent, yv);
+            emi_facet_halo<3>(K, flags, lw.y >> 16, xv, kv, C_phi, tau, TO_LDS(s_x), TO_LDS(s_k), ft, ent, yv);
+            store_nodal<3>(y, c, yv);
+        }
+        __syncthreads();
+        src = src_next;
+    }
+}
+
 // one species per launch dimension (setup only, once per KNP solve)
 template <int D>
 __global__ __launch_bounds__(KNP_BLOCK) void k_knp_blockjacobi(MeshDev m, const double* __restrict__ gphi,
@@ -768,11 +1147,46 @@ int launch_knp_apply(knp_ctx* c, const double* x, const double* gphi, double* y)
     return knp_apply_impl(c, x, gphi, y);
 }
 
+// halo-staged kernels: usable when the class and halo tables exist and the block's LDS footprint stays below 64 KB;
+// KNP_APPLY_HALO=0 selects the previous staged kernels (A/B runs)
+static bool halo_enabled() {
+    static const bool on = !(getenv("KNP_APPLY_HALO") && atoi(getenv("KNP_APPLY_HALO")) == 0);
+    return on;
+}
+static unsigned halo_entries(const knp_ctx* c) { return (unsigned)(KNP_HALO_BLK + c->m.hb_stride); }
+// persistent grid: as many workgroups as fit on the chip at once (a multiple of 8: one eighth per XCD), at most one per block;
+// KNP_HALO_WG_PER_CU overrides the occupancy query (tuning)
+template <typename KernelT> static dim3 halo_grid(const knp_ctx* c, KernelT kernel, size_t lds) {
+    const int64_t nb = (c->m.c_end - 1) / KNP_HALO_BLK - c->m.c_begin / KNP_HALO_BLK + 1;
+    static int ncu = 0;
+    if (!ncu) {
+        hipDeviceProp_t prop;
+        ncu = (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    }
+    static const int forced = getenv("KNP_HALO_WG_PER_CU") ? atoi(getenv("KNP_HALO_WG_PER_CU")) : 0;
+    int per_cu = forced;
+    if (per_cu <= 0 && hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, KNP_HALO_BLK, lds) != hipSuccess) per_cu = 2;
+    if (per_cu < 1) per_cu = 1;
+    int64_t g = std::min<int64_t>(((nb + 7) / 8) * 8, (int64_t)per_cu * ncu);
+    g = std::max<int64_t>(8, (g / 8) * 8);
+    return dim3((unsigned)g);
+}
+
 static int emi_apply_impl(knp_ctx* c, const double* x, const double* kappa, double* y) {
     if (c->degree != 1) return p2_assembled() ? tab_apply(c, 0, x, y) : p2_emi_apply(c, x, kappa, y);
     const int64_t n = c->m.c_end - c->m.c_begin;
     if (n <= 0) return 0;
     const dim3 g((unsigned)grid8(n)), b(KNP_BLOCK);
+    if (c->m.cls && c->m.hb_stride && c->m.dim == 3 && halo_enabled()) {
+        const unsigned ent = halo_entries(c);
+        const size_t lds = sizeof(double) * ((size_t)ent * 8 + (size_t)c->m.ncls * HALO_FTS);
+        if (lds <= 65536) {
+            hipLaunchKernelGGL(k_emi_apply_halo, halo_grid(c, k_emi_apply_halo, lds), dim3(KNP_HALO_BLK), lds, c->stream, c->m, x, kappa, y,
+                               c->p.C_phi, c->p.tau_emi, ent);
+            HIPCHK(c, hipGetLastError());
+            return 0;
+        }
+    }
     if (c->m.cls && c->m.dim == 3 && c->m.ncls <= CLS_MAX_LDS)
         hipLaunchKernelGGL((k_emi_apply_cls_staged<3, 256>), g, b, 0, c->stream, c->m, x, kappa, y, c->p.C_phi, c->p.tau_emi);
     else if (c->m.dim == 3)
@@ -798,6 +1212,29 @@ template <int D> static int knp_apply_dispatch(knp_ctx* c, const double* x, cons
     if (n <= 0) return 0;
     const dim3 g((unsigned)grid8(n)), b(KNP_BLOCK);
     const KnpArgs ka = make_knp_args(c);
+    if (D == 3 && c->m.cls && c->m.hb_stride && c->p.n_sys <= 2 && halo_enabled()) {
+        const unsigned ent = halo_entries(c);
+        const size_t ns = (size_t)c->p.n_sys;
+        static const bool use_mat = !(getenv("KNP_APPLY_MAT") && atoi(getenv("KNP_APPLY_MAT")) == 0);
+        static const int probe = getenv("KNP_APPLY_PROBE") ? atoi(getenv("KNP_APPLY_PROBE")) : 0;       // tools/apply_only.py experiments
+        const bool matp = use_mat && c->nmat > 0;
+        const size_t lds = sizeof(double) * (ns * ent * 4 + KNP_HALO_BLK * 4 + (ent - KNP_HALO_BLK) + (matp ? ns * KNP_MAX_MAT : ns * ent) +
+                                             (size_t)c->m.ncls * HALO_FTS);
+        if (lds <= 65536) {
+            const dim3 hb(KNP_HALO_BLK);
+#define KNP_HALO_LAUNCH(NS_, MAT_, PR_)                                                                                              \
+    hipLaunchKernelGGL((k_knp_apply_halo<NS_, MAT_, PR_>), halo_grid(c, k_knp_apply_halo<NS_, MAT_, PR_>, lds), hb, lds, c->stream, c->m, x, \
+                       gphi, c->D, y, ka, ent, (const uint8_t*)c->mat, (const uint8_t*)c->nmat4, (const double*)c->dtab)
+            if (c->p.n_sys == 1) { if (matp) KNP_HALO_LAUNCH(1, true, 0); else KNP_HALO_LAUNCH(1, false, 0); }
+            else if (probe == 2 && matp) KNP_HALO_LAUNCH(2, true, 2);
+            else if (probe == 1 && matp) KNP_HALO_LAUNCH(2, true, 1);
+            else if (matp) KNP_HALO_LAUNCH(2, true, 0);
+            else KNP_HALO_LAUNCH(2, false, 0);
+#undef KNP_HALO_LAUNCH
+            HIPCHK(c, hipGetLastError());
+            return 0;
+        }
+    }
     if (D == 3 && c->m.cls && c->m.ncls <= CLS_MAX_LDS && c->p.n_sys <= 3) {
         switch (c->p.n_sys) {
             case 1: hipLaunchKernelGGL((k_knp_apply_cls_staged<3, 1, 256>), g, b, 0, c->stream, c->m, x, gphi, c->D, y, ka); break;
@@ -844,6 +1281,14 @@ int launch_knp_blockjacobi(knp_ctx* c, const double* gphi, bjreal* binv) {
     else
         hipLaunchKernelGGL(k_knp_blockjacobi<2>, g, b, 0, c->stream, c->m, gphi, c->D, binv, ka);
     HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
+int launch_neighbour_materials(knp_ctx* c) {
+    const int64_t n = c->m.nc * 4;
+    hipLaunchKernelGGL(k_neighbour_materials, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->m.nc, c->m.nbr, c->mat, c->nmat4);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     return 0;
 }
 

@@ -40,8 +40,15 @@ struct MeshDev {
     uint16_t* cls = nullptr;       // [nc] geometry class of every cell (structured meshes), or null
     double* cls_table = nullptr;   // [ncls][KNP_CLS_STRIDE]
     int ncls = 0;
+    // per-256-cell-block neighbour tables of the halo-staged applies (3D P1; blocks are aligned at multiples of 256 from cell 0)
+    int32_t* hb_src = nullptr;     // [nblk][hb_stride]: 4 * neighbour cell + its local facet, one entry per coupled facet whose neighbour lies
+                                   // outside the block; -1 behind the block's last entry
+    uint16_t* hb_loc = nullptr;    // [nc_owned][4] LDS entry of the neighbour behind facet i: < 256 in-block cell, else 256 + position in the list
+    int hb_stride = 0;             // longest list, rounded up to 8 (0: no tables, or a list longer than one entry per thread)
 };
 #define KNP_CLS_STRIDE 36
+#define KNP_HALO_BLK 256
+#define KNP_MAX_MAT 16
 
 struct Params {
     int n_ions = 0;                // total species, last one eliminated
@@ -75,6 +82,13 @@ struct knp_ctx {
     MeshDev m;
     Params p;
     double* D = nullptr;           // [n_ions][nc]
+    // D is piecewise constant by subdomain in every reference configuration (make_global of D_sub, solver.py:88-112): when the cells
+    // carry <= KNP_MAX_MAT distinct coefficient tuples the halo-staged KNP apply reads a 1-byte material id per cell and per facet
+    // neighbour instead of n_sys doubles (set by knp_set_params; nmat = 0 -> general per-cell D, the kernels read c->D)
+    uint8_t* mat = nullptr;        // [nc] material id of the cell
+    uint8_t* nmat4 = nullptr;      // [nc][4] material id of the neighbour behind every facet (3D)
+    double* dtab = nullptr;        // [n_ions][KNP_MAX_MAT]
+    int nmat = 0;
     double* rho = nullptr;         // [nc]
     double* fsrc = nullptr;        // [n_sys][nc] DG0 source on ECS cells, or null
     // manufactured-solution mode (splitting == 2): constant coupling coefficients + host-integrated data terms
@@ -136,6 +150,7 @@ int launch_knp_apply(knp_ctx* c, const double* x, const double* dnphi, double* y
 int launch_emi_blockjacobi(knp_ctx* c, const double* kappa, bjreal* binv);
 int launch_knp_blockjacobi(knp_ctx* c, const double* dnphi, bjreal* binv);
 int launch_dnphi(knp_ctx* c, const double* phi, double* dnphi);
+int launch_neighbour_materials(knp_ctx* c);
 int launch_kappa(knp_ctx* c, const double* cc, const double* celim, double* kappa);
 int launch_emi_rhs(knp_ctx* c, const double* cc, const double* celim, const double* phiM,
                    const double* Ich, double* b);
