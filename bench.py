@@ -228,7 +228,8 @@ def main():
     cls = bool(S.dev.n_geometry_classes)
     if args.degree == 1:
         emi_name = "k_emi_apply_cls_staged<3,256>" if cls else "k_emi_apply<3,3>"
-        knp_name = "k_knp_apply_cls_staged<3,2,256>" if cls else "k_knp_apply<3,2>"
+        kv = S.dev.apply_variant(1)
+        knp_name = {2: "k_knp_apply_halo<2,false>", 6: "k_knp_apply_halo<2,true>", 1: "k_knp_apply_cls_staged<3,2,256>"}.get(kv, "k_knp_apply<3,2>")
     else:
         emi_name = "k_emi_apply_p2<3,256,%s>" % ("true" if cls else "false")
         knp_name = "k_knp_apply_p2<3,256,%s>" % ("true" if cls else "false")

@@ -212,6 +212,12 @@ int knp_bench_apply(knp_ctx* ctx, int which, int reps, float* avg_ms);
 int knp_apply_timing(knp_ctx* ctx, int enable);
 int knp_apply_timing_read(knp_ctx* ctx, int which, float* avg_ms, int* count);
 
+/* Which kernel knp_emi_apply (which = 0) / knp_knp_apply (which = 1) currently dispatches to, so that a measurement can name it:
+ * 0 coordinate path (any mesh), 1 geometry classes + LDS staging (structured 3D P1), 2 halo-staged persistent kernel, 6 the same
+ * with D read through the material table (knp_set_params found <= 16 distinct coefficient tuples), 8 matrix-free P2,
+ * 9 assembled P2 blocks (KNP_P2_ASSEMBLED=1).  Negative on bad arguments.  No reference counterpart (measurement only). */
+int knp_apply_variant(knp_ctx* ctx, int which);
+
 /* FP64 MFMA probe of the DG-P2 path's dense facet-quadrature contraction (csrc/apply_p2.hip): variant 0 = per-thread FMA chain
  * (what the product kernels use), 1 = v_mfma_f64_16x16x4_f64 tiles.  in[ncol][26] = {jump(u)[6], kappa[6], kappa'[6], dn u[3],
  * dn u'[3], area, penalty}, out[ncol][9] = {r[6], T[3]}; returns the average kernel time over `reps` launches.  Diagnostic

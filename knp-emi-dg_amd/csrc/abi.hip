@@ -214,7 +214,7 @@ int knp_ctx_create(knp_ctx** out, int device, int dim, int degree, int n_ions, i
     rc |= dev_alloc_copy(c, &m.cfacet, cfacet.data(), cfacet.size());
     rc |= dev_alloc_copy(c, &m.mf, mf.data(), mf.size());
     if (dim == 3 && degree == 1 && nc_owned > 0 && nc < (int64_t(1) << 29)) {
-        // halo-staged applies: per block of 256 consecutive cells, the coupled (SIPG / membrane) neighbours outside the block
+        // halo-staged KNP apply: per block of 256 consecutive cells, the SIPG neighbours outside the block
         const int64_t B = KNP_HALO_BLK, nblk = (nc_owned + B - 1) / B;
         std::vector<int32_t> hcnt(nblk, 0);
         std::vector<std::vector<int32_t>> lists((size_t)nblk);
@@ -226,7 +226,7 @@ int knp_ctx_create(knp_ctx** out, int device, int dim, int degree, int n_ions, i
                 for (int a = 0; a < 4; ++a) {
                     const uint32_t kind = (fb[k * 4 + a] >> 2) & 3u;
                     const int64_t nbk = nbr[k * 4 + a];
-                    if (kind >= FK_EXTERIOR || nbk < 0) continue;
+                    if (kind != FK_SIPG || nbk < 0) continue;
                     if (nbk / B == b) { hloc[k * 4 + a] = (uint16_t)(nbk - b * B); continue; }
                     hloc[k * 4 + a] = (uint16_t)(B + L.size());
                     L.push_back((int32_t)(nbk * 4 + (fb[k * 4 + a] & 3u)));
@@ -239,6 +239,7 @@ int knp_ctx_create(knp_ctx** out, int device, int dim, int degree, int n_ions, i
             for (int64_t b = 0; b < nblk; ++b) std::copy(lists[(size_t)b].begin(), lists[(size_t)b].end(), hsrc.begin() + b * hs);
             rc |= dev_alloc_copy(c, &m.hb_src, hsrc.data(), hsrc.size());
             rc |= dev_alloc_copy(c, &m.hb_loc, hloc.data(), hloc.size());
+            rc |= dev_zeros(c, &c->halo_ctr, 2 * 2 * 64 * 32);          // [2 operators][2 sets][64 queues], one 128-byte line per counter
             m.hb_stride = hs;
         }
     }
@@ -291,7 +292,7 @@ void knp_ctx_destroy(knp_ctx* c) {
     }
     hipFree(c->m.hb_src); hipFree(c->m.hb_loc);
     hipFree(c->m.cls); hipFree(c->m.cls_table); hipFree(c->m.coords); hipFree(c->m.h); hipFree(c->m.cells); hipFree(c->m.nbr); hipFree(c->m.fflag); hipFree(c->m.cfacet); hipFree(c->m.mf);
-    hipFree(c->mat); hipFree(c->nmat4); hipFree(c->dtab);
+    hipFree(c->mat); hipFree(c->nmat4); hipFree(c->dtab); hipFree(c->halo_ctr);
     hipFree(c->D); hipFree(c->rho); hipFree(c->fsrc); hipFree(c->mms_C); hipFree(c->extra_emi); hipFree(c->extra_knp); hipFree(c->partial); hipFree(c->scal); hipFree(c->status);
     hipFree(c->halo_send_idx); hipFree(c->halo_sendbuf);
     if (c->pinned) hipHostFree(c->pinned);
@@ -651,6 +652,11 @@ int knp_apply_timing(knp_ctx* c, int enable) {
     if (!c) return -1;
     c->time_applies = enable != 0;
     return 0;
+}
+
+int knp_apply_variant(knp_ctx* c, int which) {
+    if (!c || (which != 0 && which != 1)) return -1;
+    return apply_variant(c, which);
 }
 
 int knp_apply_timing_read(knp_ctx* c, int which, float* avg_ms, int* count) {

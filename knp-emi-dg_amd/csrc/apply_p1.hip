@@ -672,7 +672,8 @@ __global__ __launch_bounds__(BLK) void k_knp_apply_cls_staged(MeshDev m, const d
 // Measured on the staged kernels above (tools/pmc_apply.sh, profiles/r02_pmc_apply_halo.md): 60 % of the wave cycles are
 // spent parked, and a probe with the facet arithmetic removed still takes 85 % of the time -- the kernels are bound by their
 // memory phase, which is a CHAIN of dependent round trips (topology -> neighbour rows, inside the facet loop for the 17 %
-// of the facets whose neighbour lies outside the workgroup's 256 cells).  Here
+// of the facets whose neighbour lies outside the workgroup's 256 cells).  For the KNP operator (the EMI twin of this kernel
+// measured equal to k_emi_apply_cls_staged, 34.1 vs 33.9 us at r=2 and 277 vs 280 us at r=3, and was removed)
 //   * the out-of-block neighbours of every 256-cell block are known in advance (MeshDev::hb_src / hb_loc, built once from
 //     the topology): own records and halo records are loaded before the single barrier and the facet loop reads LDS only
 //     (one uniform path, the facet-vertex permutation folded into the per-lane LDS address, no register selects);
@@ -696,19 +697,46 @@ __device__ __forceinline__ void load_class_gram(const double* __restrict__ table
         for (int b = a; b < 4; ++b) { K.G[a][b] = rec[q]; K.G[b][a] = rec[q]; ++q; }
 }
 
-// the blocks of one workgroup: XCD x (= blockIdx.x & 7, round-robin dispatch) owns one contiguous eighth of the block range,
-// its workgroups take every nslot-th block of it
+// The blocks of one workgroup.  The block range is cut into nq contiguous chunks, nq/8 per XCD (XCD = blockIdx.x & 7,
+// round-robin dispatch; an XCD's chunks are adjacent, so facet neighbours stay in its L2); workgroup w serves chunk queue w % nq
+// with the other `members` workgroups of that queue.  Full rounds are strided (block = first + member + round * members); the
+// remainder (< members blocks) goes to whichever workgroups get there first, through the queue's counter.  A workgroup knows
+// its next block one iteration ahead, because that block's halo list is fetched while the current block is worked on.
+// counters[2][HALO_NQ] (one 128-byte line each): this launch draws from set `flip` (zero on entry) and zeroes the other one --
+// the previous launch's, which the next launch will draw from (launches of one context are ordered on its stream).
+#define HALO_NQ 64            // counters per set (upper bound of the queue count nq, a multiple of 8)
+#define HALO_CPAD 32          // ints between two counters: atomics on ONE line retire at ~13 ns chip-wide (measured with a draw per
+                              // block: 31 104 draws on one line = 392 us, more than the whole kernel)
 struct HaloWalk {
-    int64_t b_lo, rb, last, nslot;
-    __device__ __forceinline__ HaloWalk(const MeshDev& m) {
+    int64_t b_lo, first, last, members, member, dyn0, cur, nxt;
+    int n, rounds;
+    int* ctr;
+    __device__ __forceinline__ int64_t strided(int k) const { return first + member + (int64_t)k * members; }
+    __device__ __forceinline__ HaloWalk(const MeshDev& m, int* counters, int flip_nq) {
+        const int flip = flip_nq & 1;
+        const unsigned nq = (unsigned)flip_nq >> 2;
         b_lo = m.c_begin / KNP_HALO_BLK;
         const int64_t nblk = (m.c_end - 1) / KNP_HALO_BLK - b_lo + 1;
-        const int64_t chunk = (nblk + 7) >> 3;
-        const int64_t first = (int64_t)(blockIdx.x & 7u) * chunk;
+        const int64_t chunk = (nblk + nq - 1) / nq;
+        const unsigned q = blockIdx.x % nq;
+        first = (int64_t)((q & 7u) * (nq >> 3) + (q >> 3)) * chunk;
         last = first + chunk < nblk ? first + chunk : nblk;
-        nslot = gridDim.x >> 3;
-        rb = first + (blockIdx.x >> 3);
+        members = gridDim.x / nq;
+        member = blockIdx.x / nq;
+        rounds = last > first ? (int)((last - first) / members) : 0;
+        if (rounds < 2) rounds = 1 << 30;                                    // short chunks: strided throughout, no draws
+        else if (flip_nq & 2) rounds = 2;                                    // default (KNP_HALO_DYN=0 turns it off): every block after the first two is drawn
+        dyn0 = first + (int64_t)rounds * members;
+        n = 0;
+        cur = strided(0);
+        nxt = strided(1);
+        ctr = counters + (HALO_NQ * flip + q) * HALO_CPAD;
+        if (blockIdx.x == 0 && threadIdx.x < HALO_NQ) counters[(HALO_NQ * (1 - flip) + threadIdx.x) * HALO_CPAD] = 0;
     }
+    // thread 0, at the top of iteration n: the block after next
+    __device__ __forceinline__ int64_t after_next() const { return n + 2 < rounds ? strided(n + 2) : dyn0 + atomicAdd(ctr, 1); }
+    // every thread, after the iteration's second barrier
+    __device__ __forceinline__ void advance(int64_t nn) { cur = nxt; nxt = nn; ++n; }
 };
 
 // s_D: MAT ? [NS][KNP_MAX_MAT] coefficient table indexed by the neighbour's material id dsel : [NS][ent] staged values
@@ -773,22 +801,24 @@ __global__ __launch_bounds__(KNP_HALO_BLK) void k_knp_apply_halo(MeshDev m, cons
                                                                  const double* __restrict__ gphi,
                                                                  const double* __restrict__ Dall, double* __restrict__ yout,
                                                                  KnpArgs ka, unsigned ent, const uint8_t* __restrict__ mat,
-                                                                 const uint8_t* __restrict__ nmat4, const double* __restrict__ dtab) {
+                                                                 const uint8_t* __restrict__ nmat4, const double* __restrict__ dtab,
+                                                                 int* __restrict__ counters, int flip_nq) {
     constexpr int NV = 4, BLK = KNP_HALO_BLK;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* s_x = smem;                                   // [NS][4][ent]
     double* s_g = s_x + NS * ent * NV;                    // [4][256] own gphi, then [ent - 256] the halo's one component
     double* s_D = s_g + BLK * NV + (ent - BLK);           // MAT: [NS][KNP_MAX_MAT] coefficient table ; else [NS][ent]
     double* s_ft = s_D + (MAT ? NS * KNP_MAX_MAT : NS * ent);   // [ncls][25]
+    int* s_draw = reinterpret_cast<int*>(s_ft + m.ncls * HALO_FTS);
     const unsigned t = threadIdx.x;
-    HaloWalk w(m);
-    if (w.rb >= w.last) return;
+    HaloWalk w(m, counters, flip_nq);
+    if (w.cur >= w.last) return;
     for (int i = t; i < m.ncls * HALO_FT; i += BLK) s_ft[(i / HALO_FT) * HALO_FTS + (i % HALO_FT)] = m.cls_table[(i / HALO_FT) * KNP_CLS_STRIDE + 11 + (i % HALO_FT)];
     if (MAT && t < NS * KNP_MAX_MAT) s_D[t] = dtab[t];
     const bool hl = (int)t < m.hb_stride && PROBE != 2;
-    int src = hl ? m.hb_src[(w.b_lo + w.rb) * m.hb_stride + t] : -1;
-    for (; w.rb < w.last; w.rb += w.nslot) {
-        const int64_t c = (w.b_lo + w.rb) * BLK + t;
+    int src = hl ? m.hb_src[(w.b_lo + w.cur) * m.hb_stride + t] : -1;
+    while (w.cur < w.last) {
+        const int64_t c = (w.b_lo + w.cur) * BLK + t;
         const bool valid = c >= m.c_begin && c < m.c_end;
         const bool stage = c < m.nc;
         double xv[NS][NV], y[NS][NV], gp[NV], Dk[NS];
@@ -814,7 +844,7 @@ __global__ __launch_bounds__(KNP_HALO_BLK) void k_knp_apply_halo(MeshDev m, cons
                 if (!MAT) hD[k] = Dall[(int64_t)k * m.nc + Kp];
             }
         }
-        const int src_next = (hl && w.rb + w.nslot < w.last) ? m.hb_src[(w.b_lo + w.rb + w.nslot) * m.hb_stride + t] : -1;
+        const int src_next = (hl && w.nxt < w.last) ? m.hb_src[(w.b_lo + w.nxt) * m.hb_stride + t] : -1;
         uint32_t flags = 0, nm = 0;
         unsigned cls = 0, mymat = 0;
         uint2 lw = make_uint2(0u, 0u);
@@ -829,6 +859,8 @@ __global__ __launch_bounds__(KNP_HALO_BLK) void k_knp_apply_halo(MeshDev m, cons
             }
             load_class_gram(m.cls_table, cls, K);
         }
+        int64_t drawn = 0;
+        if (t == 0) drawn = w.after_next();          // behind the iteration's loads: its return does not gate them (in-order counter)
         if (stage) {
 #pragma unroll
             for (int k = 0; k < NS; ++k) {
@@ -886,8 +918,10 @@ __global__ __launch_bounds__(KNP_HALO_BLK) void k_knp_apply_halo(MeshDev m, cons
 #pragma unroll
             for (int k = 0; k < NS; ++k) store_nodal<3>(yout + (int64_t)k * m.nc * NV, c, y[k]);
         }
+        if (t == 0) *s_draw = (int)drawn;
         __syncthreads();                   // the next block overwrites the staging
         src = src_next;
+        w.advance(*s_draw);
     }
 }
 
@@ -897,154 +931,6 @@ __global__ void k_neighbour_materials(int64_t nc, const int32_t* __restrict__ nb
     if (i >= nc * 4) return;
     const int32_t nb = nbr[i];
     nmat4[i] = nb >= 0 ? mat[nb] : (uint8_t)0;
-}
-
-template <int I>
-__device__ __forceinline__ void emi_facet_halo(const CellGeom<3>& K, uint32_t flags, unsigned loc, const double* xv, const double* kv,
-                                               double C_phi, double tau, const lds_double* s_x, const lds_double* s_k,
-                                               const lds_double* ft, unsigned ent, double* y) {
-    constexpr int D = 3, NV = 4;
-    const uint32_t fb = (flags >> (8 * I)) & 0xffu;
-    const uint32_t kind = (fb >> 2) & 3u;
-    if (kind >= FK_EXTERIOR) return;
-    const unsigned j = fb & 3u;
-    const lds_double* xl = s_x + loc;                         // component-major: [a][entry]
-    const lds_double* kl = s_k + loc;
-    double xf[D], knf[D];
-    const double xap = xl[j * ent];
-#pragma unroll
-    for (int mm = 0; mm < D; ++mm) {
-        const unsigned o = (mm + (mm >= (int)j ? 1 : 0)) * ent;
-        xf[mm] = xl[o];
-        knf[mm] = kl[o];
-    }
-    double du[D], sdu = 0.0;
-#pragma unroll
-    for (int mm = 0; mm < D; ++mm) {
-        du[mm] = xv[mm + (mm >= I)] - xf[mm];
-        sdu += du[mm];
-    }
-    const double DV = (double)D * K.vol;
-    const double sqG = ft[6 * I + 4];
-    if (kind == FK_MEMBRANE) {
-        const double w = C_phi * sqG * DV * FacetConst<D>::mass;
-#pragma unroll
-        for (int mm = 0; mm < D; ++mm) y[mm + (mm >= I)] = fma(w, sdu + du[mm], y[mm + (mm >= I)]);
-        return;
-    }
-    double L[NV];
-#pragma unroll
-    for (int a = 0; a < NV; ++a) L[a] = ft[6 * I + a];
-    const double gr = K.G[I][I] * fast_rcp(L[I]);
-    double s_own = 0.0, s_nb = xap * gr;
-#pragma unroll
-    for (int a = 0; a < NV; ++a) s_own = fma(xv[a], K.G[a][I], s_own);
-#pragma unroll
-    for (int mm = 0; mm < D; ++mm) s_nb = fma(xf[mm], fma(-L[mm + (mm >= I)], gr, K.G[mm + (mm >= I)][I]), s_nb);
-    double kf[D], sk = 0.0, skn = 0.0, q = 0.0;
-#pragma unroll
-    for (int mm = 0; mm < D; ++mm) {
-        kf[mm] = kv[mm + (mm >= I)];
-        sk += kf[mm];
-        skn += knf[mm];
-        q = fma(kf[mm], sdu + du[mm], q);
-    }
-    const double hm = 0.5 * DV * FacetConst<D>::mass;
-    q *= hm;
-#pragma unroll
-    for (int a = 0; a < NV; ++a) y[a] = fma(K.G[a][I], q, y[a]);
-    const double pw = tau * ft[6 * I + 5] * sqG * DV * FacetConst<D>::trip;
-    double kb[D], skb = 0.0, skd = 0.0;
-#pragma unroll
-    for (int mm = 0; mm < D; ++mm) {
-        kb[mm] = 0.5 * (kf[mm] + knf[mm]);
-        skb += kb[mm];
-        skd = fma(kb[mm], du[mm], skd);
-    }
-    const double base = fma(skb, sdu, skd);
-#pragma unroll
-    for (int mm = 0; mm < D; ++mm) {
-        const double t1 = hm * fma(s_own, sk + kf[mm], s_nb * (skn + knf[mm]));
-        const double t3 = pw * (base + fma(kb[mm], sdu, du[mm] * fma(2.0, kb[mm], skb)));
-        y[mm + (mm >= I)] += t1 + t3;
-    }
-}
-
-__global__ __launch_bounds__(KNP_HALO_BLK) void k_emi_apply_halo(MeshDev m, const double* __restrict__ x,
-                                                                 const double* __restrict__ kappa, double* __restrict__ y,
-                                                                 double C_phi, double tau, unsigned ent) {
-    constexpr int NV = 4, BLK = KNP_HALO_BLK;
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    double* s_x = smem;                    // [4][ent]
-    double* s_k = s_x + ent * NV;          // [4][ent]
-    double* s_ft = s_k + ent * NV;         // [ncls][25]
-    const unsigned t = threadIdx.x;
-    HaloWalk w(m);
-    if (w.rb >= w.last) return;
-    for (int i = t; i < m.ncls * HALO_FT; i += BLK) s_ft[(i / HALO_FT) * HALO_FTS + (i % HALO_FT)] = m.cls_table[(i / HALO_FT) * KNP_CLS_STRIDE + 11 + (i % HALO_FT)];
-    const bool hl = (int)t < m.hb_stride;
-    int src = hl ? m.hb_src[(w.b_lo + w.rb) * m.hb_stride + t] : -1;
-    for (; w.rb < w.last; w.rb += w.nslot) {
-        const int64_t c = (w.b_lo + w.rb) * BLK + t;
-        const bool valid = c >= m.c_begin && c < m.c_end;
-        const bool stage = c < m.nc;
-        double xv[NV], kv[NV], yv[NV];
-        if (stage) {
-            load_nodal<3>(x, c, xv);
-            load_nodal<3>(kappa, c, kv);
-        }
-        double2 hx[2], hk[2];
-        if (src >= 0) {
-            const int64_t Kp = src >> 2;
-            const double2* px = reinterpret_cast<const double2*>(x + Kp * NV);
-            const double2* pk = reinterpret_cast<const double2*>(kappa + Kp * NV);
-            hx[0] = px[0]; hx[1] = px[1];
-            hk[0] = pk[0]; hk[1] = pk[1];
-        }
-        const int src_next = (hl && w.rb + w.nslot < w.last) ? m.hb_src[(w.b_lo + w.rb + w.nslot) * m.hb_stride + t] : -1;
-        uint32_t flags = 0;
-        unsigned cls = 0;
-        uint2 lw = make_uint2(0u, 0u);
-        CellGeom<3> K;
-        if (valid) {
-            flags = m.fflag[c];
-            cls = m.cls[c];
-            lw = *reinterpret_cast<const uint2*>(m.hb_loc + c * NV);
-            load_class_gram(m.cls_table, cls, K);
-        }
-        if (stage) {
-#pragma unroll
-            for (int a = 0; a < NV; ++a) { s_x[a * ent + t] = xv[a]; s_k[a * ent + t] = kv[a]; }
-        }
-        if (src >= 0) {
-            double* dx = s_x + BLK + t;
-            double* dk = s_k + BLK + t;
-            dx[0] = hx[0].x; dx[ent] = hx[0].y; dx[2 * ent] = hx[1].x; dx[3 * ent] = hx[1].y;
-            dk[0] = hk[0].x; dk[ent] = hk[0].y; dk[2 * ent] = hk[1].x; dk[3 * ent] = hk[1].y;
-        }
-        __syncthreads();
-        if (valid) {
-            const lds_double* ft = TO_LDS(s_ft) + cls * HALO_FTS;
-            double kbar = 0.0;
-#pragma unroll
-            for (int a = 0; a < NV; ++a) kbar += kv[a];
-            kbar *= K.vol / (double)NV;
-#pragma unroll
-            for (int a = 0; a < NV; ++a) {
-                double sa = 0.0;
-#pragma unroll
-                for (int bb = 0; bb < NV; ++bb) sa = fma(K.G[a][bb], xv[bb], sa);
-                yv[a] = kbar * sa;
-            }
-            emi_facet_halo<0>(K, flags, lw.x & 0xffffu, xv, kv, C_phi, tau, TO_LDS(s_x), TO_LDS(s_k), ft, ent, yv);
-            emi_facet_halo<1>(K, flags, lw.x >> 16, xv, kv, C_phi, tau, TO_LDS(s_x), TO_LDS(s_k), ft, ent, yv);
-            emi_facet_halo<2>(K, flags, lw.y & 0xffffu, xv, kv, C_phi, tau, TO_LDS(s_x), TO_LDS(s_k), ft, ent, yv);
-            emi_facet_halo<3>(K, flags, lw.y >> 16, xv, kv, C_phi, tau, TO_LDS(s_x), TO_LDS(s_k), ft, ent, yv);
-            store_nodal<3>(y, c, yv);
-        }
-        __syncthreads();
-        src = src_next;
-    }
 }
 
 // one species per launch dimension (setup only, once per KNP solve)
@@ -1149,12 +1035,25 @@ int launch_knp_apply(knp_ctx* c, const double* x, const double* gphi, double* y)
 
 // halo-staged kernels: usable when the class and halo tables exist and the block's LDS footprint stays below 64 KB;
 // KNP_APPLY_HALO=0 selects the previous staged kernels (A/B runs)
-static bool halo_enabled() {
-    static const bool on = !(getenv("KNP_APPLY_HALO") && atoi(getenv("KNP_APPLY_HALO")) == 0);
-    return on;
+static int env_int(const char* name, int dflt) {            // read per launch (tests switch variants inside one process)
+    const char* v = getenv(name);
+    return v ? atoi(v) : dflt;
 }
+static bool halo_enabled() { return env_int("KNP_APPLY_HALO", 1) != 0; }
 static unsigned halo_entries(const knp_ctx* c) { return (unsigned)(KNP_HALO_BLK + c->m.hb_stride); }
-// persistent grid: as many workgroups as fit on the chip at once (a multiple of 8: one eighth per XCD), at most one per block;
+// block counters of the persistent kernels: per operator two sets of 8 that swap roles at every launch (the kernel zeroes the
+// set of the launch before it; launches of one context are ordered on its stream)
+static int halo_queues() {
+    const int v = (env_int("KNP_HALO_NQ", 8) / 8) * 8;
+    return v < 8 ? 8 : (v > HALO_NQ ? HALO_NQ : v);
+}
+static int* halo_counters(knp_ctx* c, int which, int* flip_nq) {
+    c->halo_flip[which] ^= 1;
+    const int dyn = env_int("KNP_HALO_DYN", 1) ? 2 : 0;          // default: drawn (measured: -3..7 % at 8 M cells)
+    *flip_nq = c->halo_flip[which] | dyn | (halo_queues() << 2);
+    return c->halo_ctr + which * 2 * HALO_NQ * HALO_CPAD;
+}
+// persistent grid: as many workgroups as fit on the chip at once (a multiple of the 64 chunk queues), at most one per block;
 // KNP_HALO_WG_PER_CU overrides the occupancy query (tuning)
 template <typename KernelT> static dim3 halo_grid(const knp_ctx* c, KernelT kernel, size_t lds) {
     const int64_t nb = (c->m.c_end - 1) / KNP_HALO_BLK - c->m.c_begin / KNP_HALO_BLK + 1;
@@ -1163,12 +1062,12 @@ template <typename KernelT> static dim3 halo_grid(const knp_ctx* c, KernelT kern
         hipDeviceProp_t prop;
         ncu = (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
     }
-    static const int forced = getenv("KNP_HALO_WG_PER_CU") ? atoi(getenv("KNP_HALO_WG_PER_CU")) : 0;
-    int per_cu = forced;
+    int per_cu = env_int("KNP_HALO_WG_PER_CU", 0);
     if (per_cu <= 0 && hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, KNP_HALO_BLK, lds) != hipSuccess) per_cu = 2;
     if (per_cu < 1) per_cu = 1;
-    int64_t g = std::min<int64_t>(((nb + 7) / 8) * 8, (int64_t)per_cu * ncu);
-    g = std::max<int64_t>(8, (g / 8) * 8);
+    const int64_t nq = halo_queues();
+    int64_t g = std::min<int64_t>(((nb + nq - 1) / nq) * nq, (int64_t)per_cu * ncu);
+    g = std::max<int64_t>(nq, (g / nq) * nq);
     return dim3((unsigned)g);
 }
 
@@ -1177,16 +1076,6 @@ static int emi_apply_impl(knp_ctx* c, const double* x, const double* kappa, doub
     const int64_t n = c->m.c_end - c->m.c_begin;
     if (n <= 0) return 0;
     const dim3 g((unsigned)grid8(n)), b(KNP_BLOCK);
-    if (c->m.cls && c->m.hb_stride && c->m.dim == 3 && halo_enabled()) {
-        const unsigned ent = halo_entries(c);
-        const size_t lds = sizeof(double) * ((size_t)ent * 8 + (size_t)c->m.ncls * HALO_FTS);
-        if (lds <= 65536) {
-            hipLaunchKernelGGL(k_emi_apply_halo, halo_grid(c, k_emi_apply_halo, lds), dim3(KNP_HALO_BLK), lds, c->stream, c->m, x, kappa, y,
-                               c->p.C_phi, c->p.tau_emi, ent);
-            HIPCHK(c, hipGetLastError());
-            return 0;
-        }
-    }
     if (c->m.cls && c->m.dim == 3 && c->m.ncls <= CLS_MAX_LDS)
         hipLaunchKernelGGL((k_emi_apply_cls_staged<3, 256>), g, b, 0, c->stream, c->m, x, kappa, y, c->p.C_phi, c->p.tau_emi);
     else if (c->m.dim == 3)
@@ -1194,6 +1083,29 @@ static int emi_apply_impl(knp_ctx* c, const double* x, const double* kappa, doub
     else
         hipLaunchKernelGGL(k_emi_apply<2>, g, b, 0, c->stream, c->m, x, kappa, y, c->p.C_phi, c->p.tau_emi);
     HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
+// the halo-staged persistent KNP kernel is usable when the class and halo tables exist, at most two species are solved and
+// the block's LDS footprint stays below 64 KB
+static bool knp_halo_usable(const knp_ctx* c, size_t* lds_bytes, bool* with_materials) {
+    if (c->degree != 1 || c->m.dim != 3 || !c->m.cls || !c->m.hb_stride || !c->halo_ctr || c->p.n_sys > 2 || !halo_enabled()) return false;
+    const bool matp = env_int("KNP_APPLY_MAT", 1) != 0 && c->nmat > 0;
+    const size_t ns = (size_t)c->p.n_sys, ent = halo_entries(c);
+    const size_t lds = sizeof(double) * (ns * ent * 4 + KNP_HALO_BLK * 4 + (ent - KNP_HALO_BLK) + (matp ? ns * KNP_MAX_MAT : ns * ent) +
+                                         (size_t)c->m.ncls * HALO_FTS + 1);
+    if (lds_bytes) *lds_bytes = lds;
+    if (with_materials) *with_materials = matp;
+    return lds <= 65536;
+}
+
+// which kernel an operator apply runs (bench.py / tests name the kernel they measured): 0 coordinate path, 1 geometry classes +
+// LDS staging, 2 halo-staged persistent (+ 4 when D comes from the material table), 8 matrix-free P2, 9 assembled P2 blocks
+int apply_variant(knp_ctx* c, int which) {
+    if (c->degree != 1) return p2_assembled() ? 9 : 8;
+    bool matp = false;
+    if (which == 1 && knp_halo_usable(c, nullptr, &matp)) return matp ? 6 : 2;
+    if (c->m.dim == 3 && c->m.cls && c->m.ncls <= CLS_MAX_LDS && (which == 0 || c->p.n_sys <= 3)) return 1;
     return 0;
 }
 
@@ -1212,28 +1124,25 @@ template <int D> static int knp_apply_dispatch(knp_ctx* c, const double* x, cons
     if (n <= 0) return 0;
     const dim3 g((unsigned)grid8(n)), b(KNP_BLOCK);
     const KnpArgs ka = make_knp_args(c);
-    if (D == 3 && c->m.cls && c->m.hb_stride && c->p.n_sys <= 2 && halo_enabled()) {
+    size_t lds = 0;
+    bool matp = false;
+    if (D == 3 && knp_halo_usable(c, &lds, &matp)) {
+        const int probe = env_int("KNP_APPLY_PROBE", 0);          // tools/apply_only.py experiments
         const unsigned ent = halo_entries(c);
-        const size_t ns = (size_t)c->p.n_sys;
-        static const bool use_mat = !(getenv("KNP_APPLY_MAT") && atoi(getenv("KNP_APPLY_MAT")) == 0);
-        static const int probe = getenv("KNP_APPLY_PROBE") ? atoi(getenv("KNP_APPLY_PROBE")) : 0;       // tools/apply_only.py experiments
-        const bool matp = use_mat && c->nmat > 0;
-        const size_t lds = sizeof(double) * (ns * ent * 4 + KNP_HALO_BLK * 4 + (ent - KNP_HALO_BLK) + (matp ? ns * KNP_MAX_MAT : ns * ent) +
-                                             (size_t)c->m.ncls * HALO_FTS);
-        if (lds <= 65536) {
-            const dim3 hb(KNP_HALO_BLK);
+        const dim3 hb(KNP_HALO_BLK);
+        int flip_nq = 0;
+        int* ctr = halo_counters(c, 1, &flip_nq);
 #define KNP_HALO_LAUNCH(NS_, MAT_, PR_)                                                                                              \
     hipLaunchKernelGGL((k_knp_apply_halo<NS_, MAT_, PR_>), halo_grid(c, k_knp_apply_halo<NS_, MAT_, PR_>, lds), hb, lds, c->stream, c->m, x, \
-                       gphi, c->D, y, ka, ent, (const uint8_t*)c->mat, (const uint8_t*)c->nmat4, (const double*)c->dtab)
-            if (c->p.n_sys == 1) { if (matp) KNP_HALO_LAUNCH(1, true, 0); else KNP_HALO_LAUNCH(1, false, 0); }
-            else if (probe == 2 && matp) KNP_HALO_LAUNCH(2, true, 2);
-            else if (probe == 1 && matp) KNP_HALO_LAUNCH(2, true, 1);
-            else if (matp) KNP_HALO_LAUNCH(2, true, 0);
-            else KNP_HALO_LAUNCH(2, false, 0);
+                       gphi, c->D, y, ka, ent, (const uint8_t*)c->mat, (const uint8_t*)c->nmat4, (const double*)c->dtab, ctr, flip_nq)
+        if (c->p.n_sys == 1) { if (matp) KNP_HALO_LAUNCH(1, true, 0); else KNP_HALO_LAUNCH(1, false, 0); }
+        else if (probe == 2 && matp) KNP_HALO_LAUNCH(2, true, 2);
+        else if (probe == 1 && matp) KNP_HALO_LAUNCH(2, true, 1);
+        else if (matp) KNP_HALO_LAUNCH(2, true, 0);
+        else KNP_HALO_LAUNCH(2, false, 0);
 #undef KNP_HALO_LAUNCH
-            HIPCHK(c, hipGetLastError());
-            return 0;
-        }
+        HIPCHK(c, hipGetLastError());
+        return 0;
     }
     if (D == 3 && c->m.cls && c->m.ncls <= CLS_MAX_LDS && c->p.n_sys <= 3) {
         switch (c->p.n_sys) {

@@ -89,6 +89,8 @@ struct knp_ctx {
     uint8_t* nmat4 = nullptr;      // [nc][4] material id of the neighbour behind every facet (3D)
     double* dtab = nullptr;        // [n_ions][KNP_MAX_MAT]
     int nmat = 0;
+    int* halo_ctr = nullptr;       // [2 operators][2 sets][64 queues] block counters of the persistent halo-staged applies (apply_p1.hip)
+    int halo_flip[2] = {0, 0};
     double* rho = nullptr;         // [nc]
     double* fsrc = nullptr;        // [n_sys][nc] DG0 source on ECS cells, or null
     // manufactured-solution mode (splitting == 2): constant coupling coefficients + host-integrated data terms
@@ -151,6 +153,7 @@ int launch_emi_blockjacobi(knp_ctx* c, const double* kappa, bjreal* binv);
 int launch_knp_blockjacobi(knp_ctx* c, const double* dnphi, bjreal* binv);
 int launch_dnphi(knp_ctx* c, const double* phi, double* dnphi);
 int launch_neighbour_materials(knp_ctx* c);
+int apply_variant(knp_ctx* c, int which);
 int launch_kappa(knp_ctx* c, const double* cc, const double* celim, double* kappa);
 int launch_emi_rhs(knp_ctx* c, const double* cc, const double* celim, const double* phiM,
                    const double* Ich, double* b);

@@ -58,6 +58,7 @@ SIGNATURES = {
     "knp_probe_facet_contraction": (C.c_int, [_ctxp, C.c_int, C.c_int64, C.c_int, _f64p, _f64p, C.POINTER(C.c_float)]),
     "knp_apply_timing": (C.c_int, [_ctxp, C.c_int]),
     "knp_apply_timing_read": (C.c_int, [_ctxp, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
+    "knp_apply_variant": (C.c_int, [_ctxp, C.c_int]),
     "knp_host_spgemm": (C.c_int, [C.c_int64, C.c_int64, _i32p, _i32p, _f64p, _i32p, _i32p, _f64p, _i32p, C.POINTER(_i32p),
                                   C.POINTER(_f64p), C.c_int]),
     "knp_host_spmv": (C.c_int, [C.c_int64, _i32p, _i32p, _f64p, _f64p, _f64p, C.c_int]),
@@ -454,6 +455,10 @@ class Device:
 
     def apply_timing(self, enable):
         self._chk(self.lib.knp_apply_timing(self.ctx, int(bool(enable))), "knp_apply_timing")
+
+    def apply_variant(self, which):
+        """Kernel family the operator apply dispatches to (include/knpemi_hip.h, knp_apply_variant)."""
+        return int(self.lib.knp_apply_variant(self.ctx, which))
 
     def apply_timing_read(self, which):
         """(average ms, launches) of the operator applies issued inside the solves since the last read."""

@@ -85,6 +85,54 @@ def test_knp_apply(case):
         assert relerr(y[k], Ak @ x[k].ravel()) < TOL
 
 
+@pytest.mark.parametrize("env,variant", [({}, 6), ({"KNP_APPLY_MAT": "0"}, 2), ({"KNP_HALO_DYN": "0"}, 6), ({"KNP_HALO_NQ": "64"}, 6),
+                                         ({"KNP_HALO_WG_PER_CU": "1"}, 6), ({"KNP_APPLY_HALO": "0"}, 1)])
+def test_knp_apply_kernel_variants(hip_lib, monkeypatch, env, variant):
+    """Every selectable KNP apply kernel of the structured 3D P1 path against the oracle matrix: halo-staged persistent kernel with the
+    material table (default), with per-cell D, with strided instead of drawn blocks, other queue counts / one workgroup per CU
+    (many blocks per workgroup), and the LDS-staged kernel of round 1."""
+    from knpemidg import _abi as A
+    pb = _problems()["3D_4axon_r0"]
+    x = synthetic_state(pb)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    dev = device_for(pb)
+    try:
+        push_state(dev, pb)
+        assert dev.apply_variant(1) == variant
+        dev.update_dnphi()
+        dev.upload(A.F_X, x)
+        dev.knp_apply(A.F_X, A.F_Y)
+        y = dev.download(A.F_Y).reshape(pb.N_ions, -1)
+        for k in range(pb.N_ions):
+            assert relerr(y[k], ko.assemble_knp(pb, k) @ x[k].ravel()) < TOL
+    finally:
+        dev.close()
+
+
+def test_knp_apply_with_cellwise_diffusion(hip_lib):
+    """D that differs from cell to cell (more distinct coefficient tuples than the material table holds): the halo-staged kernel
+    stages D itself; same operator as the oracle's."""
+    from knpemidg import _abi as A
+    pb = _problems()["3D_4axon_r0"]
+    rng = np.random.default_rng(5)
+    for ion in pb.ions:
+        ion["D"] = np.asarray(ion["D"], dtype=float) * rng.uniform(0.5, 1.5, size=pb.nc)
+    x = synthetic_state(pb)
+    dev = device_for(pb)
+    try:
+        push_state(dev, pb)
+        assert dev.apply_variant(1) == 2
+        dev.update_dnphi()
+        dev.upload(A.F_X, x)
+        dev.knp_apply(A.F_X, A.F_Y)
+        y = dev.download(A.F_Y).reshape(pb.N_ions, -1)
+        for k in range(pb.N_ions):
+            assert relerr(y[k], ko.assemble_knp(pb, k) @ x[k].ravel()) < TOL
+    finally:
+        dev.close()
+
+
 def test_knp_rhs(case):
     pb, dev, x, A = case
     dev.knp_rhs()
