@@ -117,7 +117,7 @@ def test_knp_apply_with_cellwise_diffusion(hip_lib):
     pb = _problems()["3D_4axon_r0"]
     rng = np.random.default_rng(5)
     for ion in pb.ions:
-        ion["D"] = np.asarray(ion["D"], dtype=float) * rng.uniform(0.5, 1.5, size=pb.nc)
+        ion["D"] = np.asarray(ion["D"], dtype=float) * rng.uniform(0.5, 1.5, size=len(pb.cell_tags))
     x = synthetic_state(pb)
     dev = device_for(pb)
     try:
