@@ -188,12 +188,12 @@ def geometry_classes(mesh, order, max_classes=4096, tol=1.0e-9):
     rng = np.random.default_rng(12345)
     h1 = (q * rng.integers(1, 2 ** 62, size=q.shape[1], dtype=np.int64)[None, :]).sum(axis=1)     # wraps mod 2^64
     h2 = (q * rng.integers(1, 2 ** 62, size=q.shape[1], dtype=np.int64)[None, :]).sum(axis=1)
-    _, first, inv = np.unique(np.stack([h1, h2], axis=1), axis=0, return_index=True, return_inverse=True)
+    _, first, inv = np.unique(h1, return_index=True, return_inverse=True)       # 1-D sort; the second hash and q itself are checked below
     inv = inv.ravel()
     ncls = len(first)
     if ncls > max_classes or ncls > max(64, nc // 8):
         return None          # not (block-)structured: the coordinate-path kernels are the right tool
-    if not np.array_equal(q[first][inv], q):               # hash collision (astronomically unlikely): give up
+    if not np.array_equal(h2[first][inv], h2) or not np.array_equal(q[first][inv], q):     # hash collision (astronomically unlikely): give up
         return None
     # records of the representatives
     Xr = X[first]

@@ -168,11 +168,26 @@ class Mesh:
         self.facet_cells = fc
         self.facet_local = fl
 
+    def _midpoints(self, what, conn):
+        """Midpoints of the cells / facets, computed once (mesh builders, the Morton order and the partitioner all ask for them);
+        invalidated when the coordinate array is replaced or rescaled in place."""
+        stamp = (id(self.coords), float(self.coords[0, 0]), float(self.coords[-1, -1]))
+        cache = self.__dict__.setdefault("_midpoint_cache", {})
+        hit = cache.get(what)
+        if hit is None or hit[0] != stamp:
+            acc = self.coords[conn[:, 0]].copy()
+            for k in range(1, conn.shape[1]):
+                acc += self.coords[conn[:, k]]
+            acc /= conn.shape[1]
+            acc.setflags(write=False)
+            hit = cache[what] = (stamp, acc)
+        return hit[1]
+
     def facet_midpoints(self):
-        return self.coords[self.facets].mean(axis=1)
+        return self._midpoints("facets", self.facets)
 
     def cell_midpoints(self):
-        return self.coords[self.cells].mean(axis=1)
+        return self._midpoints("cells", self.cells)
 
     def interior_facets(self):
         return np.nonzero(self.facet_cells[:, 1] >= 0)[0]
