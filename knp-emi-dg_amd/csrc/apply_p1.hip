@@ -1063,7 +1063,17 @@ template <typename KernelT> static dim3 halo_grid(const knp_ctx* c, KernelT kern
         ncu = (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
     }
     int per_cu = env_int("KNP_HALO_WG_PER_CU", 0);
-    if (per_cu <= 0 && hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, KNP_HALO_BLK, lds) != hipSuccess) per_cu = 2;
+    if (per_cu <= 0) {
+        static std::map<std::pair<const void*, size_t>, int> cache;            // one occupancy query per kernel instance and LDS size
+        const auto key = std::make_pair((const void*)kernel, lds);
+        auto it = cache.find(key);
+        if (it == cache.end()) {
+            int n = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, KNP_HALO_BLK, lds) != hipSuccess || n < 1) n = 2;
+            it = cache.emplace(key, n).first;
+        }
+        per_cu = it->second;
+    }
     if (per_cu < 1) per_cu = 1;
     const int64_t nq = halo_queues();
     int64_t g = std::min<int64_t>(((nb + nq - 1) / nq) * nq, (int64_t)per_cu * ncu);
