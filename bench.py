@@ -147,6 +147,18 @@ def main():
     from knpemidg import _abi as A
 
     t_setup = time.perf_counter()
+    if world > 1:
+        # a peer exchange that never completes (the multi-GPU path has only ever run on one GPU) must not hang the node: leave with an
+        # error instead of waiting for the caller's limit
+        import threading
+        limit = float(os.environ.get("KNP_BENCH_WATCHDOG_S", "900"))
+
+        def _abort():
+            print("[bench] rank %d: no result after %.0f s -- aborting (KNP_BENCH_WATCHDOG_S)" % (rank, limit), file=sys.stderr, flush=True)
+            os._exit(3)
+        wd = threading.Timer(limit, _abort)
+        wd.daemon = True
+        wd.start()
 
     def progress(msg):
         # setup of the larger meshes takes minutes of host work (mesh tables, AMG hierarchies): keep stderr alive
