@@ -98,43 +98,74 @@ struct VecDims {
 // op codes
 enum { OP_CG_INIT = 1, OP_CG_ALPHA, OP_CG_BETA, OP_BI_INIT, OP_BI_ALPHA, OP_BI_OMEGA, OP_BI_RHO, OP_SUM_ONLY };
 
-__device__ void scalar_op(int op, int s, const double* red, double* scal, int* status, double rtol, double atol, int min_it);
+__device__ void scalar_op(int op, double* S, const double* R, int* flag, int* iter, double rtol, double atol, int min_it);
 
 // op > 0: the block's thread 0 also runs the scalar recurrence of its system (single-GPU: saves one launch per reduction
-// point; with a communicator the all-reduce sits between the two and k_scalar_op runs separately)
-__global__ void k_reduce(const double* __restrict__ partial, int64_t nblocks, int nsys, int nred, double* red, int op, double* scal,
-                         int* status, double rtol, double atol, int min_it) {
+// point; with a communicator the all-reduce sits between the two and k_scalar_op runs separately).
+// Eight partial rows per thread are in flight at a time: with one row per loop trip the 15 trips of the r=2 mesh were 15 dependent
+// L2 round trips (11 us for a kernel that moves 250 KB).
+#define KNP_REDUCE_BLOCK 1024
+template <int NR>
+__global__ __launch_bounds__(KNP_REDUCE_BLOCK) void k_reduce(const double* __restrict__ partial, int64_t nblocks, int nsys, double* red, int op,
+                                                             double* scal, int* status, double rtol, double atol, int min_it) {
     // one block per system; deterministic order
     const int s = blockIdx.x;
-    __shared__ double lds[KNP_BLOCK / 64][KNP_MAX_RED];
-    double acc[KNP_MAX_RED];
+    __shared__ double lds[KNP_REDUCE_BLOCK / 64][NR];
+    // thread 0 runs the scalar recurrence at the end: its operands travel with the partial sums instead of behind them
+    double S[KS_N];
+    int flag = 0, iter = 0;
+    if (threadIdx.x == 0 && op > 0) {
 #pragma unroll
-    for (int r = 0; r < KNP_MAX_RED; ++r) acc[r] = 0.0;
-    for (int64_t b = threadIdx.x; b < nblocks; b += blockDim.x) {
-        const double* p = partial + (b * nsys + s) * KNP_MAX_RED;
-        for (int r = 0; r < nred; ++r) acc[r] += p[r];
+        for (int i = 0; i < KS_N; ++i) S[i] = scal[s * KS_N + i];
+        flag = status[2 * s];
+        iter = status[2 * s + 1];
+    }
+    double acc[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) acc[r] = 0.0;
+    for (int64_t b0 = threadIdx.x; b0 < nblocks; b0 += 4 * KNP_REDUCE_BLOCK) {
+        double v[4][NR];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t b = b0 + (int64_t)u * KNP_REDUCE_BLOCK;
+            const double* p = partial + (b * nsys + s) * KNP_MAX_RED;
+#pragma unroll
+            for (int r = 0; r < NR; ++r) v[u][r] = b < nblocks ? p[r] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int r = 0; r < NR; ++r) acc[r] += v[u][r];
     }
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    for (int r = 0; r < nred; ++r) {
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
         const double v = wave_sum(acc[r]);
         if (lane == 0) lds[wv][r] = v;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int r = 0; r < nred; ++r) {
+        double R[KNP_MAX_RED];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
             double v = lds[0][r];
-            for (int w = 1; w < KNP_BLOCK / 64; ++w) v += lds[w][r];
+#pragma unroll
+            for (int w = 1; w < KNP_REDUCE_BLOCK / 64; ++w) v += lds[w][r];
+            R[r] = v;
             red[s * KNP_MAX_RED + r] = v;
         }
-        if (op > 0) scalar_op(op, s, red, scal, status, rtol, atol, min_it);
+        if (op > 0) {
+            scalar_op(op, S, R, &flag, &iter, rtol, atol, min_it);
+#pragma unroll
+            for (int i = 0; i < KS_N; ++i) scal[s * KS_N + i] = S[i];
+            status[2 * s] = flag;
+            status[2 * s + 1] = iter;
+        }
     }
 }
 
-__device__ void scalar_op(int op, int s, const double* red, double* scal, int* status, double rtol, double atol, int min_it) {
-    double* S = scal + s * KS_N;
-    const double* R = red + s * KNP_MAX_RED;
-    int* flag = status + 2 * s;
-    int* iter = status + 2 * s + 1;
+// S: the system's KS_N scalars, R: its reduced sums, flag / iter: its two status words (global memory or local copies)
+__device__ void scalar_op(int op, double* S, const double* R, int* flag, int* iter, double rtol, double atol, int min_it) {
     if (op != OP_CG_INIT && op != OP_BI_INIT && *flag) return;
     switch (op) {
         case OP_CG_INIT: {              // R: rz, zz, (Minv b).(Minv b)
@@ -193,7 +224,8 @@ __device__ void scalar_op(int op, int s, const double* red, double* scal, int* s
 
 __global__ void k_scalar_op(int op, int nsys, const double* __restrict__ red, double* __restrict__ scal, int* __restrict__ status,
                             double rtol, double atol, int min_it) {
-    if ((int)threadIdx.x < nsys) scalar_op(op, threadIdx.x, red, scal, status, rtol, atol, min_it);
+    const int s = threadIdx.x;
+    if (s < nsys) scalar_op(op, scal + s * KS_N, red + s * KNP_MAX_RED, status + 2 * s, status + 2 * s + 1, rtol, atol, min_it);
 }
 
 // ---- PCG kernels ----------------------------------------------------------------------------
@@ -536,8 +568,13 @@ int max_abs_diff(knp_ctx* c, const double* a, const double* b, int nsys, double*
 static int finalize(knp_ctx* c, int op, int nsys, int nred, double rtol, double atol, int min_it) {
     const int64_t nb = grid_for(c->m.nc_owned);
     double* red = c->scal + KNP_MAX_SYS * KS_N;
-    hipLaunchKernelGGL(k_reduce, dim3(nsys), dim3(KNP_BLOCK), 0, c->stream, c->partial, nb, nsys, nred, red, c->dist ? 0 : op, c->scal,
-                       c->status, rtol, atol, min_it);
+    const int dop = c->dist ? 0 : op;
+    switch (nred) {
+        case 1: hipLaunchKernelGGL(k_reduce<1>, dim3(nsys), dim3(KNP_REDUCE_BLOCK), 0, c->stream, c->partial, nb, nsys, red, dop, c->scal, c->status, rtol, atol, min_it); break;
+        case 2: hipLaunchKernelGGL(k_reduce<2>, dim3(nsys), dim3(KNP_REDUCE_BLOCK), 0, c->stream, c->partial, nb, nsys, red, dop, c->scal, c->status, rtol, atol, min_it); break;
+        case 3: hipLaunchKernelGGL(k_reduce<3>, dim3(nsys), dim3(KNP_REDUCE_BLOCK), 0, c->stream, c->partial, nb, nsys, red, dop, c->scal, c->status, rtol, atol, min_it); break;
+        default: c->err = "finalize: unsupported number of partial sums"; return -1;
+    }
     if (c->dist) {
         int rc = allreduce_red(c, red, nsys * KNP_MAX_RED);
         if (rc) return rc;
