@@ -403,6 +403,42 @@ def _coarse_pseudo_inverse(A, Bnull):
     return (0.5 * (Pi + Pi.T)).astype(np.float32).astype(np.float64)
 
 
+def build_knp_groups(cspace, cspace2, sub_tags, D_subs, dt, level0_degree):
+    """Host part of the KNP preconditioner setup (reference: BoomerAMG on AA_knp, solver.py:688, 767): per species (or per group
+    of species with close diffusion coefficients) the conforming operator  1/dt M + D_k K  (symmetric part; the drift enters only
+    the Krylov operator) and its smoothed-aggregation hierarchy.  cspace2: the conforming P2 space for degree 2, else None.
+    D_subs: one {cell tag: D} dict per solved species.  Returns [(members, levels)].  Pure host code: runs in the solver's
+    process or in its helper process (knpemidg/setup_worker.py)."""
+    import os
+    tags = np.asarray(sub_tags)
+    nc = len(tags)
+    Dk = []
+    for d in D_subs:
+        q = np.zeros(nc, dtype=np.float64)
+        for key, value in d.items():
+            q[tags == int(key)] = float(value)
+        Dk.append(q)
+    # species whose diffusion coefficients differ by < 25 % share one hierarchy built from the mean coefficient (it only
+    # preconditions): one chain of V-cycle kernels then carries all species as right-hand-side columns instead of one
+    # concurrent chain per species
+    pos = Dk[0] > 0
+    shared = (len(Dk) > 1 and os.environ.get("KNP_AMG_SHARED", "1") == "1"
+              and all(np.all(np.abs(D[pos] / Dk[0][pos] - 1.0) < 0.25) and np.all((D > 0) == pos) for D in Dk[1:]))
+    groups = [(list(range(len(Dk))), np.mean(Dk, axis=0))] if shared else [([k], D) for k, D in enumerate(Dk)]
+    psmooth = int(os.environ.get("KNP_AMG_PSMOOTH_KNP", 2))
+    out = []
+    for members, D in groups:
+        mass = np.full(nc, 1.0 / float(dt))
+        if cspace2 is None:
+            Ac = cspace.stiffness(D, mass_coef=mass)
+            levels = build_hierarchy(Ac, psmooth=psmooth, level0_degree=int(os.environ.get("KNP_AMG_DEGREE0_KNP", level0_degree)))
+        else:
+            Ac = cspace2.stiffness(D, mass_coef=mass)
+            levels = build_hierarchy(Ac, psmooth=psmooth, top_interp=cspace2.interp)
+        out.append((members, levels))
+    return out
+
+
 def cheb_coefficients(rho, degree, lower):
     """Chebyshev polynomial smoother on D^-1 A for eigenvalues in [lower*rho, rho] (Saad, Alg. 12.1)."""
     lmax, lmin = rho, lower * rho

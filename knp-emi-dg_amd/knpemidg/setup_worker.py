@@ -1,0 +1,101 @@
+"""Helper process of the preconditioner setup: builds the KNP hierarchies (reference: BoomerAMG on AA_knp, solver.py:688, 767)
+while the parent process creates the device context and builds the EMI hierarchy.
+
+Why a process: two host threads building hierarchies side by side are SLOWER than one after the other (numpy's short GIL-holding
+calls convoy and the threaded LAPACK / sparse-product pools oversubscribe the cores: 0.90 s serial vs 1.44 s threaded on the r=1
+mesh).  The helper never touches the GPU (the device list is hidden from it) and is started as an ordinary child process.
+
+protocol: one pickled job on stdin -> one pickled {"groups": [(members, levels)]} or {"error": text} on stdout."""
+import os
+import pickle
+import sys
+import types
+
+
+def mesh_stub(coords, cells, facet_cells):
+    """The attributes of a Mesh that the conforming spaces of the KNP operators read (no membrane term: no facet geometry)."""
+    m = types.SimpleNamespace(coords=coords, cells=cells, facet_cells=facet_cells, gdim=coords.shape[1])
+    m.num_cells = lambda: cells.shape[0]
+    return m
+
+
+def job_from_solver(gmesh, sub_tags, facet_tags, membrane_tags, degree, D_subs, dt, level0_degree):
+    return {"coords": gmesh.coords, "cells": gmesh.cells, "facet_cells": gmesh.facet_cells, "sub_tags": sub_tags, "facet_tags": facet_tags,
+            "membrane_tags": list(membrane_tags), "degree": int(degree), "D_subs": [dict((int(k), float(v)) for k, v in d.items()) for d in D_subs],
+            "dt": float(dt), "level0_degree": int(level0_degree)}
+
+
+def run(job):
+    from knpemidg import amg
+    mesh = mesh_stub(job["coords"], job["cells"], job["facet_cells"])
+    cs = amg.ConformingSpace(mesh, job["facet_tags"], job["membrane_tags"])
+    cs2 = amg.ConformingSpaceP2(cs) if job["degree"] != 1 else None
+    return amg.build_knp_groups(cs, cs2, job["sub_tags"], job["D_subs"], job["dt"], job["level0_degree"])
+
+
+def main():
+    out = sys.stdout.buffer
+    sys.stdout = sys.stderr                       # nothing but the result may reach the pipe
+    try:
+        job = pickle.load(sys.stdin.buffer)
+        res = {"groups": run(job)}
+    except BaseException as e:                    # reported to the parent, which falls back to building in-process
+        import traceback
+        res = {"error": "%s\n%s" % (e, traceback.format_exc())}
+    pickle.dump(res, out, protocol=pickle.HIGHEST_PROTOCOL)
+    out.flush()
+
+
+def start(job):
+    """Launch the helper and hand it the job from a feeder thread (pipe I/O releases the GIL).  Returns a handle for collect()."""
+    import subprocess
+    import threading
+    env = dict(os.environ)
+    pkg_parent = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env["PYTHONPATH"] = pkg_parent + os.pathsep + env.get("PYTHONPATH", "")
+    for k in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        env[k] = ""                               # host work only
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    proc = subprocess.Popen([sys.executable, "-m", "knpemidg.setup_worker"], stdin=subprocess.PIPE, stdout=subprocess.PIPE, env=env)
+    handle = {"proc": proc, "result": None}
+
+    def feed():
+        try:
+            pickle.dump(job, proc.stdin, protocol=pickle.HIGHEST_PROTOCOL)
+            proc.stdin.close()
+            handle["result"] = pickle.load(proc.stdout)
+        except BaseException as e:
+            handle["result"] = {"error": "helper process: %r" % (e,)}
+        finally:
+            try:
+                proc.stdout.close()
+            except OSError:
+                pass
+            proc.wait()
+    th = threading.Thread(target=feed, name="knp-amg-helper-io", daemon=True)
+    th.start()
+    handle["thread"] = th
+    return handle
+
+
+def collect(handle):
+    """Groups built by the helper, or None (with the reason on stderr) when it failed."""
+    handle["thread"].join()
+    res = handle["result"] or {"error": "no result"}
+    if "groups" in res:
+        return res["groups"]
+    print("[knpemidg] KNP hierarchy helper failed, building in-process: %s" % res.get("error", "?").splitlines()[0], file=sys.stderr)
+    return None
+
+
+def cancel(handle):
+    try:
+        handle["proc"].kill()
+    except OSError:
+        pass
+    handle["thread"].join(timeout=5)
+
+
+if __name__ == "__main__":
+    main()

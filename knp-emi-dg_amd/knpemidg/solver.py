@@ -203,6 +203,8 @@ class Solver:
             membrane_tags = list(self.lm_tags) if self.mms is not None else [m['ode'].tag for m in self.mem_models]
         self.membrane_tags = list(membrane_tags)
         nc = self.mesh.num_cells()
+        if self.mms is None:
+            self._start_knp_helper()
         self.dev = _abi.Device(self.mesh, self.subdomains.array(), self.surfaces.array(), self.membrane_tags,
                                len(self.ion_list), degree=self.degree_knp, device=self.device_index,
                                nc_owned=getattr(self, "nc_owned", None))
@@ -257,20 +259,6 @@ class Solver:
         # direct_emi (MUMPS in the reference, solver.py:412-422) is emulated by a tightly converged PCG with the plain
         # block-Jacobi preconditioner: it stays SPD to rounding for any coefficient contrast (the MMS problem couples
         # the membrane with C_phi = 1e10), which a V-cycle does not
-        if self.use_amg and not self.direct_knp and os.environ.get("KNP_AMG_SERIAL_SETUP", "0") != "1":
-            # the KNP hierarchy depends only on the mesh, D_k and dt: build it on a host thread while this thread builds the
-            # EMI hierarchy (LAPACK and the library's threaded sparse products release the GIL); setup_solver_knp joins
-            import threading
-            self._amg_global()
-            self._knp_build = {}
-
-            def work():
-                try:
-                    self._knp_build["groups"] = self._build_amg_knp()
-                except BaseException as e:          # re-raised by setup_solver_knp
-                    self._knp_build["error"] = e
-            self._knp_thread = threading.Thread(target=work, name="knp-amg-setup")
-            self._knp_thread.start()
         if self.use_amg and not self.direct_emi:
             self._setup_amg_emi()
         return
@@ -347,7 +335,16 @@ class Solver:
     def setup_solver_knp(self):
         if self.use_amg and not self.direct_knp:
             self._setup_amg_knp()
+        else:
+            self._drop_knp_helper()
         return
+
+    def _drop_knp_helper(self):
+        helper = getattr(self, "_knp_helper", None)
+        if helper is not None:
+            from knpemidg import setup_worker
+            self._knp_helper = None
+            setup_worker.cancel(helper[0])
 
     def _amg_global(self):
         """(mesh, subdomains, surfaces) the conforming hierarchy is built on: the global mesh when this solver
@@ -373,47 +370,46 @@ class Solver:
             q[tags == int(key)] = float(value)
         return q
 
+    def _knp_level0_degree(self):
+        # one GPU: one Jacobi step on the finest conforming level.  With a communicator the hierarchy is replicated and the
+        # restricted residual is all-reduced: a transfer-only finest level lets that happen on level 1 (6.5x fewer bytes, no
+        # replicated level-0 SpMVs) for ~20 % more iterations
+        return 0 if getattr(self, "local_mesh", None) is not None and getattr(self.dev, "nranks", 1) > 1 else 1
+
+    def _start_knp_helper(self):
+        """KNP hierarchies depend only on the mesh, D_k and dt: a helper process builds them while this process creates the device
+        context and the EMI hierarchy (knpemidg/setup_worker.py: why a process and not a thread).  KNP_AMG_SERIAL_SETUP=1 or a
+        failure of the helper: built in this process by setup_solver_knp."""
+        if not self.use_amg or os.environ.get("KNP_AMG_SERIAL_SETUP", "0") == "1" or getattr(self, "_knp_helper", None) is not None:
+            return
+        from knpemidg import setup_worker
+        g = getattr(self, "global_mesh_tuple", None) or (self.mesh, self.subdomains, self.surfaces)
+        d0 = 0 if getattr(self, "global_mesh_tuple", None) is not None and int(os.environ.get("WORLD_SIZE", "1")) > 1 else 1
+        job = setup_worker.job_from_solver(g[0], g[1].array(), g[2].array(), self.membrane_tags, self.degree_knp,
+                                           [ion['D_sub'] for ion in self.ion_list[:-1]], _f(self.params.dt), d0)
+        self._knp_helper = (setup_worker.start(job), d0)
+
     def _build_amg_knp(self):
-        """Host part of the KNP preconditioner setup (reference: BoomerAMG on AA_knp, solver.py:688, 767): per species (or
-        per group of species with close diffusion coefficients) the conforming operator  1/dt M + D_k K  (symmetric part; the
-        drift enters only the Krylov operator) and its smoothed-aggregation hierarchy.  Returns [(members, levels)]."""
+        """[(members, levels)] of the KNP preconditioner (amg.build_knp_groups), built in this process."""
         from knpemidg import amg
         gmesh, gsub, gsurf = self._amg_global()
-        nc = gmesh.num_cells()
-        Dk = [self._by_tag(ion['D_sub'], gsub) for ion in self.ion_list[:-1]]
-        # species whose diffusion coefficients differ by < 25 % share one hierarchy built from the mean coefficient (it
-        # only preconditions): one chain of V-cycle kernels then carries all species as right-hand-side columns instead
-        # of one concurrent chain per species
-        pos = Dk[0] > 0
-        shared = (len(Dk) > 1 and os.environ.get("KNP_AMG_SHARED", "1") == "1"
-                  and all(np.all(np.abs(D[pos] / Dk[0][pos] - 1.0) < 0.25) and np.all((D > 0) == pos) for D in Dk[1:]))
-        groups = [(list(range(len(Dk))), np.mean(Dk, axis=0))] if shared else [([k], D) for k, D in enumerate(Dk)]
-        out = []
-        for members, D in groups:
-            if self.degree_knp == 1:
-                Ac = self._cspace.stiffness(D, mass_coef=np.full(nc, 1.0 / _f(self.dt)))
-                # one GPU: one Jacobi step on the finest conforming level.  With a communicator the hierarchy is replicated and
-                # the restricted residual is all-reduced: a transfer-only finest level lets that happen on level 1 (6.5x fewer
-                # bytes, no replicated level-0 SpMVs) for ~20 % more iterations
-                d0 = 0 if getattr(self, "local_mesh", None) is not None and getattr(self.dev, "nranks", 1) > 1 else 1
-                levels = amg.build_hierarchy(Ac, psmooth=int(os.environ.get("KNP_AMG_PSMOOTH_KNP", 2)),
-                                             level0_degree=int(os.environ.get("KNP_AMG_DEGREE0_KNP", d0)))
-            else:
-                Ac = self._cspace2.stiffness(D, mass_coef=np.full(nc, 1.0 / _f(self.dt)))
-                levels = amg.build_hierarchy(Ac, psmooth=int(os.environ.get("KNP_AMG_PSMOOTH_KNP", 2)), top_interp=self._cspace2.interp)
-            out.append((members, levels))
-        return out
+        return amg.build_knp_groups(self._cspace, self._cspace2 if self.degree_knp != 1 else None, gsub.array(),
+                                    [ion['D_sub'] for ion in self.ion_list[:-1]], _f(self.dt), self._knp_level0_degree())
 
     def _setup_amg_knp(self):
         ts = time.perf_counter()
-        th = getattr(self, "_knp_thread", None)
-        if th is not None:
-            th.join()
-            self._knp_thread = None
-            if "error" in self._knp_build:
-                raise self._knp_build["error"]
-            groups = self._knp_build.pop("groups")
-        else:
+        self._amg_global()
+        groups = None
+        helper = getattr(self, "_knp_helper", None)
+        if helper is not None:
+            from knpemidg import setup_worker
+            self._knp_helper = None
+            handle, d0 = helper
+            if d0 == self._knp_level0_degree():
+                groups = setup_worker.collect(handle)
+            else:                                   # the helper was started with another guess of the communicator state
+                setup_worker.cancel(handle)
+        if groups is None:
             groups = self._build_amg_knp()
         for members, levels in groups:
             self.dev.amg_upload(1 + members[0], self._local_dg2cg(), levels, ncol=len(members))

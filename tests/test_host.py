@@ -309,3 +309,30 @@ def test_dolfin_xml_mesh_round_trip(tmp_path):
         s2 = mesh_io.read_dolfin_xml_meshfunction(m2, str(tmp_path / "sub.xml"))
         f2 = mesh_io.read_dolfin_xml_meshfunction(m2, str(tmp_path / "surf.xml"))
         assert np.array_equal(s2.array(), s.array()) and np.array_equal(f2.array(), f.array())
+
+
+@pytest.mark.parametrize("degree", [1, 2])
+def test_knp_hierarchy_helper_process_matches_in_process(degree):
+    """knpemidg/setup_worker.py: the helper process builds the same KNP hierarchies from the pickled job as the solver's process
+    does from its own mesh (levels, operators and smoother data bit for bit), and a failing helper reports instead of hanging."""
+    from common import small_3d
+    from knpemidg import amg, setup_worker
+    mesh, sub, surf = small_3d((8, 4, 4))
+    D_subs = [{0: 1.33e-9, 1: 1.33e-9}, {0: 1.96e-9, 1: 1.96e-9}]
+    cs = amg.ConformingSpace(mesh, surf.array(), [1])
+    cs2 = amg.ConformingSpaceP2(cs) if degree == 2 else None
+    ref = amg.build_knp_groups(cs, cs2, sub.array(), D_subs, 1e-4, 1)
+    handle = setup_worker.start(setup_worker.job_from_solver(mesh, sub.array(), surf.array(), [1], degree, D_subs, 1e-4, 1))
+    got = setup_worker.collect(handle)
+    assert got is not None and len(got) == len(ref)
+    for (m0, l0), (m1, l1) in zip(ref, got):
+        assert m0 == m1 and len(l0) == len(l1)
+        for a, b in zip(l0, l1):
+            assert a.A.shape == b.A.shape and (a.A != b.A).nnz == 0
+            for name in ("P", "R"):
+                pa, pb = getattr(a, name, None), getattr(b, name, None)
+                assert (pa is None) == (pb is None)
+                if pa is not None:
+                    assert (pa != pb).nnz == 0
+    bad = setup_worker.start({"coords": None})
+    assert setup_worker.collect(bad) is None
