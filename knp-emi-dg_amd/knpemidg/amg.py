@@ -403,6 +403,27 @@ def _coarse_pseudo_inverse(A, Bnull):
     return (0.5 * (Pi + Pi.T)).astype(np.float32).astype(np.float64)
 
 
+def build_emi_levels(cspace, cspace2, facet_tags, membrane_tags, kappa, C_phi):
+    """Host part of the EMI preconditioner setup (the reference builds BoomerAMG from BB_emi, solver.py:433, 505): conforming
+    operator from kappa ([nc, nd] nodal or [nc]) + the membrane coupling C_phi, and its smoothed-aggregation hierarchy.
+    Pure host code: runs in the solver's process (refreshes, distributed setup) or in its helper process (first build)."""
+    import os
+    mesh = cspace.mesh
+    mem = np.nonzero((mesh.facet_cells[:, 1] >= 0) & np.isin(np.asarray(facet_tags), list(membrane_tags)))[0]
+    psmooth = int(os.environ.get("KNP_AMG_PSMOOTH_EMI", 3))
+    if cspace2 is None:
+        Ac = cspace.stiffness(kappa, membrane=(mem, float(C_phi)))
+        # EMI: the weakly coupled, long and thin intracellular tubes need wide interpolation: three damped-Jacobi steps on the
+        # tentative prolongator (PCG iterations at r=2: 68 / 17 / 8 for 1 / 2 / 3 steps; on the conforming problem alone two
+        # steps lose mesh independence, 12 -> 24 from r=1 to r=2, three do not); no smoother on the finest conforming level
+        # (same iteration count with or without it: block-Jacobi on the DG space does that job)
+        return build_hierarchy(Ac, psmooth=psmooth, level0_degree=int(os.environ.get("KNP_AMG_DEGREE0_EMI", 0)))
+    # DG-P2: auxiliary space = conforming P2 (block-Jacobi over-weights continuous quadratics by the penalty factor); the
+    # conforming P1 space is its first coarse level, aggregation starts below
+    Ac = cspace2.stiffness(kappa, membrane=(mem, float(C_phi)))
+    return build_hierarchy(Ac, psmooth=psmooth, top_interp=cspace2.interp)
+
+
 def build_knp_groups(cspace, cspace2, sub_tags, D_subs, dt, level0_degree):
     """Host part of the KNP preconditioner setup (reference: BoomerAMG on AA_knp, solver.py:688, 767): per species (or per group
     of species with close diffusion coefficients) the conforming operator  1/dt M + D_k K  (symmetric part; the drift enters only

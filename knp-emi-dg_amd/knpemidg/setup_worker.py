@@ -1,5 +1,6 @@
-"""Helper process of the preconditioner setup: builds the KNP hierarchies (reference: BoomerAMG on AA_knp, solver.py:688, 767)
-while the parent process creates the device context and builds the EMI hierarchy.
+"""Helper processes of the preconditioner setup: one builds the KNP hierarchies (reference: BoomerAMG on AA_knp, solver.py:688, 767),
+one the first EMI hierarchy (BoomerAMG on BB_emi, solver.py:433, 505) from the initial state, while the parent process creates the
+device context.
 
 Why a process: two host threads building hierarchies side by side are SLOWER than one after the other (numpy's short GIL-holding
 calls convoy and the threaded LAPACK / sparse-product pools oversubscribe the cores: 0.90 s serial vs 1.44 s threaded on the r=1
@@ -12,11 +13,19 @@ import sys
 import types
 
 
-def mesh_stub(coords, cells, facet_cells):
-    """The attributes of a Mesh that the conforming spaces of the KNP operators read (no membrane term: no facet geometry)."""
-    m = types.SimpleNamespace(coords=coords, cells=cells, facet_cells=facet_cells, gdim=coords.shape[1])
+def mesh_stub(coords, cells, facet_cells, facets=None, facet_local=None):
+    """The attributes of a Mesh that the conforming spaces read (facets / facet_local: only the membrane term of the EMI operator)."""
+    m = types.SimpleNamespace(coords=coords, cells=cells, facet_cells=facet_cells, facets=facets, facet_local=facet_local,
+                              gdim=coords.shape[1])
     m.num_cells = lambda: cells.shape[0]
     return m
+
+
+def emi_job(mesh, facet_tags, membrane_tags, degree, kappa, C_phi):
+    """kappa: [nc, nd] nodal values the hierarchy is built from (the initial state)."""
+    return {"kind": "emi", "coords": mesh.coords, "cells": mesh.cells, "facet_cells": mesh.facet_cells, "facets": mesh.facets,
+            "facet_local": mesh.facet_local, "facet_tags": facet_tags, "membrane_tags": list(membrane_tags), "degree": int(degree),
+            "kappa": kappa, "C_phi": float(C_phi)}
 
 
 def job_from_solver(gmesh, sub_tags, facet_tags, membrane_tags, degree, D_subs, dt, level0_degree):
@@ -27,9 +36,12 @@ def job_from_solver(gmesh, sub_tags, facet_tags, membrane_tags, degree, D_subs, 
 
 def run(job):
     from knpemidg import amg
-    mesh = mesh_stub(job["coords"], job["cells"], job["facet_cells"])
+    mesh = mesh_stub(job["coords"], job["cells"], job["facet_cells"], job.get("facets"), job.get("facet_local"))
     cs = amg.ConformingSpace(mesh, job["facet_tags"], job["membrane_tags"])
     cs2 = amg.ConformingSpaceP2(cs) if job["degree"] != 1 else None
+    if job.get("kind") == "emi":
+        levels = amg.build_emi_levels(cs, cs2, job["facet_tags"], job["membrane_tags"], job["kappa"], job["C_phi"])
+        return {"levels": levels, "dof": (cs2 if cs2 is not None else cs).dof}
     return amg.build_knp_groups(cs, cs2, job["sub_tags"], job["D_subs"], job["dt"], job["level0_degree"])
 
 

@@ -205,6 +205,7 @@ class Solver:
         nc = self.mesh.num_cells()
         if self.mms is None:
             self._start_knp_helper()
+            self._start_emi_helper()
         self.dev = _abi.Device(self.mesh, self.subdomains.array(), self.surfaces.array(), self.membrane_tags,
                                len(self.ion_list), degree=self.degree_knp, device=self.device_index,
                                nc_owned=getattr(self, "nc_owned", None))
@@ -261,7 +262,36 @@ class Solver:
         # the membrane with C_phi = 1e10), which a V-cycle does not
         if self.use_amg and not self.direct_emi:
             self._setup_amg_emi()
+        else:
+            self._drop_emi_helper()
         return
+
+    def _host_initial_kappa(self):
+        """kappa = F psi sum_k z_k^2 D_k c_k of the initial state, nodal [nc, nd] (what k_kappa computes on the device)."""
+        nc = self.mesh.num_cells()
+        kappa = np.zeros((nc, self.nd))
+        for idx, ion in enumerate(self.ion_list):
+            c = self._init_c_elim if idx == len(self.ion_list) - 1 else self._init_c[idx]
+            kappa += _f(self.F) * float(ion['z']) ** 2 * self.psi * np.asarray(ion['D'], dtype=np.float64)[:, None] * c
+        return kappa
+
+    def _start_emi_helper(self):
+        """First EMI hierarchy (from the initial state) in a helper process, next to the KNP one (knpemidg/setup_worker.py).
+        Not for partitions (their hierarchy is the global one) and not for manufactured solutions (direct_emi)."""
+        if (not self.use_amg or os.environ.get("KNP_AMG_SERIAL_SETUP", "0") == "1" or getattr(self, "_emi_helper", None) is not None
+                or getattr(self, "global_mesh_tuple", None) is not None or not hasattr(self, "_init_c")):
+            return
+        from knpemidg import setup_worker
+        kappa = self._host_initial_kappa()
+        job = setup_worker.emi_job(self.mesh, self.surfaces.array(), self.membrane_tags, self.degree_knp, kappa, _f(self.params.C_phi))
+        self._emi_helper = (setup_worker.start(job), kappa)
+
+    def _drop_emi_helper(self):
+        helper = getattr(self, "_emi_helper", None)
+        if helper is not None:
+            from knpemidg import setup_worker
+            self._emi_helper = None
+            setup_worker.cancel(helper[0])
 
     def _setup_amg_emi(self):
         """Preconditioner setup (the reference builds BoomerAMG from BB_emi, solver.py:433, 505): conforming
@@ -270,37 +300,43 @@ class Solver:
         from knpemidg import amg
         ts = time.perf_counter()
         dev = self.dev
-        gmesh, gsub, gsurf = self._amg_global()
-        if gmesh is self.mesh:
+        levels = dg2cg = None
+        helper = getattr(self, "_emi_helper", None)
+        if helper is not None:
+            # first build: collected from the helper process if the device state still is the initial state it was given
+            from knpemidg import setup_worker
+            self._emi_helper = None
+            handle, kappa_h = helper
             dev.update_kappa()
             kappa = dev.download(_abi.F_KAPPA).reshape(self.mesh.num_cells(), self.nd)
-            self._amg_kappa0 = kappa.ravel().copy()          # what the hierarchy was built from (refresh policy)
-        else:
-            # distributed: every rank builds the SAME global hierarchy from the tag-wise initial state (no
-            # communication; the preconditioner is lagged anyway)
-            kappa = np.zeros(gmesh.num_cells())
-            for ion in self.ion_list:
-                if ion['c_init_sub_type'] != 'constant':
-                    raise NotImplementedError("distributed AMG setup needs tag-wise constant initial concentrations")
-                D = self._by_tag(ion['D_sub'], gsub)
-                c0 = self._by_tag(ion['c_init_sub'], gsub)
-                kappa += _f(self.F) * float(ion['z']) ** 2 * self.psi * D * c0
-        ft = gsurf.array()
-        mem = np.nonzero((gmesh.facet_cells[:, 1] >= 0) & np.isin(ft, self.membrane_tags))[0]
-        if self.degree_knp == 1:
-            Ac = self._cspace.stiffness(kappa, membrane=(mem, _f(self.C_phi)))
-            # EMI: the weakly coupled, long and thin intracellular tubes need wide interpolation: three damped-Jacobi steps on
-            # the tentative prolongator (PCG iterations at r=2: 68 / 17 / 8 for 1 / 2 / 3 steps; on the conforming problem
-            # alone two steps lose mesh independence, 12 -> 24 from r=1 to r=2, three do not); no smoother on the finest
-            # conforming level (same iteration count with or without it: block-Jacobi on the DG space does that job)
-            levels = amg.build_hierarchy(Ac, psmooth=int(os.environ.get("KNP_AMG_PSMOOTH_EMI", 3)),
-                                         level0_degree=int(os.environ.get("KNP_AMG_DEGREE0_EMI", 0)))
-        else:
-            # DG-P2: auxiliary space = conforming P2 (block-Jacobi over-weights continuous quadratics by the penalty
-            # factor); the conforming P1 space is its first coarse level, aggregation starts below
-            Ac = self._cspace2.stiffness(kappa, membrane=(mem, _f(self.C_phi)))
-            levels = amg.build_hierarchy(Ac, psmooth=int(os.environ.get("KNP_AMG_PSMOOTH_EMI", 3)), top_interp=self._cspace2.interp)
-        dev.amg_upload(0, self._local_dg2cg(), levels)
+            if np.allclose(kappa, kappa_h, rtol=1e-8, atol=0.0):
+                res = setup_worker.collect(handle)
+                if res is not None:
+                    levels, dg2cg = res["levels"], res["dof"]
+                    self._amg_kappa0 = kappa.ravel().copy()
+                    self._dg2cg_helper = dg2cg
+            else:
+                setup_worker.cancel(handle)
+        if levels is None:
+            gmesh, gsub, gsurf = self._amg_global()
+            if gmesh is self.mesh:
+                dev.update_kappa()
+                kappa = dev.download(_abi.F_KAPPA).reshape(self.mesh.num_cells(), self.nd)
+                self._amg_kappa0 = kappa.ravel().copy()          # what the hierarchy was built from (refresh policy)
+            else:
+                # distributed: every rank builds the SAME global hierarchy from the tag-wise initial state (no
+                # communication; the preconditioner is lagged anyway)
+                kappa = np.zeros(gmesh.num_cells())
+                for ion in self.ion_list:
+                    if ion['c_init_sub_type'] != 'constant':
+                        raise NotImplementedError("distributed AMG setup needs tag-wise constant initial concentrations")
+                    D = self._by_tag(ion['D_sub'], gsub)
+                    c0 = self._by_tag(ion['c_init_sub'], gsub)
+                    kappa += _f(self.F) * float(ion['z']) ** 2 * self.psi * D * c0
+            levels = amg.build_emi_levels(self._cspace, self._cspace2 if self.degree_knp != 1 else None, gsurf.array(),
+                                          self.membrane_tags, kappa, _f(self.C_phi))
+            dg2cg = self._local_dg2cg()
+        dev.amg_upload(0, dg2cg, levels)
         self.amg_setup_timer = time.perf_counter() - ts
         if self.verbose:
             print(" AMG(EMI) levels:", [lv.A.shape[0] for lv in levels], "setup %.2f s" % self.amg_setup_timer)
@@ -359,6 +395,9 @@ class Solver:
 
     def _local_dg2cg(self):
         loc = getattr(self, "local_mesh", None)
+        if loc is None and not hasattr(self, "_cspace") and getattr(self, "_dg2cg_helper", None) is not None:
+            return self._dg2cg_helper             # spaces built by the helper process only (same deterministic numbering)
+        self._amg_global()
         dof = self._cspace.dof if self.degree_knp == 1 else self._cspace2.dof
         return dof if loc is None else dof[loc.cells_global]
 
@@ -398,7 +437,6 @@ class Solver:
 
     def _setup_amg_knp(self):
         ts = time.perf_counter()
-        self._amg_global()
         groups = None
         helper = getattr(self, "_knp_helper", None)
         if helper is not None:

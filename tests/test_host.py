@@ -334,5 +334,15 @@ def test_knp_hierarchy_helper_process_matches_in_process(degree):
                 assert (pa is None) == (pb is None)
                 if pa is not None:
                     assert (pa != pb).nnz == 0
+    # the first EMI hierarchy the same way
+    rng = np.random.default_rng(3)
+    nd = 4 if degree == 1 else 10
+    kappa = rng.uniform(0.5, 1.5, size=(mesh.num_cells(), nd))
+    ref_e = amg.build_emi_levels(cs, cs2, surf.array(), [1], kappa, 2.0e2)
+    res = setup_worker.collect(setup_worker.start(setup_worker.emi_job(mesh, surf.array(), [1], degree, kappa, 2.0e2)))
+    assert res is not None and len(res["levels"]) == len(ref_e)
+    assert np.array_equal(res["dof"], (cs2 if cs2 is not None else cs).dof)
+    for a, b in zip(ref_e, res["levels"]):
+        assert a.A.shape == b.A.shape and (a.A != b.A).nnz == 0
     bad = setup_worker.start({"coords": None})
     assert setup_worker.collect(bad) is None
