@@ -21,7 +21,7 @@ if h5:
     H = H5File(h5[0])
     names = sorted(H.datasets)
     print("datasets:", len(names), "first:", names[:6], "last:", names[-3:])
-    pots = [n for n in names if n.startswith("potential/")]
+    pots = [n for n in names if n.startswith("potential/vector_")]
     last = max(pots, key=lambda n: int(n.rsplit("_", 1)[1]))
     phi = np.asarray(H.read(last)).ravel()
     print(last, "min %.6e max %.6e finite %s" % (phi.min(), phi.max(), np.isfinite(phi).all()))
