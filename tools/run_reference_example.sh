@@ -26,7 +26,13 @@ if h5:
     phi = np.asarray(H.read(last)).ravel()
     print(last, "min %.6e max %.6e finite %s" % (phi.min(), phi.max(), np.isfinite(phi).all()))
 for f in glob.glob("results/data/3D/solver/*niter*") + glob.glob("results/data/3D/*niter*"):
-    a = np.loadtxt(f)
-    print(" ", os.path.basename(f), "n=%d mean %.2f max %d" % (a.size, a.mean(), a.max()))
+    vals = []
+    for line in open(f):
+        try:
+            vals.append(float(line.split()[-1]))
+        except (ValueError, IndexError):
+            pass
+    if vals:
+        print(" ", os.path.basename(f), "n=%d mean %.2f max %d" % (len(vals), np.mean(vals), max(vals)))
 PY
 cat "$GRAFT_REPO_ROOT/gpurun_out/run3d_r$r.log"
