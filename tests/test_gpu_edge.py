@@ -105,6 +105,8 @@ def test_bad_arguments_are_rejected(hip_lib):
         dev.set_params(0.02, 0.0, 96485, 8.314, 300, 200, 40, 40, [1, -1, 1], np.ones((3, dev.nc)))     # dt = 0
     with pytest.raises(A.KnpError):
         dev.set_params(0.02, 1e-4, 96485, 8.314, 300, 200, 40, 40, [1, 0, 1], np.ones((3, dev.nc)))     # z = 0
+    assert dev.apply_variant(0) == 0 and dev.apply_variant(1) == 0      # 2D: coordinate-path kernels
+    assert dev.apply_variant(2) < 0                                     # no such operator
     dev.close()
     bad = m.facet_cells.copy()
     bad[0, 0] = m.num_cells() + 7
