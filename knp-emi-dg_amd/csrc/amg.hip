@@ -43,12 +43,15 @@ static double g4_limit() {
     return v;
 }
 
-// partial dot products of CSR row `row` with NC vectors x + j * xstride over this lane's entries (lane, lane+G, ...).  The loop is
-// unrolled so that 2 (col, val) pairs x NC gathers are in flight per lane: these kernels are latency-bound (a row has 15..100
-// entries), not bandwidth-bound.  NC = 2 carries both KNP species of a shared hierarchy through ONE pass over the matrix
-// (indices and fp32 values are read once instead of once per column).
+// Level vectors carry NC right-hand-side columns INTERLEAVED ([n][NC]; further column groups behind each other): a gather of entry
+// `col` fetches both species' values from one 16-byte location.  With the columns stored one behind the other every gather pulled
+// its own 64-byte sector out of L2 for 8 useful bytes, and the two-column kernels were bound by exactly that: k_csr-type kernels
+// cost 24 bytes of useful data per entry but ran at the L2's sector rate (a 28-entry-per-row product took 1.9x the time of a
+// 15-entry one -- linear in the entries, not in the launches; profiles/README.md, round 2).
+// Partial dot products of CSR row `row` with the NC interleaved columns of x over this lane's entries (lane, lane+G, ...); the loop
+// is unrolled so that U (col, val) pairs are in flight per lane.
 template <int G, int NC>
-__device__ __forceinline__ void row_dot(const CsrDev& A, int64_t row, int lane, const double* __restrict__ x, int64_t xstride, double* out) {
+__device__ __forceinline__ void row_dot(const CsrDev& A, int64_t row, int lane, const double* __restrict__ x, double* out) {
     constexpr int U = NC == 1 ? 4 : 2;                    // (col, val) pairs in flight per lane
     double s[U][NC];
 #pragma unroll
@@ -66,7 +69,7 @@ __device__ __forceinline__ void row_dot(const CsrDev& A, int64_t row, int lane, 
 #pragma unroll
             for (int u = 0; u < U; ++u)
 #pragma unroll
-                for (int j = 0; j < NC; ++j) s[u][j] = fma(vv[u], x[cc[u] + j * xstride], s[u][j]);
+                for (int j = 0; j < NC; ++j) s[u][j] = fma(vv[u], x[(int64_t)cc[u] * NC + j], s[u][j]);
         }
 #pragma unroll
         for (int u = 0; u < U - 1; ++u) {
@@ -74,7 +77,7 @@ __device__ __forceinline__ void row_dot(const CsrDev& A, int64_t row, int lane, 
                 const int c0 = A.col[k];
                 const double v0 = A.val[k];
 #pragma unroll
-                for (int j = 0; j < NC; ++j) s[u][j] = fma(v0, x[c0 + j * xstride], s[u][j]);
+                for (int j = 0; j < NC; ++j) s[u][j] = fma(v0, x[(int64_t)c0 * NC + j], s[u][j]);
                 k += G;
             }
         }
@@ -99,11 +102,11 @@ __global__ __launch_bounds__(256) void k_csr(CsrDev A, const double* __restrict_
     const int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) / G;
     const int lane = threadIdx.x % G;
     double s[NC];
-    row_dot<G, NC>(A, row, lane, x, A.ncols, s);
+    row_dot<G, NC>(A, row, lane, x, s);
     if (row < A.nrows && lane == 0) {
 #pragma unroll
         for (int j = 0; j < NC; ++j) {
-            const int64_t o = row + (int64_t)j * A.nrows;
+            const int64_t o = row * NC + j;
             if (MODE == 0) y[o] = s[j];
             else if (MODE == 1) y[o] = b[o] - s[j];
             else y[o] += s[j];
@@ -165,15 +168,15 @@ template <int MODE> void launch_csr(knp_ctx* c, const CsrDev& A, const double* x
 }
 
 // first Chebyshev update:  d = dinv r / theta ;  x = d (zero guess) or x += d
-__global__ void k_cheb_first(int64_t n, const double* __restrict__ dinv, const double* __restrict__ b, double inv_theta,
+__global__ void k_cheb_first(int64_t n, int nil, const double* __restrict__ dinv, const double* __restrict__ b, double inv_theta,
                              double* __restrict__ r, double* __restrict__ d, double* __restrict__ x) {
-    // zero initial guess: r = b ; d = dinv r / theta ; x = d
+    // zero initial guess: r = b ; d = dinv r / theta ; x = d.   grid.y = column group, nil interleaved columns per row
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int64_t o = (int64_t)blockIdx.y * n;
+    if (i >= n * nil) return;
+    const int64_t o = (int64_t)blockIdx.y * n * nil;
     b += o; r += o; d += o; x += o;
     const double bi = b[i];
-    const double v = dinv[i] * bi * inv_theta;
+    const double v = dinv[i / nil] * bi * inv_theta;
     r[i] = bi;
     d[i] = v;
     x[i] = v;
@@ -189,12 +192,12 @@ __global__ __launch_bounds__(256) void k_cheb_first_res(CsrDev A, const double* 
     const int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) / G;
     const int lane = threadIdx.x % G;
     double s[NC];
-    row_dot<G, NC>(A, row, lane, x, A.nrows, s);
+    row_dot<G, NC>(A, row, lane, x, s);
     if (row < A.nrows && lane == 0) {
         const double di = dinv[row];
 #pragma unroll
         for (int j = 0; j < NC; ++j) {
-            const int64_t q = row + (int64_t)j * A.nrows;
+            const int64_t q = row * NC + j;
             const double rn = b[q] - s[j];
             const double v = di * rn * inv_theta;
             r[q] = rn;
@@ -214,12 +217,12 @@ __global__ __launch_bounds__(256) void k_cheb_step(CsrDev A, const double* __res
     const int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) / G;
     const int lane = threadIdx.x % G;
     double s[NC];
-    row_dot<G, NC>(A, row, lane, din, A.nrows, s);
+    row_dot<G, NC>(A, row, lane, din, s);
     if (row < A.nrows && lane == 0) {
         const double di = dinv[row];
 #pragma unroll
         for (int j = 0; j < NC; ++j) {
-            const int64_t q = row + (int64_t)j * A.nrows;
+            const int64_t q = row * NC + j;
             const double rn = r[q] - s[j];
             const double dn = fma(c1, din[q], c2 * di * rn);
             r[q] = rn;
@@ -260,12 +263,12 @@ __global__ __launch_bounds__(256) void k_dense_mv(int n, const float* __restrict
 #pragma unroll
         for (int u = 0; u < 4; ++u)
 #pragma unroll
-            for (int j = 0; j < NC; ++j) s[u][j] = fma((double)m[u], b[(int64_t)j * n + k + 256 * u], s[u][j]);
+            for (int j = 0; j < NC; ++j) s[u][j] = fma((double)m[u], b[(int64_t)(k + 256 * u) * NC + j], s[u][j]);
     }
     for (; k < n; k += 256) {
         const double m = (double)Mr[k];
 #pragma unroll
-        for (int j = 0; j < NC; ++j) s[0][j] = fma(m, b[(int64_t)j * n + k], s[0][j]);
+        for (int j = 0; j < NC; ++j) s[0][j] = fma(m, b[(int64_t)k * NC + j], s[0][j]);
     }
 #pragma unroll
     for (int j = 0; j < NC; ++j) {
@@ -275,16 +278,16 @@ __global__ __launch_bounds__(256) void k_dense_mv(int n, const float* __restrict
         if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6][j] = v;
     }
     __syncthreads();
-    if ((int)threadIdx.x < NC) y[(int64_t)threadIdx.x * n + row] = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+    if ((int)threadIdx.x < NC) y[(int64_t)row * NC + threadIdx.x] = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
 }
 
 // rc[v] = sum over the DG dofs mapped to conforming dof v (CSR list, fixed order -> deterministic)
 // G lanes per conforming dof (a vertex is shared by ~24 tets); fixed summation tree -> deterministic
 template <int G>
 __global__ __launch_bounds__(256) void k_dg_restrict(int64_t ncg, const int32_t* __restrict__ ptr, const int32_t* __restrict__ idx,
-                                                     const double* __restrict__ r, double* __restrict__ rc, int64_t r_stride) {
+                                                     const double* __restrict__ r, double* __restrict__ rc, int64_t r_stride, int nil) {
     r += (int64_t)blockIdx.y * r_stride;
-    rc += (int64_t)blockIdx.y * ncg;
+    rc += (int64_t)(blockIdx.y / nil) * nil * ncg + (blockIdx.y % nil);          // column blockIdx.y of the interleaved level vector
     const int64_t v = ((int64_t)blockIdx.x * 256 + threadIdx.x) / G;
     const int lane = threadIdx.x % G;
     double s = 0.0;
@@ -294,7 +297,7 @@ __global__ __launch_bounds__(256) void k_dg_restrict(int64_t ncg, const int32_t*
     }
 #pragma unroll
     for (int off = G / 2; off > 0; off >>= 1) s += __shfl_down(s, off, G);
-    if (v < ncg && lane == 0) rc[v] = s;
+    if (v < ncg && lane == 0) rc[v * nil] = s;
 }
 
 // Tile-wise restriction, stage 1: the tile's DG values (consecutive cells: one coalesced read of r) go to LDS; every slot (= one
@@ -333,15 +336,15 @@ __global__ __launch_bounds__(256) void k_restrict_tiles(int64_t ndof_owned, int 
 
 // stage 2: rc[v] = sum of the slots of conforming dof v (fixed order)
 __global__ __launch_bounds__(256) void k_restrict_sum(int64_t ncg, const int32_t* __restrict__ part_ptr, const int32_t* __restrict__ part_idx,
-                                                      const double* __restrict__ part, int64_t nslots, double* __restrict__ rc) {
+                                                      const double* __restrict__ part, int64_t nslots, double* __restrict__ rc, int nil) {
     part += (int64_t)blockIdx.y * nslots;
-    rc += (int64_t)blockIdx.y * ncg;
+    rc += (int64_t)(blockIdx.y / nil) * nil * ncg + (blockIdx.y % nil);          // column blockIdx.y of the interleaved level vector
     const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (v >= ncg) return;
     double s = 0.0;
     const int e = part_ptr[v + 1];
     for (int k = part_ptr[v]; k < e; ++k) s += part[part_idx[k]];
-    rc[v] = s;
+    rc[v * nil] = s;
 }
 
 }  // namespace
@@ -351,9 +354,10 @@ static void smooth(knp_ctx* c, AmgLevel& L, bool zero_guess) {
     const double lmax = L.rho, lmin = L.cheb_lower * L.rho;
     const double theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin), sigma = theta / delta;
     double rho = 1.0 / sigma;
-    const unsigned g = (unsigned)((L.n + 255) / 256);
+    const int nil = (s_ncol % 2 == 0) ? 2 : 1;
     if (zero_guess) {
-        hipLaunchKernelGGL(k_cheb_first, GRIDX(g), dim3(256), 0, c->stream, L.n, L.dinv, L.b, 1.0 / theta, L.r, L.d0, L.x);
+        hipLaunchKernelGGL(k_cheb_first, dim3((unsigned)((L.n * nil + 255) / 256), (unsigned)(s_ncol / nil)), dim3(256), 0, c->stream, L.n, nil,
+                           L.dinv, L.b, 1.0 / theta, L.r, L.d0, L.x);
     } else {
         // x lives in L.x; the fused kernel writes the updated iterate to L.d1 (free at this point), then swap
         LAUNCH_BY_DENSITY(k_cheb_first_res, L.A, L.A, L.dinv, L.b, L.x, 1.0 / theta, L.r, L.d0, L.d1);
@@ -446,9 +450,9 @@ int amg_restrict_from_dg(knp_ctx* c, AmgHierarchy& H, const double* r_dg, hipStr
         hipLaunchKernelGGL(k_restrict_tiles, dim3((unsigned)H.ntiles, (unsigned)H.ncol), dim3(256), sizeof(double) * tile_dofs, st,
                            c->m.nc_owned * c->nd, tile_dofs, H.tile_off, H.slot_ptr, H.slot_idx, r_dg, r_stride, H.part, H.nslots);
         hipLaunchKernelGGL(k_restrict_sum, GRIDX((H.ncg + 255) / 256), dim3(256), 0, st, H.ncg, H.part_ptr, H.part_idx,
-                           (const double*)H.part, H.nslots, H.levels[0].b);
+                           (const double*)H.part, H.nslots, H.levels[0].b, (H.ncol % 2 == 0) ? 2 : 1);
     } else {
-        hipLaunchKernelGGL(k_dg_restrict<8>, GRIDX((H.ncg * 8 + 255) / 256), dim3(256), 0, st, H.ncg, H.cg_ptr, H.cg_idx, r_dg, H.levels[0].b, r_stride);
+        hipLaunchKernelGGL(k_dg_restrict<8>, GRIDX((H.ncg * 8 + 255) / 256), dim3(256), 0, st, H.ncg, H.cg_ptr, H.cg_idx, r_dg, H.levels[0].b, r_stride, (H.ncol % 2 == 0) ? 2 : 1);
     }
     // multi-GPU: the conforming hierarchy is replicated on every rank; the restricted residual is the sum of the
     // ranks' owned-cell contributions (one all-reduce), after which every rank runs the same V-cycle.  When the finest
@@ -566,7 +570,7 @@ int knp_amg_level(knp_ctx* c, int which, int64_t n, const int32_t* rpA, const in
         rc |= up_csr(c, L.R, ncoarse, n, rpR, ciR, vR);
     }
     double** w[] = {&L.x, &L.b, &L.r, &L.d0, &L.d1};
-    const size_t nbuf = (size_t)(n ? n : 1) * (size_t)H->ncol;          // [ncol][n]
+    const size_t nbuf = (size_t)(n ? n : 1) * (size_t)H->ncol;          // [ncol / nil][n][nil], nil = 2 interleaved columns when ncol is even
     for (auto p : w) {
         if (hipMalloc((void**)p, nbuf * sizeof(double)) != hipSuccess) rc = -2;
         else hipMemset(*p, 0, nbuf * sizeof(double));

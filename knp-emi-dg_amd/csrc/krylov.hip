@@ -71,9 +71,10 @@ template <int NV> __device__ __forceinline__ void stv(double* p, int64_t c, cons
 // conforming-space correction e gathered into the DG dofs of cell c: dg2cg[c][a] is the conforming dof of DG dof (c, a)
 // (P1: membrane-broken vertex dofs; P2: vertex + edge dofs of the conforming P2 space) -- pure injection
 template <int NV> __device__ __forceinline__ void prolong_cell(const int32_t* __restrict__ dg2cg, const double* __restrict__ e,
-                                                                int64_t c, double* add) {
+                                                                int64_t c, double* add, int nil = 1) {
+    // nil: interleaved right-hand-side columns of the level vector (amg.hip); e points at this column's first entry
 #pragma unroll
-    for (int a = 0; a < NV; ++a) add[a] = e[dg2cg[c * NV + a]];
+    for (int a = 0; a < NV; ++a) add[a] = e[(int64_t)dg2cg[c * NV + a] * nil];
 }
 
 template <int NV> __device__ __forceinline__ void block_matvec(const bjreal* __restrict__ binv, int64_t c, const double* r, double* z) {
@@ -353,9 +354,11 @@ template <int NV>
 __global__ __launch_bounds__(KNP_BLOCK) void k_prolong_add(VecDims d, const int* __restrict__ status, int sys,
                                                            const int32_t* __restrict__ dg2cg, const double* __restrict__ e,
                                                            int64_t ncg, double* __restrict__ y) {
-    if (sys < 0) {                                   // batched: grid.y = species, e is [nsys][ncg], y is [nsys][nc*NV]
-        sys = blockIdx.y;
-        e += (int64_t)sys * ncg;
+    int nil = 1;
+    if (sys < 0) {                                   // batched: grid.y = species, y is [nsys][nc*NV]; e is the shared hierarchy's level
+        sys = blockIdx.y;                            // vector: columns interleaved in pairs when nsys is even (amg.hip)
+        nil = (d.nsys % 2 == 0) ? 2 : 1;
+        e += (int64_t)(sys / nil) * nil * ncg + (sys % nil);
         y += (int64_t)sys * d.nc * NV;
     }
     if (status[2 * sys]) return;
@@ -364,7 +367,7 @@ __global__ __launch_bounds__(KNP_BLOCK) void k_prolong_add(VecDims d, const int*
     double yv[NV];
     ldv<NV>(y, c, yv);
     double ad[NV];
-    prolong_cell<NV>(dg2cg, e, c, ad);
+    prolong_cell<NV>(dg2cg, e, c, ad, nil);
 #pragma unroll
     for (int a = 0; a < NV; ++a) yv[a] += ad[a];
     stv<NV>(y, c, yv);
