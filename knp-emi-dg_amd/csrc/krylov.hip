@@ -349,6 +349,37 @@ __global__ __launch_bounds__(KNP_BLOCK) void k_prolong_dot(VecDims d, const int*
     write_partials<NR>(partial, 1, acc);
 }
 
+// y += P e for a PAIR of species whose corrections sit interleaved in the shared hierarchy's level vector (grid.y = pair): one
+// 16-byte gather per DG dof serves both
+template <int NV>
+__global__ __launch_bounds__(KNP_BLOCK) void k_prolong_add_pair(VecDims d, const int* __restrict__ status, const int32_t* __restrict__ dg2cg,
+                                                                const double* __restrict__ e, int64_t ncg, double* __restrict__ y) {
+    const int s0 = 2 * blockIdx.y;
+    const bool on0 = !status[2 * s0], on1 = !status[2 * (s0 + 1)];
+    if (!on0 && !on1) return;
+    const int64_t c = (int64_t)blockIdx.x * KNP_BLOCK + threadIdx.x;
+    if (c >= d.nc_owned) return;
+    const double2* e2 = reinterpret_cast<const double2*>(e + (int64_t)s0 * ncg);
+    double2 ad[NV];
+#pragma unroll
+    for (int a = 0; a < NV; ++a) ad[a] = e2[dg2cg[c * NV + a]];
+    double* y0 = y + (int64_t)s0 * d.nc * NV;
+    double* y1 = y0 + d.nc * NV;
+    double yv[NV];
+    if (on0) {
+        ldv<NV>(y0, c, yv);
+#pragma unroll
+        for (int a = 0; a < NV; ++a) yv[a] += ad[a].x;
+        stv<NV>(y0, c, yv);
+    }
+    if (on1) {
+        ldv<NV>(y1, c, yv);
+#pragma unroll
+        for (int a = 0; a < NV; ++a) yv[a] += ad[a].y;
+        stv<NV>(y1, c, yv);
+    }
+}
+
 // y += P e for one species block (BiCGStab preconditioner application)
 template <int NV>
 __global__ __launch_bounds__(KNP_BLOCK) void k_prolong_add(VecDims d, const int* __restrict__ status, int sys,
@@ -760,8 +791,12 @@ static int knp_coarse_correction(knp_ctx* c, const VecDims& d, const double* in,
         AmgHierarchy& H = c->amg[1];
         if ((rc = amg_restrict_from_dg(c, H, in, nullptr, d.nc * NV))) return rc;
         if ((rc = amg_vcycle(c, H))) return rc;
-        hipLaunchKernelGGL(k_prolong_add<NV>, dim3(g1.x, (unsigned)d.nsys), b, 0, c->stream, d, c->status, -1, H.dg2cg, H.levels[0].x,
-                           H.ncg, out);
+        if (d.nsys % 2 == 0)
+            hipLaunchKernelGGL(k_prolong_add_pair<NV>, dim3(g1.x, (unsigned)(d.nsys / 2)), b, 0, c->stream, d, c->status, H.dg2cg,
+                               H.levels[0].x, H.ncg, out);
+        else
+            hipLaunchKernelGGL(k_prolong_add<NV>, dim3(g1.x, (unsigned)d.nsys), b, 0, c->stream, d, c->status, -1, H.dg2cg, H.levels[0].x,
+                               H.ncg, out);
         return 0;
     }
     // every species is an independent chain  restrict -> V-cycle -> prolong  of short latency-bound kernels writing
