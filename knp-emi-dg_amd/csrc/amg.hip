@@ -114,6 +114,33 @@ __global__ __launch_bounds__(256) void k_csr(CsrDev A, const double* __restrict_
     }
 }
 
+// b_c = R r together with the first (zero-guess) Chebyshev update of the level that receives it:  rc = b_c ; d = dinv b_c / theta ;
+// x = d  -- the separate k_cheb_first launch (5 us, three vector writes of a vector this kernel has in registers) goes away
+template <int G, int NC>
+__global__ __launch_bounds__(256) void k_csr_first(CsrDev R, const double* __restrict__ rfine, const double* __restrict__ dinv, double inv_theta,
+                                                   double* __restrict__ bc, double* __restrict__ rc, double* __restrict__ d,
+                                                   double* __restrict__ x) {
+    rfine += (int64_t)blockIdx.y * NC * R.ncols;
+    const int64_t o = (int64_t)blockIdx.y * NC * R.nrows;
+    bc += o; rc += o; d += o; x += o;
+    const int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) / G;
+    const int lane = threadIdx.x % G;
+    double s[NC];
+    row_dot<G, NC>(R, row, lane, rfine, s);
+    if (row < R.nrows && lane == 0) {
+        const double w = dinv[row] * inv_theta;
+#pragma unroll
+        for (int j = 0; j < NC; ++j) {
+            const int64_t q = row * NC + j;
+            const double v = w * s[j];
+            bc[q] = s[j];
+            rc[q] = s[j];
+            d[q] = v;
+            x[q] = v;
+        }
+    }
+}
+
 #define LAUNCH_BY_DENSITY(KERN, A, ...)                                                                                       \
     do {                                                                                                                      \
         const double avg_ = (A).nrows ? (double)(A).nnz / (double)(A).nrows : 0.0;                                            \
@@ -350,12 +377,16 @@ __global__ __launch_bounds__(256) void k_restrict_sum(int64_t ncg, const int32_t
 }  // namespace
 
 // smoother on level lv: Chebyshev polynomial of D^-1 A on [lower*rho, rho]
-static void smooth(knp_ctx* c, AmgLevel& L, bool zero_guess) {
+static double level_theta(const AmgLevel& L) { return 0.5 * (L.rho + L.cheb_lower * L.rho); }
+
+// first_done: the zero-guess first update was written by the kernel that produced L.b (k_csr_first)
+static void smooth(knp_ctx* c, AmgLevel& L, bool zero_guess, bool first_done = false) {
     const double lmax = L.rho, lmin = L.cheb_lower * L.rho;
     const double theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin), sigma = theta / delta;
     double rho = 1.0 / sigma;
     const int nil = (s_ncol % 2 == 0) ? 2 : 1;
-    if (zero_guess) {
+    if (zero_guess && first_done) {
+    } else if (zero_guess) {
         hipLaunchKernelGGL(k_cheb_first, dim3((unsigned)((L.n * nil + 255) / 256), (unsigned)(s_ncol / nil)), dim3(256), 0, c->stream, L.n, nil,
                            L.dinv, L.b, 1.0 / theta, L.r, L.d0, L.x);
     } else {
@@ -378,16 +409,23 @@ static int amg_vcycle_eager(knp_ctx* c, AmgHierarchy& H) {
     const int nl = (int)H.levels.size();
     s_ncol = H.ncol;
     struct Reset { ~Reset() { s_ncol = 1; } } reset_on_exit;
+    bool first_done = false;
     for (int l = 0; l < nl - 1; ++l) {
         AmgLevel& L = H.levels[l];
         if (L.cheb_degree == 0) {                                    // transfer-only level: x = 0, r = b
             // level 0: amg_restrict_from_dg already went down to level 1 (outside the captured graph, see there)
             if (l > 0) launch_csr<0>(c, L.R, L.b, nullptr, H.levels[l + 1].b);
+            first_done = false;
             continue;
         }
-        smooth(c, L, true);
+        smooth(c, L, true, first_done);
         launch_csr<1>(c, L.A, L.x, L.b, L.r);                        // r = b - A x
-        launch_csr<0>(c, L.R, L.r, nullptr, H.levels[l + 1].b);      // b_{l+1} = R r
+        AmgLevel& N = H.levels[l + 1];
+        first_done = l + 1 < nl - 1 && N.cheb_degree > 0;
+        if (first_done)                                              // b_{l+1} = R r and the next level's first update at once
+            LAUNCH_BY_DENSITY(k_csr_first, L.R, L.R, L.r, N.dinv, 1.0 / level_theta(N), N.b, N.r, N.d0, N.x);
+        else
+            launch_csr<0>(c, L.R, L.r, nullptr, N.b);                // b_{l+1} = R r
     }
     AmgLevel& C = H.levels[nl - 1];
     if (H.ncol % 2 == 0)

@@ -496,25 +496,22 @@ __global__ __launch_bounds__(KNP_BLOCK) void k_bi_s(VecDims d, const double* __r
     stv<NV>(SYS_PTR(z, s), c, zv);
 }
 
-// second step of the two-step Chebyshev iteration on Binv A (zero initial guess), given y0 = Binv r and t = A y0:
-//   y = ca y0 + cb Binv (r - ct t)
+// second step of the two-step Chebyshev iteration on Binv A (zero initial guess), given t = A y0 with y0 = Binv r:
+//   y = ca y0 + cb Binv (r - ct t) = Binv ((ca + cb) r - cb ct t)        (Binv is linear: y0 need not be read back)
 template <int NV>
 __global__ __launch_bounds__(KNP_BLOCK) void k_bj_cheb2(VecDims d, const int* __restrict__ status, const bjreal* __restrict__ binv,
                                                         const double* __restrict__ r, const double* __restrict__ t,
-                                                        double* __restrict__ y, double ca, double cb, double ct) {
+                                                        double* __restrict__ y, double cr, double ctt) {
     const int s = blockIdx.y;
     if (status && status[2 * s]) return;
     const int64_t c = (int64_t)blockIdx.x * KNP_BLOCK + threadIdx.x;
     if (c >= d.nc_owned) return;
-    double rv[NV], tv[NV], yv[NV], uv[NV];
+    double rv[NV], tv[NV], yv[NV];
     ldv<NV>(SYS_PTR(r, s), c, rv);
     ldv<NV>(SYS_PTR(t, s), c, tv);
-    ldv<NV>(SYS_PTR(y, s), c, yv);
 #pragma unroll
-    for (int a = 0; a < NV; ++a) rv[a] -= ct * tv[a];
-    block_matvec<NV>(binv + (int64_t)s * d.nc * NV * NV, c, rv, uv);
-#pragma unroll
-    for (int a = 0; a < NV; ++a) yv[a] = ca * yv[a] + cb * uv[a];
+    for (int a = 0; a < NV; ++a) rv[a] = cr * rv[a] - ctt * tv[a];
+    block_matvec<NV>(binv + (int64_t)s * d.nc * NV * NV, c, rv, yv);
     stv<NV>(SYS_PTR(y, s), c, yv);
 }
 
@@ -655,7 +652,7 @@ static int bj_cheb2(knp_ctx* c, const VecDims& d, const KrylovVecs& kv, const do
     const dim3 g((unsigned)grid_for(c->m.nc_owned), (unsigned)d.nsys), b(KNP_BLOCK);
     hipLaunchKernelGGL(k_bj_cheb2<NV>, g, b, 0, c->stream, d, use_status ? (const int*)c->status : (const int*)nullptr, kv.binv, r,
                        (const double*)kv.tmp, y,
-                       (1.0 + rho1 * rho0) / theta, 2.0 * rho1 / delta, 1.0 / theta);
+                       (1.0 + rho1 * rho0) / theta + 2.0 * rho1 / delta, (2.0 * rho1 / delta) / theta);
     return 0;
 }
 
