@@ -795,8 +795,7 @@ __device__ __forceinline__ void knp_facet_halo(const CellGeom<3>& K, uint32_t fl
     }
 }
 
-// PROBE (tools/apply_only.py experiments only): 1 = memory phase without the facet arithmetic, 2 = additionally without halo loads
-template <int NS, bool MAT, int PROBE = 0>
+template <int NS, bool MAT>
 __global__ __launch_bounds__(KNP_HALO_BLK) void k_knp_apply_halo(MeshDev m, const double* __restrict__ x,
                                                                  const double* __restrict__ gphi,
                                                                  const double* __restrict__ Dall, double* __restrict__ yout,
@@ -815,7 +814,7 @@ __global__ __launch_bounds__(KNP_HALO_BLK) void k_knp_apply_halo(MeshDev m, cons
     if (w.cur >= w.last) return;
     for (int i = t; i < m.ncls * HALO_FT; i += BLK) s_ft[(i / HALO_FT) * HALO_FTS + (i % HALO_FT)] = m.cls_table[(i / HALO_FT) * KNP_CLS_STRIDE + 11 + (i % HALO_FT)];
     if (MAT && t < NS * KNP_MAX_MAT) s_D[t] = dtab[t];
-    const bool hl = (int)t < m.hb_stride && PROBE != 2;
+    const bool hl = (int)t < m.hb_stride;
     int src = hl ? m.hb_src[(w.b_lo + w.cur) * m.hb_stride + t] : -1;
     while (w.cur < w.last) {
         const int64_t c = (w.b_lo + w.cur) * BLK + t;
@@ -903,18 +902,10 @@ __global__ __launch_bounds__(KNP_HALO_BLK) void k_knp_apply_halo(MeshDev m, cons
                     y[k][a] = fma(mw, sx + xv[k][a], fma(dv, s, drift * gp[a]));
                 }
             }
-            if (PROBE >= 1) {
-#pragma unroll
-                for (int k = 0; k < NS; ++k) {
-                    y[k][0] += TO_LDS(s_x)[(unsigned)k * NV * ent + (lw.x & 0xffffu)] + TO_LDS(s_x)[(unsigned)k * NV * ent + (lw.x >> 16)];
-                    y[k][1] += TO_LDS(s_x)[(unsigned)k * NV * ent + (lw.y & 0xffffu)] + TO_LDS(s_g)[(lw.y >> 16)] + ft[flags & 7u] + (double)nm;
-                }
-            } else {
-                knp_facet_halo<NS, MAT, 0>(K, flags, lw.x & 0xffffu, nm & 0xffu, xv, gp, Dk, ka, TO_LDS(s_x), TO_LDS(s_g), TO_LDS(s_D), ft, ent, y);
-                knp_facet_halo<NS, MAT, 1>(K, flags, lw.x >> 16, (nm >> 8) & 0xffu, xv, gp, Dk, ka, TO_LDS(s_x), TO_LDS(s_g), TO_LDS(s_D), ft, ent, y);
-                knp_facet_halo<NS, MAT, 2>(K, flags, lw.y & 0xffffu, (nm >> 16) & 0xffu, xv, gp, Dk, ka, TO_LDS(s_x), TO_LDS(s_g), TO_LDS(s_D), ft, ent, y);
-                knp_facet_halo<NS, MAT, 3>(K, flags, lw.y >> 16, nm >> 24, xv, gp, Dk, ka, TO_LDS(s_x), TO_LDS(s_g), TO_LDS(s_D), ft, ent, y);
-            }
+            knp_facet_halo<NS, MAT, 0>(K, flags, lw.x & 0xffffu, nm & 0xffu, xv, gp, Dk, ka, TO_LDS(s_x), TO_LDS(s_g), TO_LDS(s_D), ft, ent, y);
+            knp_facet_halo<NS, MAT, 1>(K, flags, lw.x >> 16, (nm >> 8) & 0xffu, xv, gp, Dk, ka, TO_LDS(s_x), TO_LDS(s_g), TO_LDS(s_D), ft, ent, y);
+            knp_facet_halo<NS, MAT, 2>(K, flags, lw.y & 0xffffu, (nm >> 16) & 0xffu, xv, gp, Dk, ka, TO_LDS(s_x), TO_LDS(s_g), TO_LDS(s_D), ft, ent, y);
+            knp_facet_halo<NS, MAT, 3>(K, flags, lw.y >> 16, nm >> 24, xv, gp, Dk, ka, TO_LDS(s_x), TO_LDS(s_g), TO_LDS(s_D), ft, ent, y);
 #pragma unroll
             for (int k = 0; k < NS; ++k) store_nodal<3>(yout + (int64_t)k * m.nc * NV, c, y[k]);
         }
@@ -1137,19 +1128,16 @@ template <int D> static int knp_apply_dispatch(knp_ctx* c, const double* x, cons
     size_t lds = 0;
     bool matp = false;
     if (D == 3 && knp_halo_usable(c, &lds, &matp)) {
-        const int probe = env_int("KNP_APPLY_PROBE", 0);          // tools/apply_only.py experiments
         const unsigned ent = halo_entries(c);
         const dim3 hb(KNP_HALO_BLK);
         int flip_nq = 0;
         int* ctr = halo_counters(c, 1, &flip_nq);
-#define KNP_HALO_LAUNCH(NS_, MAT_, PR_)                                                                                              \
-    hipLaunchKernelGGL((k_knp_apply_halo<NS_, MAT_, PR_>), halo_grid(c, k_knp_apply_halo<NS_, MAT_, PR_>, lds), hb, lds, c->stream, c->m, x, \
-                       gphi, c->D, y, ka, ent, (const uint8_t*)c->mat, (const uint8_t*)c->nmat4, (const double*)c->dtab, ctr, flip_nq)
-        if (c->p.n_sys == 1) { if (matp) KNP_HALO_LAUNCH(1, true, 0); else KNP_HALO_LAUNCH(1, false, 0); }
-        else if (probe == 2 && matp) KNP_HALO_LAUNCH(2, true, 2);
-        else if (probe == 1 && matp) KNP_HALO_LAUNCH(2, true, 1);
-        else if (matp) KNP_HALO_LAUNCH(2, true, 0);
-        else KNP_HALO_LAUNCH(2, false, 0);
+#define KNP_HALO_LAUNCH(NS_, MAT_)                                                                                                   \
+    hipLaunchKernelGGL((k_knp_apply_halo<NS_, MAT_>), halo_grid(c, k_knp_apply_halo<NS_, MAT_>, lds), hb, lds, c->stream, c->m, x, gphi,   \
+                       c->D, y, ka, ent, (const uint8_t*)c->mat, (const uint8_t*)c->nmat4, (const double*)c->dtab, ctr, flip_nq)
+        if (c->p.n_sys == 1) { if (matp) KNP_HALO_LAUNCH(1, true); else KNP_HALO_LAUNCH(1, false); }
+        else if (matp) KNP_HALO_LAUNCH(2, true);
+        else KNP_HALO_LAUNCH(2, false);
 #undef KNP_HALO_LAUNCH
         HIPCHK(c, hipGetLastError());
         return 0;
