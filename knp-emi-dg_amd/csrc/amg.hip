@@ -330,70 +330,48 @@ __global__ __launch_bounds__(256) void k_dg_restrict(int64_t ncg, const int32_t*
 // Tile-wise restriction, stage 1: the tile's DG values (consecutive cells: one coalesced read of r) go to LDS; every slot (= one
 // conforming dof touched by the tile) is summed by one thread in a fixed order.  The gather form above reads 8 bytes out of every
 // 32-byte cell record four times over (once per vertex): 38 us at r=2 against 64 MB of input.
-// NC = 2: both species of a shared hierarchy in one pass (the slot tables are read once, the partial sums and the level vector carry
-// the pair interleaved); further column groups along grid.y
-template <int NC>
 __global__ __launch_bounds__(256) void k_restrict_tiles(int64_t ndof_owned, int tile_dofs, const int32_t* __restrict__ tile_off,
                                                         const int32_t* __restrict__ slot_ptr, const uint16_t* __restrict__ slot_idx,
                                                         const double* __restrict__ r, int64_t r_stride, double* __restrict__ part,
                                                         int64_t nslots) {
-    extern __shared__ double s_r[];                                              // [NC][tile_dofs]
-    r += (int64_t)blockIdx.y * NC * r_stride;
-    part += (int64_t)blockIdx.y * NC * nslots;
+    extern __shared__ double s_r[];
+    r += (int64_t)blockIdx.y * r_stride;
+    part += (int64_t)blockIdx.y * nslots;
     const int64_t d0 = (int64_t)blockIdx.x * tile_dofs;
     const int n = (int)((ndof_owned - d0 < tile_dofs) ? (ndof_owned - d0) : tile_dofs);
-#pragma unroll
-    for (int j = 0; j < NC; ++j) {
-        const double* src = r + (int64_t)j * r_stride + d0;
-        double* dst = s_r + j * tile_dofs;
-        if ((reinterpret_cast<uintptr_t>(src) & 15u) == 0) {                    // 16-byte aligned column: pairs (tile_dofs is even)
-            const double2* src2 = reinterpret_cast<const double2*>(src);
-            for (int i = threadIdx.x; 2 * i + 1 < n; i += 256) {
-                const double2 v = src2[i];
-                dst[2 * i] = v.x;
-                dst[2 * i + 1] = v.y;
-            }
-            if ((n & 1) && threadIdx.x == 0) dst[n - 1] = src[n - 1];
-        } else {
-            for (int i = threadIdx.x; i < n; i += 256) dst[i] = src[i];
+    const double* src = r + d0;
+    if ((reinterpret_cast<uintptr_t>(src) & 15u) == 0) {                        // 16-byte aligned column: pairs (tile_dofs is even)
+        const double2* src2 = reinterpret_cast<const double2*>(src);
+        for (int i = threadIdx.x; 2 * i + 1 < n; i += 256) {
+            const double2 v = src2[i];
+            s_r[2 * i] = v.x;
+            s_r[2 * i + 1] = v.y;
         }
+        if ((n & 1) && threadIdx.x == 0) s_r[n - 1] = src[n - 1];
+    } else {
+        for (int i = threadIdx.x; i < n; i += 256) s_r[i] = src[i];
     }
     __syncthreads();
     const int p1 = tile_off[blockIdx.x + 1];
     for (int p = tile_off[blockIdx.x] + threadIdx.x; p < p1; p += 256) {
-        double acc[NC];
-#pragma unroll
-        for (int j = 0; j < NC; ++j) acc[j] = 0.0;
+        double acc = 0.0;
         const int e = slot_ptr[p + 1];
-        for (int k = slot_ptr[p]; k < e; ++k) {
-            const int q = slot_idx[k];
-#pragma unroll
-            for (int j = 0; j < NC; ++j) acc[j] += s_r[j * tile_dofs + q];
-        }
-#pragma unroll
-        for (int j = 0; j < NC; ++j) part[(int64_t)p * NC + j] = acc[j];
+        for (int k = slot_ptr[p]; k < e; ++k) acc += s_r[slot_idx[k]];
+        part[p] = acc;
     }
 }
 
-// stage 2: rc[v] = sum of the slots of conforming dof v (fixed order); NC interleaved columns per entry
-template <int NC>
+// stage 2: rc[v] = sum of the slots of conforming dof v (fixed order)
 __global__ __launch_bounds__(256) void k_restrict_sum(int64_t ncg, const int32_t* __restrict__ part_ptr, const int32_t* __restrict__ part_idx,
-                                                      const double* __restrict__ part, int64_t nslots, double* __restrict__ rc) {
-    part += (int64_t)blockIdx.y * NC * nslots;
-    rc += (int64_t)blockIdx.y * NC * ncg;
+                                                      const double* __restrict__ part, int64_t nslots, double* __restrict__ rc, int nil) {
+    part += (int64_t)blockIdx.y * nslots;
+    rc += (int64_t)(blockIdx.y / nil) * nil * ncg + (blockIdx.y % nil);          // column blockIdx.y of the interleaved level vector
     const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (v >= ncg) return;
-    double s[NC];
-#pragma unroll
-    for (int j = 0; j < NC; ++j) s[j] = 0.0;
+    double s = 0.0;
     const int e = part_ptr[v + 1];
-    for (int k = part_ptr[v]; k < e; ++k) {
-        const double* q = part + (int64_t)part_idx[k] * NC;
-#pragma unroll
-        for (int j = 0; j < NC; ++j) s[j] += q[j];
-    }
-#pragma unroll
-    for (int j = 0; j < NC; ++j) rc[v * NC + j] = s[j];
+    for (int k = part_ptr[v]; k < e; ++k) s += part[part_idx[k]];
+    rc[v * nil] = s;
 }
 
 }  // namespace
@@ -507,17 +485,10 @@ int amg_restrict_from_dg(knp_ctx* c, AmgHierarchy& H, const double* r_dg, hipStr
             HIPCHK(c, hipMalloc((void**)&H.part, sizeof(double) * (size_t)H.ncol * (size_t)(H.nslots ? H.nslots : 1)));
             H.part_cols = H.ncol;
         }
-        if (H.ncol % 2 == 0) {
-            hipLaunchKernelGGL(k_restrict_tiles<2>, dim3((unsigned)H.ntiles, (unsigned)(H.ncol / 2)), dim3(256), sizeof(double) * 2 * tile_dofs, st,
-                               c->m.nc_owned * c->nd, tile_dofs, H.tile_off, H.slot_ptr, H.slot_idx, r_dg, r_stride, H.part, H.nslots);
-            hipLaunchKernelGGL(k_restrict_sum<2>, dim3((unsigned)((H.ncg + 255) / 256), (unsigned)(H.ncol / 2)), dim3(256), 0, st, H.ncg, H.part_ptr,
-                               H.part_idx, (const double*)H.part, H.nslots, H.levels[0].b);
-        } else {
-            hipLaunchKernelGGL(k_restrict_tiles<1>, dim3((unsigned)H.ntiles, (unsigned)H.ncol), dim3(256), sizeof(double) * tile_dofs, st,
-                               c->m.nc_owned * c->nd, tile_dofs, H.tile_off, H.slot_ptr, H.slot_idx, r_dg, r_stride, H.part, H.nslots);
-            hipLaunchKernelGGL(k_restrict_sum<1>, dim3((unsigned)((H.ncg + 255) / 256), (unsigned)H.ncol), dim3(256), 0, st, H.ncg, H.part_ptr,
-                               H.part_idx, (const double*)H.part, H.nslots, H.levels[0].b);
-        }
+        hipLaunchKernelGGL(k_restrict_tiles, dim3((unsigned)H.ntiles, (unsigned)H.ncol), dim3(256), sizeof(double) * tile_dofs, st,
+                           c->m.nc_owned * c->nd, tile_dofs, H.tile_off, H.slot_ptr, H.slot_idx, r_dg, r_stride, H.part, H.nslots);
+        hipLaunchKernelGGL(k_restrict_sum, GRIDX((H.ncg + 255) / 256), dim3(256), 0, st, H.ncg, H.part_ptr, H.part_idx,
+                           (const double*)H.part, H.nslots, H.levels[0].b, (H.ncol % 2 == 0) ? 2 : 1);
     } else {
         hipLaunchKernelGGL(k_dg_restrict<8>, GRIDX((H.ncg * 8 + 255) / 256), dim3(256), 0, st, H.ncg, H.cg_ptr, H.cg_idx, r_dg, H.levels[0].b, r_stride, (H.ncol % 2 == 0) ? 2 : 1);
     }
