@@ -106,7 +106,7 @@ __device__ void scalar_op(int op, double* S, const double* R, int* flag, int* it
 // Eight partial rows per thread are in flight at a time: with one row per loop trip the 15 trips of the r=2 mesh were 15 dependent
 // L2 round trips (11 us for a kernel that moves 250 KB).
 #define KNP_REDUCE_BLOCK 1024
-template <int NR>
+template <int NR, int UR = 4>
 __global__ __launch_bounds__(KNP_REDUCE_BLOCK) void k_reduce(const double* __restrict__ partial, int64_t nblocks, int nsys, double* red, int op,
                                                              double* scal, int* status, double rtol, double atol, int min_it) {
     // one block per system; deterministic order
@@ -124,17 +124,17 @@ __global__ __launch_bounds__(KNP_REDUCE_BLOCK) void k_reduce(const double* __res
     double acc[NR];
 #pragma unroll
     for (int r = 0; r < NR; ++r) acc[r] = 0.0;
-    for (int64_t b0 = threadIdx.x; b0 < nblocks; b0 += 4 * KNP_REDUCE_BLOCK) {
-        double v[4][NR];
+    for (int64_t b0 = threadIdx.x; b0 < nblocks; b0 += UR * KNP_REDUCE_BLOCK) {
+        double v[UR][NR];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < UR; ++u) {
             const int64_t b = b0 + (int64_t)u * KNP_REDUCE_BLOCK;
             const double* p = partial + (b * nsys + s) * KNP_MAX_RED;
 #pragma unroll
             for (int r = 0; r < NR; ++r) v[u][r] = b < nblocks ? p[r] : 0.0;
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < UR; ++u)
 #pragma unroll
             for (int r = 0; r < NR; ++r) acc[r] += v[u][r];
     }
@@ -600,12 +600,23 @@ static int finalize(knp_ctx* c, int op, int nsys, int nred, double rtol, double 
     const int64_t nb = grid_for(c->m.nc_owned);
     double* red = c->scal + KNP_MAX_SYS * KS_N;
     const int dop = c->dist ? 0 : op;
+    // partial rows in flight per thread: 4 up to 8 192 producer blocks (r=2: 3 888), 8 beyond (r=3: 31 104 blocks were eight
+    // dependent trips = 64 us)
+    const bool deep = nb > 8192;
+#define KNP_REDUCE(NR_)                                                                                                                  \
+    do {                                                                                                                                 \
+        if (deep) hipLaunchKernelGGL((k_reduce<NR_, 8>), dim3(nsys), dim3(KNP_REDUCE_BLOCK), 0, c->stream, c->partial, nb, nsys, red, dop,  \
+                                     c->scal, c->status, rtol, atol, min_it);                                                            \
+        else hipLaunchKernelGGL((k_reduce<NR_, 4>), dim3(nsys), dim3(KNP_REDUCE_BLOCK), 0, c->stream, c->partial, nb, nsys, red, dop,       \
+                                c->scal, c->status, rtol, atol, min_it);                                                                 \
+    } while (0)
     switch (nred) {
-        case 1: hipLaunchKernelGGL(k_reduce<1>, dim3(nsys), dim3(KNP_REDUCE_BLOCK), 0, c->stream, c->partial, nb, nsys, red, dop, c->scal, c->status, rtol, atol, min_it); break;
-        case 2: hipLaunchKernelGGL(k_reduce<2>, dim3(nsys), dim3(KNP_REDUCE_BLOCK), 0, c->stream, c->partial, nb, nsys, red, dop, c->scal, c->status, rtol, atol, min_it); break;
-        case 3: hipLaunchKernelGGL(k_reduce<3>, dim3(nsys), dim3(KNP_REDUCE_BLOCK), 0, c->stream, c->partial, nb, nsys, red, dop, c->scal, c->status, rtol, atol, min_it); break;
+        case 1: KNP_REDUCE(1); break;
+        case 2: KNP_REDUCE(2); break;
+        case 3: KNP_REDUCE(3); break;
         default: c->err = "finalize: unsupported number of partial sums"; return -1;
     }
+#undef KNP_REDUCE
     if (c->dist) {
         int rc = allreduce_red(c, red, nsys * KNP_MAX_RED);
         if (rc) return rc;
