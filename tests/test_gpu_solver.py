@@ -486,6 +486,40 @@ def test_knp_hierarchy_shared_or_per_species(hip_lib, monkeypatch, shared):
     assert max(max(n) for n in S.knp_niter) < 60          # the auxiliary space is active (block-Jacobi alone needs hundreds)
 
 
+def test_setup_helper_processes_and_their_fallback(hip_lib):
+    """knpemidg/setup_worker.py: the first EMI hierarchy and the KNP hierarchies come from the helper processes when the device state
+    still is the initial state they were given (the conforming spaces are then never built in this process); a changed state discards
+    the helper's EMI result and builds in-process.  Both ways the step matches the oracle."""
+    from common_examples import make_solver, solver_parameters, Constant
+    from knpemidg import _abi as A
+    for changed in (False, True):
+        mt = small_3d((10, 4, 4))
+        S = make_solver(dim=3, resolution=0, n_axons=1, mesh_tuple=mt)
+        assert S._emi_helper is not None and S._knp_helper is not None
+        pb = ko.build_idealized(mt[0], mt[1].array(), mt[2].array(), membrane_tags=(1,))
+        if changed:
+            S.dev.upload(A.F_C, 1.2 * S._init_c)
+            S.dev.upload(A.F_C_PREV, 1.2 * S._init_c)
+            S.dev.upload(A.F_C_ELIM, 1.2 * S._init_c_elim)
+            pb.c *= 1.2; pb.c_prev_n *= 1.2; pb.c_elim *= 1.2
+        S._unpack_solver_params(solver_parameters(3, 0)._replace(rtol_emi=1e-10, rtol_knp=1e-12))
+        S.save_fields = S.save_solver_stats = False
+        S.splitting_scheme = True
+        S.setup_varform_emi(); S.setup_varform_knp(); S.setup_solver_emi(); S.setup_solver_knp()
+        assert S._emi_helper is None and S._knp_helper is None
+        assert hasattr(S, "_cspace") == changed                 # in-process build only when the helper's result was discarded
+        t = Constant(0.0)
+        S.step_membrane_models(0)
+        pb.phi_M = S.phi_M_prev_PDE.array().copy()
+        for ion in pb.ions:
+            pb.I_ch[ion["name"]] = S.mem_models[0]['I_ch_k'][ion["name"]].array().copy()
+        S.solve_for_time_step(0, t)
+        ko.solve_for_time_step(pb, direct=True)
+        assert relerr(S.c.array(), pb.c) < 1e-8
+        assert max(S.emi_niter) < 40 and max(max(n) for n in S.knp_niter) < 60
+        S.dev.close()
+
+
 def test_amg_hierarchy_is_refreshed_when_kappa_drifts(hip_lib, monkeypatch):
     """The reference rebuilds its AMG preconditioner at every solve (solver.py:505); this build lags it and refreshes when the
     coefficient has drifted (Solver._maybe_refresh_amg_emi): after the concentrations are scaled by 1.6 mid-run the EMI
