@@ -110,6 +110,38 @@ def test_knp_apply_kernel_variants(hip_lib, monkeypatch, env, variant):
         dev.close()
 
 
+@pytest.mark.parametrize("names,variant", [(("K", "Cl"), 6), (("K", "Cl", "Na", "Ca"), 1)])
+def test_knp_apply_with_one_and_three_solved_species(hip_lib, names, variant):
+    """Species counts other than the reference's two solved ions: ONE solved species runs the halo-staged kernel's NS = 1 instance,
+    THREE run the LDS-staged kernel (the halo-staged one carries at most two); same operators as the oracle's."""
+    from knpemidg import _abi as A
+    from knpemidg.mesh import make_mesh_3D
+    m, s, f = make_mesh_3D(0)
+    P = ko.idealized_params()
+    nc = m.num_cells()
+    z = dict(P["z"], Ca=2.0)
+    Dc = dict(P["D"], Ca=0.8e-9)
+    ions = [dict(name=n, z=z[n], D=np.full(nc, Dc[n])) for n in names]
+    pb = ko.Problem(m, s.array().astype(np.int64), f.array(), 1, ions, P, membrane_tags=(1, 2))
+    rng = np.random.default_rng(11)
+    pb.c = rng.uniform(50.0, 150.0, size=pb.c.shape)
+    pb.c_prev_n = pb.c.copy()
+    pb.c_elim = rng.uniform(50.0, 150.0, size=pb.c_elim.shape)
+    x = synthetic_state(pb)
+    dev = device_for(pb)
+    try:
+        push_state(dev, pb)
+        assert dev.apply_variant(1) == variant
+        dev.update_dnphi()
+        dev.upload(A.F_X, x)
+        dev.knp_apply(A.F_X, A.F_Y)
+        y = dev.download(A.F_Y).reshape(pb.N_ions, -1)
+        for k in range(pb.N_ions):
+            assert relerr(y[k], ko.assemble_knp(pb, k) @ x[k].ravel()) < TOL
+    finally:
+        dev.close()
+
+
 def test_knp_apply_with_cellwise_diffusion(hip_lib):
     """D that differs from cell to cell (more distinct coefficient tuples than the material table holds): the halo-staged kernel
     stages D itself; same operator as the oracle's."""
