@@ -232,6 +232,12 @@ int knp_comm_init(knp_ctx* ctx, int rank, int nranks, const char* id128);
  * overlaps the launch over the interior cells; knp_set_interior declares how many leading owned cells have no ghost neighbour
  * (checked).  Without these two calls every exchange runs on the context's stream in front of the apply. */
 int knp_comm_init_halo(knp_ctx* ctx, const char* id128);
+/* Instead of knp_comm_init: a host-staged communicator through the POSIX shared-memory segment `name` for ranks that are processes
+ * of one node and may share one GPU (RCCL refuses that).  Same semantics -- summed / maximised reductions in rank order, peer halo
+ * exchange -- with every transfer staged through the host: a validation path (the partitioned solver with 2-4 ranks on a one-GPU
+ * box, tests/test_gpu_multirank.py), never the measured one.  red_doubles / out_doubles: capacity of a rank's reduction slot and
+ * halo outbox.  Call knp_halo_tables afterwards (it publishes where each peer finds its message and ends in a barrier). */
+int knp_comm_init_shm(knp_ctx* ctx, int rank, int nranks, const char* name, int64_t red_doubles, int64_t out_doubles);
 int knp_set_interior(knp_ctx* ctx, int64_t n_interior);
 /* send_cells: owned cell ids whose DoFs peer p needs, grouped by peer; ghosts of peer p occupy
  * cells [recv_offsets[p], recv_offsets[p]+recv_counts[p]). */

@@ -8,8 +8,14 @@
 #include "../../include/knpemi_hip.h"
 #include "knpemi_internal.hpp"
 #include <rccl/rccl.h>
+#include <atomic>
+#include <chrono>
 #include <cstring>
 #include <cstdlib>
+#include <fcntl.h>
+#include <sched.h>
+#include <sys/mman.h>
+#include <unistd.h>
 
 #define NCCLCHK(ctx, call)                                                         \
     do {                                                                           \
@@ -22,7 +28,10 @@
 
 static_assert(sizeof(ncclUniqueId) <= 128, "unique id must fit the ABI buffer");
 
+static void shm_destroy(knp_ctx* c);
+
 void comm_destroy(knp_ctx* c) {
+    shm_destroy(c);
     if (c->comm_halo) { ncclCommDestroy((ncclComm_t)c->comm_halo); c->comm_halo = nullptr; }
     if (c->comm) { ncclCommDestroy((ncclComm_t)c->comm); c->comm = nullptr; }
     if (c->halo_stream) { hipStreamDestroy(c->halo_stream); c->halo_stream = nullptr; }
@@ -30,15 +39,26 @@ void comm_destroy(knp_ctx* c) {
     if (c->halo_done) { hipEventDestroy(c->halo_done); c->halo_done = nullptr; }
 }
 
+static int shm_allreduce(knp_ctx* c, double* dev, int count, bool is_max);
+static int shm_halo_exchange(knp_ctx* c, double* v, int nfields, hipStream_t st);
+
 int allreduce_red(knp_ctx* c, double* red, int count) {
+    if (c->shm) return shm_allreduce(c, red, count, false);
     if (!c->comm) { c->err = "allreduce without communicator"; return -6; }
     NCCLCHK(c, ncclAllReduce(red, red, count, ncclDouble, ncclSum, (ncclComm_t)c->comm, c->stream));
     return 0;
 }
 
 int allreduce_max(knp_ctx* c, double* host_value) {
-    if (!c->comm) { c->err = "allreduce without communicator"; return -6; }
     double* d = c->scal + KNP_MAX_SYS * 12;            // reduction scratch (krylov.hpp: KS_N = 12)
+    if (c->shm) {
+        HIPCHK(c, hipMemcpyAsync(d, host_value, sizeof(double), hipMemcpyHostToDevice, c->stream));
+        int rc = shm_allreduce(c, d, 1, true);
+        if (rc) return rc;
+        HIPCHK(c, hipMemcpy(host_value, d, sizeof(double), hipMemcpyDeviceToHost));
+        return 0;
+    }
+    if (!c->comm) { c->err = "allreduce without communicator"; return -6; }
     HIPCHK(c, hipMemcpyAsync(d, host_value, sizeof(double), hipMemcpyHostToDevice, c->stream));
     NCCLCHK(c, ncclAllReduce(d, d, 1, ncclDouble, ncclMax, (ncclComm_t)c->comm, c->stream));
     HIPCHK(c, hipMemcpyAsync(host_value, d, sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -59,8 +79,124 @@ __global__ void k_halo_pack(const double* __restrict__ v, const int32_t* __restr
 
 static int halo_exchange_on(knp_ctx* c, double* v, int nfields, hipStream_t st, ncclComm_t comm);
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Host-staged communicator through POSIX shared memory (knp_comm_init_shm): the same three primitives as the RCCL path -- summed /
+// maximised reductions and the peer halo exchange -- for ranks that are PROCESSES OF ONE NODE, possibly sharing one GPU (RCCL
+// refuses two ranks on a device).  Its purpose is validation: it runs the whole partitioned solver (partition, ghost layer, halo
+// tables, pack / unpack, all-reduced Krylov scalars and restricted residuals, replicated hierarchies, membrane facets on a cut) with
+// 2..4 ranks on a one-GPU box against the single-rank solution (tests/test_gpu_multirank.py).  Every transfer is staged through the
+// host and every step ends in a barrier, so it is slow by construction and never the measured path.
+// Segment layout: header | per rank { directory[SHM_MAX_PEERS] | reduce slot [red_cap doubles] | outbox [out_cap doubles] }.
+// ---------------------------------------------------------------------------------------------------------------------------
+#define SHM_MAX_PEERS 64
+struct ShmHeader {
+    std::atomic<uint32_t> arrive;
+    std::atomic<uint32_t> gen;
+    uint32_t nranks;
+    uint32_t pad;
+    uint64_t red_cap, out_cap;
+};
+struct ShmDirEntry { int64_t peer, off, cnt; };
+struct ShmComm {
+    int rank = 0, nranks = 1;
+    size_t bytes = 0, rank_stride = 0;
+    char* base = nullptr;
+    uint64_t red_cap = 0, out_cap = 0;
+    std::vector<double> tmp;
+    ShmHeader* hdr() const { return reinterpret_cast<ShmHeader*>(base); }
+    char* rank_base(int r) const { return base + 4096 + (size_t)r * rank_stride; }
+    ShmDirEntry* dir(int r) const { return reinterpret_cast<ShmDirEntry*>(rank_base(r)); }
+    double* red(int r) const { return reinterpret_cast<double*>(rank_base(r) + sizeof(ShmDirEntry) * SHM_MAX_PEERS); }
+    double* out(int r) const { return red(r) + red_cap; }
+};
+
+static int shm_barrier(knp_ctx* c, ShmComm* s) {
+    ShmHeader* h = s->hdr();
+    const uint32_t g = h->gen.load(std::memory_order_acquire);
+    if (h->arrive.fetch_add(1, std::memory_order_acq_rel) + 1 == (uint32_t)s->nranks) {
+        h->arrive.store(0, std::memory_order_relaxed);
+        h->gen.store(g + 1, std::memory_order_release);
+        return 0;
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    while (h->gen.load(std::memory_order_acquire) == g) {
+        sched_yield();
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) { c->err = "shm communicator: a rank did not reach the barrier"; return -6; }
+    }
+    return 0;
+}
+
+static int shm_allreduce(knp_ctx* c, double* dev, int count, bool is_max) {
+    ShmComm* s = (ShmComm*)c->shm;
+    if ((uint64_t)count > s->red_cap) { c->err = "shm communicator: reduction longer than the slot (KNP_SHM_RED_DOUBLES)"; return -6; }
+    HIPCHK(c, hipMemcpyAsync(s->red(s->rank), dev, sizeof(double) * count, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    int rc;
+    if ((rc = shm_barrier(c, s))) return rc;
+    s->tmp.assign(s->red(0), s->red(0) + count);                      // rank order: every rank forms the same sum bit for bit
+    for (int r = 1; r < s->nranks; ++r) {
+        const double* q = s->red(r);
+        if (is_max) for (int i = 0; i < count; ++i) s->tmp[i] = q[i] > s->tmp[i] ? q[i] : s->tmp[i];
+        else for (int i = 0; i < count; ++i) s->tmp[i] += q[i];
+    }
+    if ((rc = shm_barrier(c, s))) return rc;                          // nobody refills a slot that is still being read
+    HIPCHK(c, hipMemcpyAsync(dev, s->tmp.data(), sizeof(double) * count, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+static int shm_halo_exchange(knp_ctx* c, double* v, int nfields, hipStream_t st) {
+    ShmComm* s = (ShmComm*)c->shm;
+    const int NV = c->nd;
+    const int64_t stride = c->m.nc * NV;
+    const int np = (int)c->halo_peer.size();
+    if ((uint64_t)(c->halo_send_total * KNP_MAX_SYS * NV) > s->out_cap) { c->err = "shm communicator: outbox too small (KNP_SHM_OUT_DOUBLES)"; return -6; }
+    for (int p = 0; p < np; ++p) {
+        const int64_t cnt = c->halo_send_cnt[p];
+        if (!cnt) continue;
+        const int64_t n = cnt * NV;
+        double* seg = c->halo_sendbuf + c->halo_send_off[p] * KNP_MAX_SYS * NV;
+        hipLaunchKernelGGL(k_halo_pack, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const double*)v,
+                           (const int32_t*)(c->halo_send_idx + c->halo_send_off[p]), cnt, nfields, stride, NV, seg);
+        HIPCHK(c, hipMemcpyAsync(s->out(s->rank) + c->halo_send_off[p] * KNP_MAX_SYS * NV, seg, sizeof(double) * nfields * n,
+                                 hipMemcpyDeviceToHost, st));
+    }
+    HIPCHK(c, hipStreamSynchronize(st));
+    int rc;
+    if ((rc = shm_barrier(c, s))) return rc;
+    for (int p = 0; p < np; ++p) {
+        const int peer = c->halo_peer[p];
+        const int64_t want = c->halo_recv_cnt[p];
+        if (!want) continue;
+        const ShmDirEntry* d = s->dir(peer);
+        int64_t off = -1;
+        for (int k = 0; k < SHM_MAX_PEERS; ++k)
+            if (d[k].peer == s->rank && d[k].cnt > 0) { if (d[k].cnt != want) { c->err = "shm halo exchange: count mismatch with the peer"; return -6; } off = d[k].off; break; }
+        if (off < 0) { c->err = "shm halo exchange: the peer sends nothing to this rank"; return -6; }
+        const double* src = s->out(peer) + off * KNP_MAX_SYS * NV;      // [field][cell][nv] of the peer's message
+        for (int f = 0; f < nfields; ++f)
+            HIPCHK(c, hipMemcpyAsync(v + (int64_t)f * stride + c->halo_recv_off[p] * NV, src + (int64_t)f * want * NV, sizeof(double) * want * NV,
+                                     hipMemcpyHostToDevice, st));
+    }
+    HIPCHK(c, hipStreamSynchronize(st));
+    return shm_barrier(c, s);                                          // outboxes may be refilled
+}
+
+static void shm_destroy(knp_ctx* c) {
+    ShmComm* s = (ShmComm*)c->shm;
+    if (!s) return;
+    if (s->base) munmap(s->base, s->bytes);
+    delete s;
+    c->shm = nullptr;
+}
+
 int halo_exchange(knp_ctx* c, double* v, int nfields) {
-    if (!c->dist || c->halo_peer.empty()) return 0;
+    if (!c->dist) return 0;
+    if (c->shm) {
+        if (nfields > KNP_MAX_SYS) { c->err = "halo exchange: too many fields"; return -1; }
+        return shm_halo_exchange(c, v, nfields, c->stream);          // every rank takes part in the barriers, with or without peers
+    }
+    if (c->halo_peer.empty()) return 0;
     if (!c->comm) { c->err = "halo exchange without communicator"; return -6; }
     return halo_exchange_on(c, v, nfields, c->stream, (ncclComm_t)c->comm);
 }
@@ -183,6 +319,53 @@ int knp_comm_init_halo(knp_ctx* c, const char* id128) {
     return 0;
 }
 
+// Host-staged communicator over a POSIX shared-memory segment `name` (all ranks of one node; see the block comment above).
+// red_doubles / out_doubles: capacity of a rank's reduction slot and halo outbox.  Rank 0 creates the segment, the others attach.
+int knp_comm_init_shm(knp_ctx* c, int rank, int nranks, const char* name, int64_t red_doubles, int64_t out_doubles) {
+    if (!c || !name || nranks < 1 || rank < 0 || rank >= nranks || red_doubles < 64 || out_doubles < 0) return -1;
+    if (c->comm || c->shm) { c->err = "communicator already initialised"; return -1; }
+    ShmComm* s = new ShmComm();
+    s->rank = rank; s->nranks = nranks; s->red_cap = (uint64_t)red_doubles; s->out_cap = (uint64_t)out_doubles;
+    s->rank_stride = ((sizeof(ShmDirEntry) * SHM_MAX_PEERS + sizeof(double) * (s->red_cap + s->out_cap) + 4095) / 4096) * 4096;
+    s->bytes = 4096 + s->rank_stride * (size_t)nranks;
+    int fd = -1;
+    if (rank == 0) {
+        shm_unlink(name);
+        fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
+        if (fd < 0 || ftruncate(fd, (off_t)s->bytes) != 0) { c->err = "shm communicator: cannot create the segment"; if (fd >= 0) close(fd); delete s; return -6; }
+    } else {
+        for (int tries = 0; tries < 900 && fd < 0; ++tries) {             // wait for rank 0 (up to 90 s)
+            fd = shm_open(name, O_RDWR, 0600);
+            if (fd >= 0) {
+                off_t len = lseek(fd, 0, SEEK_END);
+                if (len < (off_t)s->bytes) { close(fd); fd = -1; }
+            }
+            if (fd < 0) usleep(100000);
+        }
+        if (fd < 0) { c->err = "shm communicator: segment of rank 0 not found"; delete s; return -6; }
+    }
+    s->base = (char*)mmap(nullptr, s->bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (s->base == MAP_FAILED) { c->err = "shm communicator: mmap failed"; s->base = nullptr; delete s; return -6; }
+    ShmHeader* h = s->hdr();
+    if (rank == 0) {                                                         // a fresh segment is zero-filled
+        h->red_cap = s->red_cap; h->out_cap = s->out_cap;
+        h->nranks = (uint32_t)nranks;                                        // published last: the others wait for it
+    } else {
+        for (int tries = 0; tries < 900 && ((volatile ShmHeader*)h)->nranks != (uint32_t)nranks; ++tries) usleep(100000);
+        if (h->nranks != (uint32_t)nranks || h->red_cap != s->red_cap || h->out_cap != s->out_cap) {
+            c->err = "shm communicator: ranks disagree about the segment layout"; munmap(s->base, s->bytes); delete s; return -6;
+        }
+    }
+    for (int k = 0; k < SHM_MAX_PEERS; ++k) s->dir(rank)[k] = ShmDirEntry{-1, 0, 0};
+    c->shm = s;
+    c->rank = rank; c->nranks = nranks;
+    c->dist = true;
+    int rc = shm_barrier(c, s);
+    if (rc == 0 && rank == 0) shm_unlink(name);                              // everyone is attached: the name can go
+    return rc;
+}
+
 int knp_halo_tables(knp_ctx* c, int npeers, const int32_t* peers, const int64_t* send_counts, const int32_t* send_cells,
                     const int64_t* recv_offsets, const int64_t* recv_counts) {
     if (!c || npeers < 0) return -1;
@@ -209,6 +392,12 @@ int knp_halo_tables(knp_ctx* c, int npeers, const int32_t* peers, const int64_t*
         HIPCHK(c, hipMalloc((void**)&c->halo_send_idx, sizeof(int32_t) * total));
         HIPCHK(c, hipMemcpy(c->halo_send_idx, send_cells, sizeof(int32_t) * total, hipMemcpyHostToDevice));
         HIPCHK(c, hipMalloc((void**)&c->halo_sendbuf, sizeof(double) * total * KNP_MAX_SYS * c->nd));
+    }
+    if (c->shm) {                                                            // where each peer finds its message in this rank's outbox
+        ShmComm* s = (ShmComm*)c->shm;
+        if (npeers > SHM_MAX_PEERS) { c->err = "shm communicator: too many peers"; return -1; }
+        for (int p = 0; p < npeers; ++p) s->dir(s->rank)[p] = ShmDirEntry{peers[p], c->halo_send_off[p], c->halo_send_cnt[p]};
+        return shm_barrier(c, s);
     }
     return 0;
 }

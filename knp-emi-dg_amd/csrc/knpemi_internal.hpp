@@ -121,6 +121,7 @@ struct knp_ctx {
     // distributed
     void* comm = nullptr;          // ncclComm_t: reductions + serial halo exchanges, on the context's stream
     void* comm_halo = nullptr;     // ncclComm_t of the overlapped halo exchanges, on halo_stream
+    void* shm = nullptr;           // host-staged shared-memory communicator (comm.hip: knp_comm_init_shm), instead of RCCL
     hipStream_t halo_stream = nullptr;
     hipEvent_t halo_ready = nullptr, halo_done = nullptr;
     int rank = 0, nranks = 1;

@@ -66,6 +66,7 @@ SIGNATURES = {
     "knp_comm_unique_id": (C.c_int, [C.c_char_p]),
     "knp_comm_init": (C.c_int, [_ctxp, C.c_int, C.c_int, C.c_char_p]),
     "knp_comm_init_halo": (C.c_int, [_ctxp, C.c_char_p]),
+    "knp_comm_init_shm": (C.c_int, [_ctxp, C.c_int, C.c_int, C.c_char_p, C.c_int64, C.c_int64]),
     "knp_set_interior": (C.c_int, [_ctxp, C.c_int64]),
     "knp_halo_tables": (C.c_int, [_ctxp, C.c_int, _i32p, _i64p, _i32p, _i64p, _i64p]),
     "knp_halo_exchange": (C.c_int, [_ctxp, C.c_int]),
@@ -486,6 +487,12 @@ class Device:
         self.nranks = int(nranks)
         if uid_halo is not None:
             self._chk(self.lib.knp_comm_init_halo(self.ctx, uid_halo), "knp_comm_init_halo")
+
+    def comm_init_shm(self, rank, nranks, name, red_doubles, out_doubles):
+        """Host-staged shared-memory communicator (include/knpemi_hip.h: knp_comm_init_shm): validation runs with several ranks
+        on one GPU."""
+        self._chk(self.lib.knp_comm_init_shm(self.ctx, rank, nranks, name.encode(), int(red_doubles), int(out_doubles)), "knp_comm_init_shm")
+        self.nranks = int(nranks)
 
     def set_interior(self, n_interior):
         self._chk(self.lib.knp_set_interior(self.ctx, int(n_interior)), "knp_set_interior")

@@ -170,10 +170,19 @@ def distribute_solver(solver_factory, mesh_tuple, ode_models, stim_params, rank,
     S.setup_parameters()
     S.setup_FEM_spaces()
     S.setup_membrane_model(stim_params, ode_models)
-    # RCCL communicators: rank 0 creates the ids, torch.distributed carries them to the others
-    uid = [(_abi.comm_unique_id(), _abi.comm_unique_id()) if rank == 0 else None]
-    dist.broadcast_object_list(uid, src=0)
-    S.dev.comm_init(rank, world, uid[0][0], uid_halo=uid[0][1])
+    import os
+    shm = os.environ.get("KNP_COMM_SHM")
+    if shm:
+        # validation runs with several ranks on ONE GPU (RCCL refuses that): host-staged shared-memory communicator, no torch.distributed
+        # (every rank must ask for the same segment layout: capacities from global quantities only)
+        ncg_bound = 4 * (mesh.coords.shape[0] + 8 * mesh.num_cells() // 4)            # conforming P1 / P2 dofs, two columns
+        most_sent = max(sum(len(sl) for sl in part.local(r).send_lists) for r in range(world))
+        S.dev.comm_init_shm(rank, world, shm, max(ncg_bound, 1 << 16), max(most_sent, 1) * 7 * S.nd)
+    else:
+        # RCCL communicators: rank 0 creates the ids, torch.distributed carries them to the others
+        uid = [(_abi.comm_unique_id(), _abi.comm_unique_id()) if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        S.dev.comm_init(rank, world, uid[0][0], uid_halo=uid[0][1])
     S.dev.halo_tables(loc.peers, loc.send_lists, loc.recv_offsets, loc.recv_counts)
     return S
 

@@ -1,0 +1,69 @@
+"""The partitioned solver END TO END with several ranks on one GPU: every rank is a process with its own device context on cuda:0 and
+the host-staged shared-memory communicator (knp_comm_init_shm) in place of RCCL, which refuses two ranks on a device.  Everything
+around the transport runs as on a multi-GPU node -- partition, ghost layer, halo tables, pack / unpack, all-reduced Krylov scalars
+and restricted residuals, replicated hierarchies, membrane facets and ODE nodes on a cut -- and the result must be the single-rank
+solution."""
+import os
+import subprocess
+import sys
+import uuid
+
+import numpy as np
+import pytest
+
+from common import relerr
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _single_rank(n_axons, steps):
+    from common_examples import make_solver, solver_parameters, Constant
+    S = make_solver(dim=3, resolution=0, n_axons=n_axons)
+    S._unpack_solver_params(solver_parameters(3, 0)._replace(rtol_emi=1e-10, rtol_knp=1e-12))
+    S.save_fields = S.save_solver_stats = False
+    S.splitting_scheme = True
+    S.setup_varform_emi(); S.setup_varform_knp(); S.setup_solver_emi(); S.setup_solver_knp()
+    t = Constant(0.0)
+    for k in range(steps):
+        S.step_membrane_models(k)
+        S.solve_for_time_step(k, t)
+    nc = S.mesh.num_cells()
+    x = S.mesh.coords[S.mesh.cells]
+    vol = np.abs(np.linalg.det(x[:, 1:] - x[:, :1])) / 6.0
+    out = (S.c.array().reshape(S.N_ions, nc, S.nd).copy(), S.phi.array().reshape(nc, S.nd).copy(), vol, list(S.emi_niter))
+    S.dev.close()
+    return out
+
+
+@pytest.mark.parametrize("world,method,n_axons", [(2, "slab", 4), (3, "slab", 4), (3, "rcb", 1)])
+def test_partitioned_solver_with_several_ranks_on_one_gpu(hip_lib, tmp_path, world, method, n_axons):
+    steps = 3
+    name = "/knp_%s" % uuid.uuid4().hex[:16]
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "multirank_worker.py"), str(r), str(world), name, str(tmp_path), method,
+                               str(n_axons), str(steps)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    logs = []
+    try:
+        for p in procs:
+            out, _ = p.communicate(timeout=240)
+            logs.append(out)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    assert all(p.returncode == 0 for p in procs), "\n".join(l[-2000:] for l in logs)
+    c_ref, phi_ref, vol, emi_ref = _single_rank(n_axons, steps)
+    nc = c_ref.shape[1]
+    c = np.full_like(c_ref, np.nan)
+    phi = np.full_like(phi_ref, np.nan)
+    seen = np.zeros(nc, dtype=int)
+    for r in range(world):
+        d = np.load(os.path.join(str(tmp_path), "rank%d.npz" % r))
+        c[:, d["cells"]] = d["c"]
+        phi[d["cells"]] = d["phi"]
+        seen[d["cells"]] += 1
+        assert len(d["emi_its"]) == steps and d["emi_its"].max() < 200 and d["knp_its"].max() < 200
+    assert (seen == 1).all()                                   # every cell owned by exactly one rank
+    mean = lambda p: p - (p.mean(axis=1) * vol).sum() / vol.sum()
+    assert relerr(c, c_ref) < 1e-8
+    assert relerr(mean(phi), mean(phi_ref)) < 1e-6
