@@ -134,6 +134,9 @@ def main():
             raise SystemExit("launch with torch.distributed.run for --gpus > 1")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback)")
+    shm_ranks = bool(os.environ.get("KNP_COMM_SHM"))      # validation only: several ranks on ONE GPU over the shared-memory communicator
+    if shm_ranks:
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dist = None
     # KNP_FORCE_COMM=1 takes the distributed code path (process group, slab partition, RCCL communicator) with one rank
@@ -141,7 +144,10 @@ def main():
     if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if shm_ranks:
+            dist.init_process_group("gloo")                # RCCL refuses two ranks on one device; the solver's own traffic goes through shm
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from idealized_common import make_solver, solver_parameters, Constant
     from knpemidg import _abi as A
@@ -206,7 +212,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if shm_ranks else "cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     ms_per_step = 1e3 * elapsed / args.steps

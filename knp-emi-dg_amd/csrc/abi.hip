@@ -233,14 +233,22 @@ int knp_ctx_create(knp_ctx** out, int device, int dim, int degree, int n_ions, i
                 }
             hmax = std::max(hmax, (int)L.size());
         }
+        // a partition's cells on the cut come last and sit in a plane: nearly all their neighbours are outside their block.  Blocks
+        // whose list does not fit one entry per thread are left to the LDS-staged kernel: the halo-staged one covers [0, hb_long0 * 256)
+        int64_t long0 = nblk;
+        for (int64_t b = 0; b < nblk; ++b)
+            if ((int64_t)lists[(size_t)b].size() > B) { long0 = b; break; }
+        hmax = 0;
+        for (int64_t b = 0; b < long0; ++b) hmax = std::max(hmax, (int)lists[(size_t)b].size());
         const int hs = ((hmax + 7) / 8) * 8;
-        if (hs > 0 && hs <= B) {                                   // one list entry per thread of the block
+        if (hs > 0 && long0 > 0) {
             std::vector<int32_t> hsrc((size_t)nblk * hs, -1);
-            for (int64_t b = 0; b < nblk; ++b) std::copy(lists[(size_t)b].begin(), lists[(size_t)b].end(), hsrc.begin() + b * hs);
+            for (int64_t b = 0; b < long0; ++b) std::copy(lists[(size_t)b].begin(), lists[(size_t)b].end(), hsrc.begin() + b * hs);
             rc |= dev_alloc_copy(c, &m.hb_src, hsrc.data(), hsrc.size());
             rc |= dev_alloc_copy(c, &m.hb_loc, hloc.data(), hloc.size());
             rc |= dev_zeros(c, &c->halo_ctr, 2 * 2 * 64 * 32);          // [2 operators][2 sets][64 queues], one 128-byte line per counter
             m.hb_stride = hs;
+            m.hb_long0 = long0;
         }
     }
     if (rc) { g_err = c->err; delete c; return -2; }

@@ -1046,12 +1046,12 @@ static int* halo_counters(knp_ctx* c, int which, int* flip_nq) {
 }
 // persistent grid: as many workgroups as fit on the chip at once (a multiple of the 64 chunk queues), at most one per block;
 // KNP_HALO_WG_PER_CU overrides the occupancy query (tuning)
-template <typename KernelT> static dim3 halo_grid(const knp_ctx* c, KernelT kernel, size_t lds) {
-    const int64_t nb = (c->m.c_end - 1) / KNP_HALO_BLK - c->m.c_begin / KNP_HALO_BLK + 1;
+template <typename KernelT> static dim3 halo_grid(const MeshDev& m, int device, KernelT kernel, size_t lds) {
+    const int64_t nb = (m.c_end - 1) / KNP_HALO_BLK - m.c_begin / KNP_HALO_BLK + 1;
     static int ncu = 0;
     if (!ncu) {
         hipDeviceProp_t prop;
-        ncu = (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+        ncu = (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
     }
     int per_cu = env_int("KNP_HALO_WG_PER_CU", 0);
     if (per_cu <= 0) {
@@ -1121,41 +1121,46 @@ static KnpArgs make_knp_args(knp_ctx* c) {
 }
 
 template <int D> static int knp_apply_dispatch(knp_ctx* c, const double* x, const double* gphi, double* y) {
-    const int64_t n = c->m.c_end - c->m.c_begin;
-    if (n <= 0) return 0;
-    const dim3 g((unsigned)grid8(n)), b(KNP_BLOCK);
+    if (c->m.c_end - c->m.c_begin <= 0) return 0;
+    const dim3 b(KNP_BLOCK);
     const KnpArgs ka = make_knp_args(c);
     size_t lds = 0;
     bool matp = false;
-    if (D == 3 && knp_halo_usable(c, &lds, &matp)) {
+    MeshDev m = c->m;                          // the cell range of this launch (the halo-staged kernel may take only its front part)
+    if (D == 3 && knp_halo_usable(c, &lds, &matp) && m.c_begin < c->m.hb_long0 * KNP_HALO_BLK) {
         const unsigned ent = halo_entries(c);
         const dim3 hb(KNP_HALO_BLK);
         int flip_nq = 0;
         int* ctr = halo_counters(c, 1, &flip_nq);
+        m.c_end = std::min<int64_t>(c->m.c_end, c->m.hb_long0 * KNP_HALO_BLK);
 #define KNP_HALO_LAUNCH(NS_, MAT_)                                                                                                   \
-    hipLaunchKernelGGL((k_knp_apply_halo<NS_, MAT_>), halo_grid(c, k_knp_apply_halo<NS_, MAT_>, lds), hb, lds, c->stream, c->m, x, gphi,   \
-                       c->D, y, ka, ent, (const uint8_t*)c->mat, (const uint8_t*)c->nmat4, (const double*)c->dtab, ctr, flip_nq)
+    hipLaunchKernelGGL((k_knp_apply_halo<NS_, MAT_>), halo_grid(m, c->device, k_knp_apply_halo<NS_, MAT_>, lds), hb, lds, c->stream, m, x,   \
+                       gphi, c->D, y, ka, ent, (const uint8_t*)c->mat, (const uint8_t*)c->nmat4, (const double*)c->dtab, ctr, flip_nq)
         if (c->p.n_sys == 1) { if (matp) KNP_HALO_LAUNCH(1, true); else KNP_HALO_LAUNCH(1, false); }
         else if (matp) KNP_HALO_LAUNCH(2, true);
         else KNP_HALO_LAUNCH(2, false);
 #undef KNP_HALO_LAUNCH
         HIPCHK(c, hipGetLastError());
-        return 0;
+        if (m.c_end >= c->m.c_end) return 0;
+        m.c_begin = m.c_end;                   // blocks with long neighbour lists (a partition's cut cells): LDS-staged kernel below
+        m.c_end = c->m.c_end;
     }
+    const int64_t nrest = m.c_end - m.c_begin;
+    const dim3 gr((unsigned)grid8(nrest));
     if (D == 3 && c->m.cls && c->m.ncls <= CLS_MAX_LDS && c->p.n_sys <= 3) {
         switch (c->p.n_sys) {
-            case 1: hipLaunchKernelGGL((k_knp_apply_cls_staged<3, 1, 256>), g, b, 0, c->stream, c->m, x, gphi, c->D, y, ka); break;
-            case 2: hipLaunchKernelGGL((k_knp_apply_cls_staged<3, 2, 256>), g, b, 0, c->stream, c->m, x, gphi, c->D, y, ka); break;
-            default: hipLaunchKernelGGL((k_knp_apply_cls_staged<3, 3, 256>), g, b, 0, c->stream, c->m, x, gphi, c->D, y, ka); break;
+            case 1: hipLaunchKernelGGL((k_knp_apply_cls_staged<3, 1, 256>), gr, b, 0, c->stream, m, x, gphi, c->D, y, ka); break;
+            case 2: hipLaunchKernelGGL((k_knp_apply_cls_staged<3, 2, 256>), gr, b, 0, c->stream, m, x, gphi, c->D, y, ka); break;
+            default: hipLaunchKernelGGL((k_knp_apply_cls_staged<3, 3, 256>), gr, b, 0, c->stream, m, x, gphi, c->D, y, ka); break;
         }
         HIPCHK(c, hipGetLastError());
         return 0;
     }
     switch (c->p.n_sys) {
-        case 1: hipLaunchKernelGGL((k_knp_apply<D, 1>), g, b, 0, c->stream, c->m, x, gphi, c->D, y, ka); break;
-        case 2: hipLaunchKernelGGL((k_knp_apply<D, 2>), g, b, 0, c->stream, c->m, x, gphi, c->D, y, ka); break;
-        case 3: hipLaunchKernelGGL((k_knp_apply<D, 3>), g, b, 0, c->stream, c->m, x, gphi, c->D, y, ka); break;
-        case 4: hipLaunchKernelGGL((k_knp_apply<D, 4>), g, b, 0, c->stream, c->m, x, gphi, c->D, y, ka); break;
+        case 1: hipLaunchKernelGGL((k_knp_apply<D, 1>), gr, b, 0, c->stream, m, x, gphi, c->D, y, ka); break;
+        case 2: hipLaunchKernelGGL((k_knp_apply<D, 2>), gr, b, 0, c->stream, m, x, gphi, c->D, y, ka); break;
+        case 3: hipLaunchKernelGGL((k_knp_apply<D, 3>), gr, b, 0, c->stream, m, x, gphi, c->D, y, ka); break;
+        case 4: hipLaunchKernelGGL((k_knp_apply<D, 4>), gr, b, 0, c->stream, m, x, gphi, c->D, y, ka); break;
         default: c->err = "knp_apply supports 1..4 solved species"; return -1;
     }
     HIPCHK(c, hipGetLastError());

@@ -44,7 +44,8 @@ struct MeshDev {
     int32_t* hb_src = nullptr;     // [nblk][hb_stride]: 4 * neighbour cell + its local facet, one entry per coupled facet whose neighbour lies
                                    // outside the block; -1 behind the block's last entry
     uint16_t* hb_loc = nullptr;    // [nc_owned][4] LDS entry of the neighbour behind facet i: < 256 in-block cell, else 256 + position in the list
-    int hb_stride = 0;             // longest list, rounded up to 8 (0: no tables, or a list longer than one entry per thread)
+    int hb_stride = 0;             // longest list of the blocks [0, hb_long0), rounded up to 8 (0: no tables)
+    int64_t hb_long0 = 0;          // first block whose list is longer than one entry per thread (cut cells of a partition), else the block count
 };
 #define KNP_CLS_STRIDE 36
 #define KNP_HALO_BLK 256
