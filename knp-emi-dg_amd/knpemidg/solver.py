@@ -410,10 +410,11 @@ class Solver:
         return q
 
     def _knp_level0_degree(self):
-        # one GPU: one Jacobi step on the finest conforming level.  With a communicator the hierarchy is replicated and the
-        # restricted residual is all-reduced: a transfer-only finest level lets that happen on level 1 (6.5x fewer bytes, no
-        # replicated level-0 SpMVs) for ~20 % more iterations
-        return 0 if getattr(self, "local_mesh", None) is not None and getattr(self.dev, "nranks", 1) > 1 else 1
+        # one Jacobi step on the finest conforming level, on one GPU and on partitions alike.  (With a communicator the hierarchy is
+        # replicated and the restricted residual is all-reduced; a transfer-only finest level would let that happen on level 1 --
+        # 6.5x fewer bytes, no replicated level-0 SpMVs -- but costs 50 % more BiCGStab iterations: 9.9 instead of 6.6 per step in
+        # a 4-rank run of the r=2 mesh, which only pays for itself beyond 8 ranks.)
+        return 1
 
     def _start_knp_helper(self):
         """KNP hierarchies depend only on the mesh, D_k and dt: a helper process builds them while this process creates the device
@@ -423,7 +424,7 @@ class Solver:
             return
         from knpemidg import setup_worker
         g = getattr(self, "global_mesh_tuple", None) or (self.mesh, self.subdomains, self.surfaces)
-        d0 = 0 if getattr(self, "global_mesh_tuple", None) is not None and int(os.environ.get("WORLD_SIZE", "1")) > 1 else 1
+        d0 = self._knp_level0_degree()
         job = setup_worker.job_from_solver(g[0], g[1].array(), g[2].array(), self.membrane_tags, self.degree_knp,
                                            [ion['D_sub'] for ion in self.ion_list[:-1]], _f(self.params.dt), d0)
         self._knp_helper = (setup_worker.start(job), d0)
