@@ -67,6 +67,12 @@ def start(job):
     env["PYTHONPATH"] = pkg_parent + os.pathsep + env.get("PYTHONPATH", "")
     for k in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
         env[k] = ""                               # host work only
+    # torch.distributed.run pins OMP_NUM_THREADS to 1 for its workers: the helper's LAPACK calls get this rank's share of the cores
+    world = max(1, int(env.get("WORLD_SIZE", "1") or 1))
+    if world > 1:
+        share = str(max(1, (os.cpu_count() or 1) // world))
+        for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+            env[k] = share
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     proc = subprocess.Popen([sys.executable, "-m", "knpemidg.setup_worker"], stdin=subprocess.PIPE, stdout=subprocess.PIPE, env=env)

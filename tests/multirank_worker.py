@@ -16,12 +16,19 @@ from knpemidg.mesh import make_mesh_3D                                          
 from knpemidg.models import mm_hh, mm_hh_no_stim                                                    # noqa: E402
 from knpemidg.partition import distribute_solver                                                    # noqa: E402
 
-mesh_tuple = make_mesh_3D(0, n_axons=n_axons)
-ode_models = {1: mm_hh, 2: mm_hh_no_stim} if n_axons > 1 else {1: mm_hh}
-params, ion_list, stim_params = physical_setup(1.0e-4)
-S = distribute_solver(lambda: SolverIdealized(params, ion_list, degree_emi=1, degree_knp=1), mesh_tuple, ode_models, stim_params,
-                      rank, world, 0, None, method=method)
-S._unpack_solver_params(solver_parameters(3, 0)._replace(rtol_emi=1e-10, rtol_knp=1e-12))
+if method == "emix":
+    # BASELINE configs[4]: the EMIx tissue reconstruction (unstructured, glial + neuronal membranes), RCB partition
+    sys.path.insert(0, os.path.join(ROOT, "examples", "emix_simulations"))
+    import emix_common
+    S = emix_common.make_distributed_solver(rank, world, 0, None)
+    S._unpack_solver_params(emix_common.solver_parameters()._replace(rtol_emi=1e-10, rtol_knp=1e-12))
+else:
+    mesh_tuple = make_mesh_3D(0, n_axons=n_axons)
+    ode_models = {1: mm_hh, 2: mm_hh_no_stim} if n_axons > 1 else {1: mm_hh}
+    params, ion_list, stim_params = physical_setup(1.0e-4)
+    S = distribute_solver(lambda: SolverIdealized(params, ion_list, degree_emi=1, degree_knp=1), mesh_tuple, ode_models, stim_params,
+                          rank, world, 0, None, method=method)
+    S._unpack_solver_params(solver_parameters(3, 0)._replace(rtol_emi=1e-10, rtol_knp=1e-12))
 S.save_fields = S.save_solver_stats = False
 S.splitting_scheme = True
 S.setup_varform_emi(); S.setup_varform_knp(); S.setup_solver_emi(); S.setup_solver_knp()
