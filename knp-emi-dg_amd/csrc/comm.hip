@@ -224,22 +224,27 @@ int dist_apply(knp_ctx* c, int which, double* x, const double* coef, double* y) 
     }
     const int nfields = which == 0 ? 1 : c->p.n_sys;
     int rc;
-    if (!c->comm_halo || c->halo_peer.empty() || c->m.n_interior <= 0) {
+    // overlap needs a second channel for the exchange: the halo communicator (RCCL) or the shm communicator's own stream.
+    // (shm: every rank takes the same branch -- the barriers inside the exchange must pair up -- so the peer list does not decide)
+    const bool overlap = c->halo_stream && c->m.n_interior > 0 && (c->shm || (c->comm_halo && !c->halo_peer.empty()));
+    if (!overlap) {
         if ((rc = halo_exchange(c, x, nfields))) return rc;
         return launch();
     }
     HIPCHK(c, hipEventRecord(c->halo_ready, c->stream));                 // x is final
     HIPCHK(c, hipStreamWaitEvent(c->halo_stream, c->halo_ready, 0));
-    if ((rc = halo_exchange_on(c, x, nfields, c->halo_stream, (ncclComm_t)c->comm_halo))) return rc;
-    HIPCHK(c, hipEventRecord(c->halo_done, c->halo_stream));
     const int64_t n_own = c->m.nc_owned;
     c->m.c_begin = 0; c->m.c_end = c->m.n_interior;
-    rc = launch();                                                       // needs no ghost value
-    if (!rc) {
-        HIPCHK(c, hipStreamWaitEvent(c->stream, c->halo_done, 0));
-        c->m.c_begin = c->m.n_interior; c->m.c_end = n_own;
-        rc = launch();
-    }
+    rc = launch();                                                       // needs no ghost value: runs while the exchange is in flight
+    c->m.c_begin = 0; c->m.c_end = n_own;
+    if (rc) return rc;
+    if (c->shm) rc = shm_halo_exchange(c, x, nfields, c->halo_stream);   // (host-staged: returns when the ghosts have arrived)
+    else rc = halo_exchange_on(c, x, nfields, c->halo_stream, (ncclComm_t)c->comm_halo);
+    if (rc) return rc;
+    HIPCHK(c, hipEventRecord(c->halo_done, c->halo_stream));
+    HIPCHK(c, hipStreamWaitEvent(c->stream, c->halo_done, 0));
+    c->m.c_begin = c->m.n_interior; c->m.c_end = n_own;
+    rc = launch();
     c->m.c_begin = 0; c->m.c_end = n_own;
     return rc;
 }
@@ -361,6 +366,11 @@ int knp_comm_init_shm(knp_ctx* c, int rank, int nranks, const char* name, int64_
     c->shm = s;
     c->rank = rank; c->nranks = nranks;
     c->dist = true;
+    if (!(getenv("KNP_HALO_OVERLAP") && atoi(getenv("KNP_HALO_OVERLAP")) == 0)) {     // the overlapped apply, as with the halo communicator
+        HIPCHK(c, hipStreamCreate(&c->halo_stream));
+        HIPCHK(c, hipEventCreateWithFlags(&c->halo_ready, hipEventDisableTiming));
+        HIPCHK(c, hipEventCreateWithFlags(&c->halo_done, hipEventDisableTiming));
+    }
     int rc = shm_barrier(c, s);
     if (rc == 0 && rank == 0) shm_unlink(name);                              // everyone is attached: the name can go
     return rc;
