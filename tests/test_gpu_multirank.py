@@ -75,3 +75,25 @@ def test_partitioned_solver_with_several_ranks_on_one_gpu(hip_lib, tmp_path, wor
     mean = lambda p: p - (p.mean(axis=1) * vol).sum() / vol.sum()
     assert relerr(c, c_ref) < 1e-8
     assert relerr(mean(phi), mean(phi_ref)) < 1e-6
+
+
+def test_bench_contract_with_two_ranks(hip_lib):
+    """bench.py launched the way the driver launches it for N > 1 (torch.distributed.run, one rank per process), here with both ranks
+    on the one GPU over the shm communicator: exactly one JSON line from rank 0, whole-job value, the fields of the contract."""
+    import json
+    root = os.path.dirname(HERE)
+    env = dict(os.environ, KNP_COMM_SHM="/knp_%s" % uuid.uuid4().hex[:16])
+    port = 29600 + (os.getpid() % 300)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--resolution", "0",
+           "--no-cpu-baseline"]
+    res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=420)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [l for l in res.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+                "data", "config", "roofline"):
+        assert key in d, key
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["value"] > 0 and d["scaling"] == "strong" and d["dtype"] == "f64"
+    assert d["config"]["parallelism"] == "slab2" and d["vs_baseline"] is None
