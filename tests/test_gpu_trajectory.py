@@ -148,6 +148,46 @@ def test_production_tolerances_r1_against_tight_solves(hip_lib, degree):
         S.dev.close()
 
 
+def test_production_tolerances_emix_against_tight_solves(hip_lib):
+    """BASELINE configs[4] (EMIx reconstruction, unstructured, glial + neuronal membranes) at the parameters its example ships
+    (examples/emix_simulations/emix_common.py: the tolerance factors calibrated on this mesh) against the same run converged to
+    1e-11 / 1e-13: the stated bounds at every one of 20 stimulated steps.  With the idealized meshes' factors the concentrations
+    are off by 7e-6 here (profiles/r02_tolerance_emix.txt)."""
+    import os
+    import sys
+    from common import mean_free
+    ex = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "emix_simulations")
+    if ex not in sys.path:
+        sys.path.insert(0, ex)
+    import emix_common as E
+    sol = []
+    for tight in (False, True):
+        S = E.make_solver()
+        sp = E.solver_parameters()
+        if tight:
+            sp = sp._replace(rtol_emi=1e-11, rtol_knp=1e-13)
+        S._unpack_solver_params(sp)
+        S.save_fields = S.save_solver_stats = False
+        S.splitting_scheme = True
+        S.setup_varform_emi(); S.setup_varform_knp(); S.setup_solver_emi(); S.setup_solver_knp()
+        sol.append(S)
+    vol = _cell_volumes(sol[0].mesh)
+    ts = [E.Constant(0.0), E.Constant(0.0)]
+    for k in range(20):
+        for S, t in zip(sol, ts):
+            S.step_membrane_models(k)
+            S.solve_for_time_step(k, t)
+        a, b = sol
+        e_phi = relerr(mean_free(a.phi.array(), vol), mean_free(b.phi.array(), vol))
+        e_c = max(relerr(x, y) for x, y in zip(a.c.array().reshape(a.N_ions, -1), b.c.array().reshape(b.N_ions, -1)))
+        pm_a, pm_b = a.phi_M_prev_PDE.array(), b.phi_M_prev_PDE.array()
+        mem = np.nonzero(pm_b)[0]
+        e_pm = relerr(pm_a[mem], pm_b[mem])
+        assert e_c < 1e-6 and e_phi < 1e-4 and e_pm < 1e-4, (k, e_c, e_phi, e_pm, a.emi_niter[-3:], a.knp_niter[-3:])
+    for S in sol:
+        S.dev.close()
+
+
 def test_full_size_properties_p2_r1(hip_lib):
     """BASELINE configs[2] mesh (r=1: 124 416 tets, 3.73 M P2 DoFs, two membrane tags) is too large for the oracle, so
     the P2 operators are checked through size-independent properties (the P2 twin of test_full_size_properties_r2): EMI
