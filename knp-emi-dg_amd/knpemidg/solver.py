@@ -484,7 +484,7 @@ class Solver:
         self._rtol_emi = float(getattr(sp, "rtol_direct", 1e-10)) if self.direct_emi else max(rt * scale, min(rt, 1.0e-11))
         self._atol_emi = 1e-40 if self.direct_emi else float(self.atol_emi)
         kscale = float(os.environ.get("KNP_KNP_RTOL_SCALE", getattr(sp, "knp_rtol_scale", None) or 1.0))
-        rk = float(self.rtol_knp)
+        rk = float(self.rtol_knp) if not self.direct_knp else 0.0
         self._rtol_knp = float(getattr(sp, "rtol_direct", 1e-10)) if self.direct_knp else max(rk * kscale, min(rk, 1.0e-13))
         self._atol_knp = 1e-40 if self.direct_knp else float(self.atol_knp)
 
