@@ -81,9 +81,17 @@ int knp_set_geometry_classes(knp_ctx* ctx, int ncls, const uint16_t* cls, const 
  * host and added to L_emi / L_knp; the solution-dependent term -jump(phi) jump(C v) is evaluated on the device. */
 int knp_set_mms(knp_ctx* ctx, const double* C, const double* extra_emi, const double* extra_knp);
 
-/* DG-p path (degree 2): reference-basis tabulation of one integral class.  The quadratic forms are integrated by
- * numerical quadrature once per time step into dense cell blocks (the device analogue of assemble(), solver.py:477-479,
- * 730-731); the rules and the basis tabulated at their points come from the host (knpemidg/dgtab.py).
+/* Ion sources that are not constants (ion['f_source'] is any UFL coefficient in the reference, solver.py:599; e.g. the box- and
+ * time-window Expression of examples/local-astrocyte-depolarization/run_tortuosity.py:180-200): src[n_sys][nc*nd] = the load
+ * vector int f_k v dx(0) integrated by the caller, added to L_knp by knp_knp_rhs; null clears.  Constant sources travel as
+ * fsrc[n_sys][nc] of knp_set_params. */
+int knp_set_source(knp_ctx* ctx, const double* src);
+
+/* DG-p path (degree 2): reference-basis tabulation of one integral class.  The operator applies are matrix-free and need
+ * no tabulation (csrc/apply_p2.hip); the right-hand sides, facet averages and Nernst projections of step III (the device
+ * analogue of assemble(L_emi / L_knp), solver.py:477-479, 730-731, and of pcws_constant_project, utils.py:100-124) are
+ * integrated by numerical quadrature from these tables; the rules and the basis tabulated at their points come from the host
+ * (knpemidg/dgtab.py).
  *  w[nq] weights summing to 1;  B[nloc][nq][nd] basis values;  dB[nloc][nq][nd][dim+1] derivatives with respect to
  *  the barycentric coordinates;  nloc = 1 for cell rules, dim+1 for facet rules (one tabulation per local facet, all
  *  with the same facet points: facet vertex m <-> cell vertex m + (m >= local facet index)).
@@ -107,6 +115,29 @@ int64_t knp_field_size(knp_ctx* ctx, int field);
 int knp_upload(knp_ctx* ctx, int field, const double* src, int64_t offset, int64_t count);
 int knp_download(knp_ctx* ctx, int field, double* dst, int64_t offset, int64_t count);
 int knp_copy_field(knp_ctx* ctx, int dst_field, int src_field);
+
+/* Inspection of the connectivity tables the library derives in knp_ctx_create from the raw cell / facet / tag arrays -- the
+ * device counterpart of interface_normal / plus / minus (utils.py:61-98) and of the dS / membrane facet classification by tag
+ * (solver.py:113-121).  `north_star` asks for bit-exact DoF / connectivity indexing: the parity tests read these tables back and
+ * compare them entry for entry with the oracle's independently derived ones (tests/test_gpu_tables.py).  All tables are in DEVICE
+ * cell order (the order of the `cells` argument of knp_ctx_create); facet ids are the caller's.
+ *  knp_debug_table_size: number of BYTES of table `which`, < 0 if unknown
+ *  knp_debug_table     : copies the table into out[nbytes]; nbytes must equal knp_debug_table_size */
+enum knp_debug_table_id {
+    KNP_DT_CELLS = 0,   /* int32  [nc][dim+1]  cell -> vertex (storage ids)                                                   */
+    KNP_DT_NBR = 1,     /* int32  [nc][dim+1]  cell behind local facet i (opposite vertex i), -1 on the boundary              */
+    KNP_DT_FLAG = 2,    /* uint32 [nc]         dim+1 flag bytes: bits 0-1 local facet index in the neighbour, bits 2-3 kind
+                                               (0 SIPG, 1 membrane, 2 exterior, 3 inactive), bit 4 this cell is the `plus` side */
+    KNP_DT_CFACET = 3,  /* int32  [nc][dim+1]  facet id behind local facet i                                                  */
+    KNP_DT_MF = 4,      /* int32  [nmf][6]     membrane facets: plus cell, minus cell, their local facet indices, facet id,
+                                               1 if a side is an owned cell                                                     */
+    KNP_DT_HB_SRC = 5,  /* int32  [nblk][hs]   halo-staged apply: per 256-cell block, 4 * cell + local facet of every SIPG
+                                               neighbour outside the block, in (cell, facet) order, -1 padded (0 bytes if unused) */
+    KNP_DT_HB_LOC = 6,  /* uint16 [nc_owned][4] LDS entry of the neighbour behind facet i: < 256 in-block, else 256 + list position */
+    KNP_DT_META = 7     /* int64  [8]          nc, nc_owned, nf, nmf, hb_stride, hb_long0, n_interior, dim                     */
+};
+int64_t knp_debug_table_size(knp_ctx* ctx, int which);
+int knp_debug_table(knp_ctx* ctx, int which, void* out, int64_t nbytes);
 
 /* ---- per-step coefficient updates ----------------------------------------------------------- */
 int knp_update_kappa(knp_ctx* ctx);        /* KAPPA <- C, C_ELIM                (solver.py:303-306) */
@@ -166,8 +197,9 @@ int knp_max_abs_diff(knp_ctx* ctx, int field_a, int field_b, double* out);
 int knp_facet_trace(knp_ctx* ctx, int field, int species, int side, int slot);
 
 /* ---- membrane ODEs: batched device integrator replacing the per-facet LSODA loop of
- * MembraneModel.step_lsoda (membrane.py:84-119).  model: 1 = Hodgkin-Huxley + stimulus (mm_hh.py), 2 = without
- * (mm_hh_no_stim.py).  Tables are [n][ns] states and [n][np] parameters in the reference's column layout.
+ * MembraneModel.step_lsoda (membrane.py:84-119).  model: 1 = Hodgkin-Huxley + stimulus (examples/idealized-geometries/mm_hh.py),
+ * 2 = without (mm_hh_no_stim.py), 3 = EMIx neuron (examples/emix-simulations/mm_hh.py), 4 = EMIx glia (mm_glial.py), 5 = passive
+ * leak (examples/rat-neuron/mm_leak.py).  Tables are [n][ns] states and [n][np] parameters in the reference's column layout.
  *  knp_ode_create  : returns a handle >= 0; facets[n] = facet id of every ODE node
  *  knp_ode_table   : what 0 = states, 1 = parameters; upload != 0 copies host -> device, else device -> host
  *  knp_ode_exchange: table column <- facet field (to_facet = 0, set_state/set_parameter) or facet field <- table

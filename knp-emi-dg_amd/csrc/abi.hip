@@ -396,6 +396,23 @@ int knp_set_geometry_classes(knp_ctx* c, int ncls, const uint16_t* cls, const do
     return 0;
 }
 
+// Host-integrated load vector of the ion sources, int f_k v dx(0) (solver.py:599), for sources that are not constants: added to
+// L_knp by the right-hand-side kernels.  src[n_sys][nc*nd] in device cell order, or null to clear.  (The manufactured-solution
+// mode owns the same buffer: knp_set_mms.)
+int knp_set_source(knp_ctx* c, const double* src) {
+    if (!c) return -1;
+    if (c->p.splitting == 2) { c->err = "knp_set_source: the manufactured-solution mode sets its own data terms"; return -1; }
+    const int64_t n = (int64_t)c->p.n_sys * c->m.nc * c->nd;
+    if (!src) {
+        hipFree(c->extra_knp);
+        c->extra_knp = nullptr;
+        return 0;
+    }
+    if (!c->extra_knp) HIPCHK(c, hipMalloc((void**)&c->extra_knp, sizeof(double) * n));
+    HIPCHK(c, hipMemcpy(c->extra_knp, src, sizeof(double) * n, hipMemcpyHostToDevice));
+    return 0;
+}
+
 int knp_set_mms(knp_ctx* c, const double* C, const double* extra_emi, const double* extra_knp) {
     if (!c) return -1;
     const int64_t ndof = c->m.nc * c->nd, ns = c->p.n_sys;
@@ -417,6 +434,40 @@ int knp_set_mms(knp_ctx* c, const double* C, const double* extra_emi, const doub
 }
 
 int64_t knp_field_size(knp_ctx* c, int field) { return chk_field(c, field) ? -1 : F(c)->n[field]; }
+
+static int64_t debug_table_ptr(knp_ctx* c, int which, const void** p) {
+    const MeshDev& m = c->m;
+    const int64_t NV = m.dim + 1;
+    const int64_t nblk = (m.nc_owned + KNP_HALO_BLK - 1) / KNP_HALO_BLK;
+    switch (which) {
+        case KNP_DT_CELLS: *p = m.cells; return m.nc * NV * 4;
+        case KNP_DT_NBR: *p = m.nbr; return m.nc * NV * 4;
+        case KNP_DT_FLAG: *p = m.fflag; return m.nc * 4;
+        case KNP_DT_CFACET: *p = m.cfacet; return m.nc * NV * 4;
+        case KNP_DT_MF: *p = m.mf; return m.nmf * 6 * 4;
+        case KNP_DT_HB_SRC: *p = m.hb_src; return m.hb_src ? nblk * m.hb_stride * 4 : 0;
+        case KNP_DT_HB_LOC: *p = m.hb_loc; return m.hb_loc ? m.nc_owned * 4 * 2 : 0;
+        case KNP_DT_META: *p = nullptr; return 8 * 8;
+        default: return -1;
+    }
+}
+int64_t knp_debug_table_size(knp_ctx* c, int which) {
+    const void* p = nullptr;
+    return c ? debug_table_ptr(c, which, &p) : -1;
+}
+int knp_debug_table(knp_ctx* c, int which, void* out, int64_t nbytes) {
+    if (!c) return -1;
+    const void* p = nullptr;
+    const int64_t n = debug_table_ptr(c, which, &p);
+    if (n < 0 || nbytes != n || (n && !out)) { c->err = "debug_table: unknown table or size mismatch"; return -1; }
+    if (which == KNP_DT_META) {
+        const int64_t meta[8] = {c->m.nc, c->m.nc_owned, c->m.nf, c->m.nmf, c->m.hb_stride, c->m.hb_long0, c->m.n_interior, c->m.dim};
+        memcpy(out, meta, sizeof(meta));
+        return 0;
+    }
+    if (n) HIPCHK(c, hipMemcpy(out, p, (size_t)n, hipMemcpyDeviceToHost));
+    return 0;
+}
 
 int knp_upload(knp_ctx* c, int field, const double* src, int64_t offset, int64_t count) {
     if (chk_field(c, field)) return -1;

@@ -1046,7 +1046,10 @@ static int* halo_counters(knp_ctx* c, int which, int* flip_nq) {
 }
 // persistent grid: as many workgroups as fit on the chip at once (a multiple of the 64 chunk queues), at most one per block;
 // KNP_HALO_WG_PER_CU overrides the occupancy query (tuning)
-template <typename KernelT> static dim3 halo_grid(const MeshDev& m, int device, KernelT kernel, size_t lds) {
+// reserve_cus: with an active communicator the interior launch runs next to the halo exchange (pack kernel + RCCL's send / receive
+// kernels on the high-priority halo stream, comm.hip): a persistent grid that occupies every CU would leave them nothing to run on
+// until its first workgroups retire, so it is sized for (CUs - reserve_cus).
+template <typename KernelT> static dim3 halo_grid(const MeshDev& m, int device, KernelT kernel, size_t lds, int reserve_cus) {
     const int64_t nb = (m.c_end - 1) / KNP_HALO_BLK - m.c_begin / KNP_HALO_BLK + 1;
     static int ncu = 0;
     if (!ncu) {
@@ -1067,7 +1070,8 @@ template <typename KernelT> static dim3 halo_grid(const MeshDev& m, int device, 
     }
     if (per_cu < 1) per_cu = 1;
     const int64_t nq = halo_queues();
-    int64_t g = std::min<int64_t>(((nb + nq - 1) / nq) * nq, (int64_t)per_cu * ncu);
+    const int cus = std::max(ncu - std::max(reserve_cus, 0), ncu / 2);
+    int64_t g = std::min<int64_t>(((nb + nq - 1) / nq) * nq, (int64_t)per_cu * cus);
     g = std::max<int64_t>(nq, (g / nq) * nq);
     return dim3((unsigned)g);
 }
@@ -1133,8 +1137,9 @@ template <int D> static int knp_apply_dispatch(knp_ctx* c, const double* x, cons
         int flip_nq = 0;
         int* ctr = halo_counters(c, 1, &flip_nq);
         m.c_end = std::min<int64_t>(c->m.c_end, c->m.hb_long0 * KNP_HALO_BLK);
+        const int reserve = (c->dist && c->halo_stream) ? env_int("KNP_HALO_RESERVE_CU", 8) : 0;
 #define KNP_HALO_LAUNCH(NS_, MAT_)                                                                                                   \
-    hipLaunchKernelGGL((k_knp_apply_halo<NS_, MAT_>), halo_grid(m, c->device, k_knp_apply_halo<NS_, MAT_>, lds), hb, lds, c->stream, m, x,   \
+    hipLaunchKernelGGL((k_knp_apply_halo<NS_, MAT_>), halo_grid(m, c->device, k_knp_apply_halo<NS_, MAT_>, lds, reserve), hb, lds, c->stream, m, x,   \
                        gphi, c->D, y, ka, ent, (const uint8_t*)c->mat, (const uint8_t*)c->nmat4, (const double*)c->dtab, ctr, flip_nq)
         if (c->p.n_sys == 1) { if (matp) KNP_HALO_LAUNCH(1, true); else KNP_HALO_LAUNCH(1, false); }
         else if (matp) KNP_HALO_LAUNCH(2, true);

@@ -226,7 +226,10 @@ int dist_apply(knp_ctx* c, int which, double* x, const double* coef, double* y) 
     int rc;
     // overlap needs a second channel for the exchange: the halo communicator (RCCL) or the shm communicator's own stream.
     // (shm: every rank takes the same branch -- the barriers inside the exchange must pair up -- so the peer list does not decide)
-    const bool overlap = c->halo_stream && c->m.n_interior > 0 && (c->shm || (c->comm_halo && !c->halo_peer.empty()));
+    // The choice of channel must not depend on anything rank-local: a rank whose owned cells ALL touch the cut (n_interior == 0)
+    // still posts its sends / receives on the halo communicator, like its peers -- point-to-point calls on different
+    // communicators never pair.  Its interior launch is empty (the dispatchers return at c_end <= c_begin).
+    const bool overlap = c->halo_stream && (c->shm || (c->comm_halo && !c->halo_peer.empty()));
     if (!overlap) {
         if ((rc = halo_exchange(c, x, nfields))) return rc;
         return launch();
@@ -278,6 +281,15 @@ static int halo_exchange_on(knp_ctx* c, double* v, int nfields, hipStream_t st, 
     return 0;
 }
 
+// The halo stream carries the pack kernel and RCCL's send / receive kernels while the interior launch of the apply occupies the
+// chip: highest priority, so that their workgroups are dispatched ahead of the interior launch's queued ones (the interior launch
+// also leaves a few CUs unoccupied when a communicator is active: apply_p1.hip halo_grid).
+static hipError_t create_halo_stream(knp_ctx* c) {
+    int lo = 0, hi = 0;                                                     // numerically LOWER = higher priority
+    if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { lo = hi = 0; }
+    return hipStreamCreateWithPriority(&c->halo_stream, hipStreamNonBlocking, hi);
+}
+
 extern "C" {
 
 int knp_comm_unique_id(char* out128) {
@@ -318,7 +330,7 @@ int knp_comm_init_halo(knp_ctx* c, const char* id128) {
     ncclComm_t comm;
     NCCLCHK(c, ncclCommInitRank(&comm, c->nranks, id, c->rank));
     c->comm_halo = comm;
-    HIPCHK(c, hipStreamCreate(&c->halo_stream));
+    HIPCHK(c, create_halo_stream(c));
     HIPCHK(c, hipEventCreateWithFlags(&c->halo_ready, hipEventDisableTiming));
     HIPCHK(c, hipEventCreateWithFlags(&c->halo_done, hipEventDisableTiming));
     return 0;
@@ -367,7 +379,7 @@ int knp_comm_init_shm(knp_ctx* c, int rank, int nranks, const char* name, int64_
     c->rank = rank; c->nranks = nranks;
     c->dist = true;
     if (!(getenv("KNP_HALO_OVERLAP") && atoi(getenv("KNP_HALO_OVERLAP")) == 0)) {     // the overlapped apply, as with the halo communicator
-        HIPCHK(c, hipStreamCreate(&c->halo_stream));
+        HIPCHK(c, create_halo_stream(c));
         HIPCHK(c, hipEventCreateWithFlags(&c->halo_ready, hipEventDisableTiming));
         HIPCHK(c, hipEventCreateWithFlags(&c->halo_done, hipEventDisableTiming));
     }

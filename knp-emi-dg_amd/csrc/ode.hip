@@ -13,7 +13,7 @@
 #define ODE_MAX_OPS 12
 
 struct OdeSet {
-    int model = 0;              // 1 = HH with synaptic stimulus, 2 = HH without, 3 = EMIx HH (cm/ms/mV), 4 = glial
+    int model = 0;              // 1 = HH with synaptic stimulus, 2 = HH without, 3 = EMIx HH (cm/ms/mV), 4 = glial, 5 = passive leak
     int ns = 0, np = 0;
     int64_t n = 0;
     int32_t* facet = nullptr;   // [n] facet id of every node
@@ -106,11 +106,28 @@ __device__ __forceinline__ void glial_rhs(double t, const double* y, double* p, 
     dy[0] = (-i_K - i_Na) / p[6];
 }
 
+// Passive membrane: Na / K leak + Na/K pump + decaying synaptic conductance on the Na leak, one state, SI units
+// (reference: examples/rat-neuron/mm_leak.py:107-133).  parameters (mm_leak.py:44-50): 0 g_leak_Na 1 g_leak_K 2 E_Na 3 E_K 4 Cm
+//  5 stim_amplitude 6 I_ch_Na 7 I_ch_K 8 I_ch_Cl 9 K_e 10 Na_i 11 m_K 12 m_Na 13 I_max 14 E_Cl
+__device__ __forceinline__ void leak_rhs(double t, const double* y, double* p, double* dy) {
+    const double V = y[0];
+    const double g_stim = p[5] * exp(-fmod(t, 0.03) / 0.002);
+    const double a = 1 + p[11] / p[9], b = 1 + p[12] / p[10];
+    const double i_pump = p[13] / (a * a * b * b * b);
+    const double i_Na = (p[0] + g_stim) * (V - p[2]) + 3 * i_pump;
+    const double i_K = p[1] * (V - p[3]) - 2 * i_pump;
+    p[6] = i_Na;
+    p[7] = i_K;
+    p[8] = 0.0;
+    dy[0] = (-i_K - i_Na) / p[4];
+}
+
 template <int MODEL> __device__ __forceinline__ void model_rhs(double t, const double* y, double* p, double* dy) {
     if (MODEL == 1) hh_rhs<true>(t, y, p, dy);
     else if (MODEL == 2) hh_rhs<false>(t, y, p, dy);
     else if (MODEL == 3) hh_emix_rhs(t, y, p, dy);
-    else glial_rhs(t, y, p, dy);
+    else if (MODEL == 4) glial_rhs(t, y, p, dy);
+    else leak_rhs(t, y, p, dy);
 }
 
 template <int MODEL, int NS, int NP>
@@ -253,9 +270,10 @@ extern "C" {
 int knp_ode_create(knp_ctx* c, int model, int64_t n, const int32_t* facets, int ns, int np, const double* states,
                    const double* params) {
     if (!c) return -1;
-    if (model < 1 || model > 4) { c->err = "ode: unknown device model id"; return -1; }
+    if (model < 1 || model > 5) { c->err = "ode: unknown device model id"; return -1; }
     if (model <= 3 && (ns != 4 || np != 17)) { c->err = "ode: HH models have 4 states and 17 parameters"; return -1; }
     if (model == 4 && (ns != 1 || np != 19)) { c->err = "ode: the glial model has 1 state and 19 parameters"; return -1; }
+    if (model == 5 && (ns != 1 || np != 15)) { c->err = "ode: the leak model has 1 state and 15 parameters"; return -1; }
     for (int64_t i = 0; i < n; ++i)
         if (facets[i] < 0 || facets[i] >= c->m.nf) { c->err = "ode: facet id out of range"; return -1; }
     OdeSet S;
@@ -367,7 +385,8 @@ int knp_ode_step(knp_ctx* c, int handle, double t0, double dt, double rtol, doub
     if (S->model == 1) ODE_LAUNCH(1, 4, 17);
     else if (S->model == 2) ODE_LAUNCH(2, 4, 17);
     else if (S->model == 3) ODE_LAUNCH(3, 4, 17);
-    else ODE_LAUNCH(4, 1, 19);
+    else if (S->model == 4) ODE_LAUNCH(4, 1, 19);
+    else ODE_LAUNCH(5, 1, 15);
 #undef ODE_LAUNCH
     HIPCHK(c, hipGetLastError());
     return 0;

@@ -16,6 +16,8 @@ F_PHI, F_C, F_C_PREV, F_C_ELIM, F_PHI_M, F_I_CH, F_E, F_KAPPA, F_DNPHI, F_B_EMI,
     F_FACET_TMP = range(14)
 
 FACET_TMP_SLOTS = 4        # KNP_FACET_TMP_SLOTS (include/knpemi_hip.h)
+# knp_debug_table_id (include/knpemi_hip.h)
+DT_CELLS, DT_NBR, DT_FLAG, DT_CFACET, DT_MF, DT_HB_SRC, DT_HB_LOC, DT_META = range(8)
 
 _f64p = C.POINTER(C.c_double)
 _i32p = C.POINTER(C.c_int32)
@@ -34,7 +36,10 @@ SIGNATURES = {
     "knp_set_geometry_classes": (C.c_int, [_ctxp, C.c_int, C.POINTER(C.c_uint16), _f64p]),
     "knp_set_tabulation": (C.c_int, [_ctxp, C.c_int, C.c_int, C.c_int, _f64p, _f64p, _f64p]),
     "knp_set_mms": (C.c_int, [_ctxp, _f64p, _f64p, _f64p]),
+    "knp_set_source": (C.c_int, [_ctxp, _f64p]),
     "knp_field_size": (C.c_int64, [_ctxp, C.c_int]),
+    "knp_debug_table_size": (C.c_int64, [_ctxp, C.c_int]),
+    "knp_debug_table": (C.c_int, [_ctxp, C.c_int, C.c_void_p, C.c_int64]),
     "knp_upload": (C.c_int, [_ctxp, C.c_int, _f64p, C.c_int64, C.c_int64]),
     "knp_download": (C.c_int, [_ctxp, C.c_int, _f64p, C.c_int64, C.c_int64]),
     "knp_copy_field": (C.c_int, [_ctxp, C.c_int, C.c_int]),
@@ -265,6 +270,7 @@ class Device:
         vorder = morton_order(mesh.coords, scale) if reorder else np.arange(nv, dtype=np.int64)
         vrank = np.empty(nv, dtype=np.int64)
         vrank[vorder] = np.arange(nv)
+        self.vertex_rank = vrank                                  # caller vertex id -> storage id
         coords = np.ascontiguousarray(mesh.coords[vorder], dtype=np.float64)
         cells = np.ascontiguousarray(vrank[mesh.cells[order]], dtype=np.int32)
         ctags = np.ascontiguousarray(np.asarray(cell_tags)[order], dtype=np.uint32)
@@ -346,6 +352,12 @@ class Device:
         ek = np.ascontiguousarray(np.asarray(extra_knp, dtype=np.float64).reshape(self.n_sys, self.nc, self.nd)[:, o])
         self._chk(self.lib.knp_set_mms(self.ctx, _p(C_, _f64p), _p(ee, _f64p), _p(ek, _f64p)), "knp_set_mms")
 
+    def set_source(self, src):
+        """Load vector of non-constant ion sources, [n_sys, nc, nd] in caller cell order (None clears)."""
+        if src is not None:
+            src = np.ascontiguousarray(np.asarray(src, dtype=np.float64).reshape(self.n_sys, self.nc, self.nd)[:, self.cell_order])
+        self._chk(self.lib.knp_set_source(self.ctx, _p(src, _f64p)), "knp_set_source")
+
     def size(self, field):
         return int(self.lib.knp_field_size(self.ctx, field))
 
@@ -374,6 +386,18 @@ class Device:
         nb = self._nodal_blocks(field, offset, n)
         if nb is not None:
             out = np.ascontiguousarray(out.reshape(nb, self.nc, self.nd)[:, self.cell_rank]).ravel()
+        return out
+
+    _DT_DTYPE = {0: np.int32, 1: np.int32, 2: np.uint32, 3: np.int32, 4: np.int32, 5: np.int32, 6: np.uint16, 7: np.int64}
+
+    def debug_table(self, which):
+        """Connectivity table `which` (include/knpemi_hip.h: knp_debug_table_id) as the library derived it, flat, in DEVICE cell
+        order (device cell d = caller cell `cell_order[d]`)."""
+        n = int(self.lib.knp_debug_table_size(self.ctx, which))
+        if n < 0:
+            raise KnpError("unknown debug table %d" % which)
+        out = np.zeros(n // np.dtype(self._DT_DTYPE[which]).itemsize, dtype=self._DT_DTYPE[which])
+        self._chk(self.lib.knp_debug_table(self.ctx, which, out.ctypes.data_as(C.c_void_p), n), "knp_debug_table")
         return out
 
     def copy_field(self, dst, src):

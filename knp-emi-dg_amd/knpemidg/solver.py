@@ -229,11 +229,26 @@ class Solver:
     def _push_params(self, splitting):
         z = [float(ion['z']) for ion in self.ion_list]
         D = np.stack([ion['D'] for ion in self.ion_list])
+        # ion['f_source'] v dx(0) (solver.py:599): a number / Constant or a per-cell array travels as a DG0 coefficient on the ECS
+        # cells; a callable f(x) or f(x, t) (the reference accepts any UFL coefficient, e.g. the box-and-time-window Expression
+        # of run_tortuosity.py:180-200) is integrated on the host before every KNP solve (_update_sources)
         fsrc = None
-        fs = [float(ion.get('f_source', 0.0)) for ion in self.ion_list[:-1]]
-        if any(v != 0.0 for v in fs):
-            ecs = (self.subdomains.array() == 0).astype(np.float64)
-            fsrc = np.stack([v * ecs for v in fs])
+        nc = self.mesh.num_cells()
+        ecs = (self.subdomains.array() == 0).astype(np.float64)
+        rows, self._callable_sources = [], {}
+        for k, ion in enumerate(self.ion_list[:-1]):
+            f = ion.get('f_source', 0.0)
+            if callable(f) and not hasattr(f, '__float__'):
+                self._callable_sources[k] = f
+                rows.append(np.zeros(nc))
+            elif isinstance(f, np.ndarray) and f.ndim >= 1 and f.size > 1:
+                if f.shape != (nc,):
+                    raise ValueError("f_source array of ion %s must hold one value per cell" % ion.get('name', k))
+                rows.append(f.astype(np.float64) * ecs)
+            else:
+                rows.append(float(f) * ecs)
+        if any(r.any() for r in rows):
+            fsrc = np.stack(rows)
         self.dev.set_params(_f(self.C_M), _f(self.dt), _f(self.F), _f(self.R), _f(self.temperature), _f(self.C_phi),
                             _f(self.tau_emi), _f(self.tau_knp), z, D, rho=self.rho, fsrc=fsrc, splitting=splitting)
 
@@ -254,6 +269,23 @@ class Solver:
 
     def setup_varform_knp(self):
         return
+
+    def _update_sources(self, t):
+        """Load vector of the callable ion sources at time t: int f_k(x, t) v dx(0) by a degree-8 rule per ECS cell (the reference
+        interpolates its Expression to the declared degree and integrates that: run_tortuosity.py:180-200, solver.py:599)."""
+        srcs = getattr(self, "_callable_sources", None)
+        if not srcs or self.mms is not None:
+            return
+        import inspect
+        from knpemidg.mms_terms import _cell_source, _geometry
+        if not hasattr(self, "_src_geom"):
+            self._src_geom = (_geometry(self.mesh)[0], np.nonzero(self.subdomains.array() == 0)[0])
+        vol, sel = self._src_geom
+        out = np.zeros((self.N_ions, self.mesh.num_cells(), self.nd))
+        for k, f in srcs.items():
+            two = len(inspect.signature(f).parameters) >= 2
+            _cell_source(self.mesh, vol, sel, (lambda X, f=f: f(X, float(t))) if two else f, out[k], p=self.degree_knp)
+        self.dev.set_source(out)
 
     def setup_solver_emi(self):
         self._read_solver_params()
@@ -346,7 +378,9 @@ class Solver:
         EVERY solve (solver.py:479, 505); here the hierarchy is built from kappa at setup time and rebuilt when it has gone
         stale: (a) kappa has moved by more than KNP_AMG_REFRESH_KAPPA (default 25 %) anywhere since the last build (checked
         every KNP_AMG_REFRESH_EVERY = 50 solves), or (b) the PCG iteration count has stayed above 3x its post-build level for 10 consecutive solves.
-        (The KNP hierarchies depend on the mesh, D_k and dt only -- nothing to refresh.)"""
+        (The KNP hierarchies depend on the mesh, D_k and dt only -- nothing to refresh.)  A partitioned run keeps the hierarchy
+        of the initial state (every rank would have to gather kappa to rebuild the replicated levels): the Krylov solves still
+        converge to their tolerance, only the iteration count can grow."""
         if not (self.use_amg and not self.direct_emi) or getattr(self, "local_mesh", None) is not None:
             return
         st = self.__dict__.setdefault("_amg_refresh", {"solves": 0, "ref": None, "high": 0})
@@ -360,7 +394,9 @@ class Solver:
         if st["solves"] % int(os.environ.get("KNP_AMG_REFRESH_EVERY", 50)) == 0:
             kap, k0 = self.dev.download(_abi.F_KAPPA), self._amg_kappa0
             lim = float(os.environ.get("KNP_AMG_REFRESH_KAPPA", 0.25))
-            stale = stale or bool(np.max(np.abs(kap - k0) / np.abs(k0)) > lim)
+            floor = 1e-12 * max(float(np.abs(k0).max()), 1e-300)                # a zero entry of kappa must not force a rebuild
+            drift = np.abs(kap - k0) / np.maximum(np.abs(k0), floor)
+            stale = stale or bool(np.nanmax(drift) > lim) or not bool(np.isfinite(kap).all())
         if stale:
             if self.verbose:
                 print(" AMG(EMI): hierarchy refreshed (kappa drift / iteration count)")
@@ -538,6 +574,7 @@ class Solver:
     def solve_knp(self):
         dev = self.dev
         ts = time.perf_counter()
+        self._update_sources(getattr(self, "_t_now", 0.0))
         dev.update_dnphi()
         dev.knp_rhs()
         dev.sync()
@@ -573,6 +610,7 @@ class Solver:
         if self.mms is not None and getattr(self.mms, "time_dependent", False):
             from knpemidg.mms_terms import extra_rhs       # data terms at the current t (solver.py:845 advances t last)
             self.dev.set_mms(*extra_rhs(self))
+        self._t_now = float(t)              # time-dependent sources see the t of this step (solver.py:845 advances t last)
         self.solve_emi()                    # step I
         self.solve_knp()                    # step II
         self.dev.step_updates()             # step III: c_prev <- c, phi_M, E_k, c_elim
@@ -586,6 +624,7 @@ class Solver:
         if self.verbose:
             print(f"{bcolors.WARNING} t = {float(t)}  k = {k} (Picard) {bcolors.ENDC}")
         t.assign(float(t + self.dt))
+        self._t_now = float(t)
         tol, eps, max_iter, it = 1.0e-4, 2.0, 25, 0
         A = _abi
         while eps > tol:
@@ -622,7 +661,7 @@ class Solver:
             print("Please specify filename when initiating Solver.solve_system_*() method")
             sys.exit(0)
         if self.save_fields:
-            self.init_h5_savefile(filename + 'results')
+            self.init_h5_savefile(filename + 'results.h5')                          # solver.py:978, 1063
         if self.save_solver_stats:
             self.init_solver_stats(filename + 'solver/')
 
@@ -739,7 +778,8 @@ class Solver:
         os.makedirs(os.path.dirname(filename) or ".", exist_ok=True)
         loc = getattr(self, "local_mesh", None)
         rank_sfx = "" if loc is None else "_rank%d" % getattr(self.dev, "rank", loc.rank)
-        self.h5_path = filename + rank_sfx + ".h5"
+        stem, ext = os.path.splitext(filename)                      # the reference passes the full file name (solver.py:978, 1214)
+        self.h5_path = stem + rank_sfx + (ext or ".h5")
         w = self.h5_file = H5Writer(self.h5_path)
         w.write("/mesh/coordinates", self.mesh.coords)
         w.write("/mesh/topology", self.mesh.cells.astype(np.int64))

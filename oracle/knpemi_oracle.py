@@ -531,9 +531,18 @@ def knp_rhs(pb, idx):
     wq = w[None, :] * geom.vol[:, None]
     cq = np.einsum("qj,cj->cq", B, pb.c_prev_n[idx])
     b += np.einsum("cq,cq,qv->cv", wq, cq, B) / pb.dt
-    fs = pb.f_source[idx]
-    if fs != 0.0:
-        ecs = (pb.cell_tags == 0)
+    fs = pb.f_source[idx]                                         # ion['f_source'] * v_c * dx(0), solver.py:599
+    ecs = (pb.cell_tags == 0)
+    if callable(fs):
+        # any UFL coefficient in the reference (e.g. the Expression(degree=4) of run_tortuosity.py:180-200): evaluated at the
+        # points of a degree-8 rule (t = pb.t for time-dependent sources)
+        bary8, w8, B8, _ = S.cell_tab(8)
+        X = np.einsum("ql,cld->cqd", bary8, mesh.coords[mesh.cells[ecs]])
+        fq = np.broadcast_to(np.asarray(fs(X, getattr(pb, "t", 0.0)), dtype=float), X.shape[:-1])
+        b[ecs] += np.einsum("q,c,cq,qv->cv", w8, geom.vol[ecs], fq, B8)
+    elif isinstance(fs, np.ndarray):
+        b[ecs] += fs[ecs, None] * np.einsum("cq,qv->cv", wq[ecs], B)
+    elif fs != 0.0:
         b[ecs] += fs * np.einsum("cq,qv->cv", wq[ecs], B)
 
     if len(pb.mem) and pb.mms is None:
@@ -739,4 +748,40 @@ def build_idealized(mesh, subdomains, surfaces, p=1, membrane_tags=(1, 2)):
     pb.c_prev_n = pb.c.copy()
     pb.c_elim = np.where(ics, init["Na"][0], init["Na"][1]) * ones
     pb.phi_M[pb.mem] = P["phi_M_init"]
+    return pb
+
+
+def emix_params():
+    """Physical parameters and initial values of examples/emix-simulations/run_EMIx_simulation.py:56-91 (cm / ms / mV / mM:
+    temperature in mK, F in mC/mol, R in mJ/(K mol), D in cm^2/ms).  init = (ECS, glial, neuronal) by subdomain 0 / 1 / 2."""
+    dt = 0.1
+    C_M = 2.0
+    return dict(dt=dt, C_M=C_M, temperature=300e3, F=96485e3, R=8.314e3, C_phi=C_M / dt,
+                D=dict(Na=1.33e-8, K=1.96e-8, Cl=2.03e-8),
+                z=dict(Na=1.0, K=1.0, Cl=-1.0),
+                init=dict(K=(3.3236967382613933, 102.75563828644862, 124.15397583492471),
+                          Na=(100.71925900028181, 12.39731187972181, 12.838513108606818)),
+                # initial membrane potentials = the ODE models' initial V per membrane tag (mm_glial.py:11, mm_hh.py:14)
+                phi_M_init={1: -83.08511451850003, 2: -74.3848784437955})
+
+
+def build_emix(mesh, subdomains, surfaces, p=1, membrane_tags=(1, 2)):
+    """Problem of run_EMIx_simulation.py:56-170: ion_list = [K, Cl, Na] (Na eliminated, :147), concentrations constant per
+    subdomain (0 ECS, 1 glial, 2 neuronal; :118-124), Cl = Na + K in every subdomain (:86-89), phi_M = the membrane models'
+    initial potentials on their facets (glial tag 1, neuronal tag 2; :249)."""
+    P = emix_params()
+    tags = np.asarray(subdomains).astype(np.int64)
+    nc = mesh.num_cells()
+    init = dict(P["init"])
+    init["Cl"] = tuple(a + b for a, b in zip(init["Na"], init["K"]))
+    ions = [dict(name=n, z=P["z"][n], D=np.full(nc, P["D"][n])) for n in ("K", "Cl", "Na")]
+    pb = Problem(mesh, tags, np.asarray(surfaces), p, ions, P, membrane_tags=membrane_tags)
+    ones = np.ones((nc, pb.nd))
+    for i, n in enumerate(("K", "Cl")):
+        pb.c[i] = np.asarray(init[n])[tags][:, None] * ones
+    pb.c_prev_n = pb.c.copy()
+    pb.c_elim = np.asarray(init["Na"])[tags][:, None] * ones
+    for tag, v in P["phi_M_init"].items():
+        if tag in membrane_tags:
+            pb.phi_M[pb.mem[pb.facet_tags[pb.mem] == tag]] = v
     return pb

@@ -4,23 +4,24 @@ import numpy as np
 import knpemi_oracle as ko
 
 
-def synthetic_state(pb, seed=0):
+def synthetic_state(pb, seed=0, volt=1.0):
     """x ~ U(-1,1) seed 0; c_k = tag-wise ICs * (1 + 0.01 U(-1,1)) seed 1; phi ~ 0.07 U(-1,1) seed 2
-    (BASELINE.md section 4, config 2).  Also perturbs phi_M and channel currents."""
+    (BASELINE.md section 4, config 2).  Also perturbs phi_M and channel currents.
+    volt = 1e3 for configurations in mV (EMIx)."""
     nc, nd = pb.mesh.num_cells(), pb.nd
     x = np.random.default_rng(seed).uniform(-1, 1, size=(pb.N_ions, nc, nd))
     r1 = np.random.default_rng(seed + 1)
     pb.c = pb.c * (1 + 0.01 * r1.uniform(-1, 1, size=pb.c.shape))
     pb.c_elim = pb.c_elim * (1 + 0.01 * r1.uniform(-1, 1, size=pb.c_elim.shape))
     pb.c_prev_n = pb.c * (1 + 0.001 * r1.uniform(-1, 1, size=pb.c.shape))
-    pb.phi = 0.07 * np.random.default_rng(seed + 2).uniform(-1, 1, size=(nc, nd))
+    pb.phi = 0.07 * volt * np.random.default_rng(seed + 2).uniform(-1, 1, size=(nc, nd))
     r3 = np.random.default_rng(seed + 3)
     nf = pb.mesh.num_facets()
     pb.phi_M = np.zeros(nf)
-    pb.phi_M[pb.mem] = -0.07 + 0.01 * r3.uniform(-1, 1, size=len(pb.mem))
+    pb.phi_M[pb.mem] = volt * (-0.07 + 0.01 * r3.uniform(-1, 1, size=len(pb.mem)))
     for name in pb.I_ch:
         pb.I_ch[name] = np.zeros(nf)
-        pb.I_ch[name][pb.mem] = 1e-3 * r3.uniform(-1, 1, size=len(pb.mem))
+        pb.I_ch[name][pb.mem] = 1e-3 * volt * r3.uniform(-1, 1, size=len(pb.mem))
     return x
 
 

@@ -25,6 +25,13 @@ import knpemi_oracle as ko                                    # noqa: E402
 import membrane_oracle as mo                                  # noqa: E402
 from knpemidg.mesh import make_mesh_3D, make_mesh_2D           # noqa: E402
 
+
+
+def _emix_sub():
+    from emix_sub import emix_submesh
+    return emix_submesh()
+
+
 STIMULUS = {"stim_amplitude": 10.0}                            # g_syn_bar, run_3D.py:148-153
 LOCATOR = lambda x: x[0] < 20.0e-6                             # noqa: E731   run_3D.py:153
 N_SAMPLE = 2048
@@ -34,10 +41,14 @@ def mean_free(phi, vol):
     return phi - (phi.mean(axis=1) * vol).sum() / vol.sum()
 
 
-def trajectory(name, mesh_tuple, p, tags_models, n_steps):
+def trajectory(name, mesh_tuple, p, tags_models, n_steps, build=None, stimulus=None, locator=None):
+    """tags_models: (membrane tag, True / False = idealized HH with / without stimulus, or a name of membrane_oracle.MODELS)."""
     m, s, f = mesh_tuple
-    pb = ko.build_idealized(m, s.array(), f.array(), p=p, membrane_tags=tuple(t for t, _ in tags_models))
-    models = [mo.MembraneOracle(pb, tag, stim, pb.C_M) for tag, stim in tags_models]
+    build = build or ko.build_idealized
+    STIMULUS, LOCATOR = stimulus or globals()["STIMULUS"], locator or globals()["LOCATOR"]
+    pb = build(m, s.array(), f.array(), p=p, membrane_tags=tuple(t for t, _ in tags_models))
+    models = [mo.MembraneOracle(pb, tag, stim is True, pb.C_M, model=None if isinstance(stim, bool) else stim)
+              for tag, stim in tags_models]
     E = {ion["name"]: ko.nernst(pb, k) for k, ion in enumerate(pb.ions)}          # solver.py:299-300
     rng = np.random.default_rng(2024)
     sample = np.sort(rng.choice(pb.ndof, size=min(N_SAMPLE, pb.ndof), replace=False))
@@ -75,6 +86,10 @@ CASES = {
     "traj_3D_r0_4axon_P2": lambda: trajectory("traj_3D_r0_4axon_P2", make_mesh_3D(0, n_axons=4), 2, ((1, True), (2, False)), 3),
     # BASELINE configs[0]: 2D neuron r=2, 40 steps
     "traj_2D_r2_P1": lambda: trajectory("traj_2D_r2_P1", make_mesh_2D(2), 1, ((1, True),), 40),
+    # BASELINE configs[4] physics on a 17 920-tet piece of its real mesh (tests/emix_sub.py): glial (Kir 4.1) + neuronal (HH, cm / ms / mV)
+    # membranes, three subdomains, stimulus g_syn = 5 mS/cm^2 on x < 3e-4 cm (run_EMIx_simulation.py:56-170), 25 steps of 0.1 ms
+    "traj_emix_sub_P1": lambda: trajectory("traj_emix_sub_P1", _emix_sub(), 1, ((1, "glial"), (2, "hh_emix")), 25, build=ko.build_emix,
+                                           stimulus={"stim_amplitude": 5.0}, locator=lambda x: x[0] < 3.0e-4),
 }
 
 if __name__ == "__main__":

@@ -268,6 +268,62 @@ def test_device_ode_matches_lsoda_oracle(hip_lib):
     dev.close()
 
 
+@pytest.mark.parametrize("which", ["hh_emix", "glial", "leak"])
+def test_device_ode_other_models_match_lsoda_oracle(hip_lib, which):
+    """k_ode_step models 3 / 4 / 5 -- the EMIx neuron and glial membranes of BASELINE configs[4] (reference:
+    examples/emix-simulations/mm_hh.py:118-161, mm_glial.py:117-170; cm / ms / mV) and the passive leak membrane of the
+    rat-neuron example (examples/rat-neuron/mm_leak.py:107-133; SI) -- against the ORACLE's independent restatement of the
+    same reference text stepped by scipy LSODA per facet at rtol 1e-8 / atol 0 (oracle/membrane_oracle.py; reference
+    membrane.py:108-112): rows with varying K_e, Na_i, E_K, E_Na, a stimulus on part of them, 25 steps.
+    Tolerance as for the HH test: both integrate to rtol 1e-8 per step -> 1e-6 (states), 1e-5 (currents) after 25 steps."""
+    import membrane_oracle as mo
+    from knpemidg.mesh import make_mesh_2D
+    from knpemidg.functions import FacetSpace, FacetFunction
+    from knpemidg.membrane import MembraneModel
+    from knpemidg.models import mm_hh_emix, mm_glial, mm_leak
+    ode = {"hh_emix": mm_hh_emix, "glial": mm_glial, "leak": mm_leak}[which]
+    si = which == "leak"
+    m, s, f = make_mesh_2D(1)
+    pb = ko.build_idealized(m, s.array(), f.array(), membrane_tags=(1,))
+    dev = device_for(pb)
+    Q = FacetSpace(m)
+    rng = np.random.default_rng(23)
+    u = lambda: rng.uniform(-1, 1, Q.dim())
+    mV = 1e-3 if si else 1.0
+    fields = {'K_e': 3.32 * (1 + 0.2 * u()), 'Na_i': 12.8 * (1 + 0.1 * u()),
+              'E_K': (-93.6 + 3.0 * u()) * mV, 'E_Na': (53.3 + 2.0 * u()) * mV}
+    Cm, dt, amp = (0.02, 1e-4, 40.0) if si else (2.0, 0.1, 5.0)               # run_rat_neuron / run_EMIx_simulation settings
+    locator = lambda x: x[0] < 20e-6
+    init_s, init_p, _, pidx, iV = mo.MODELS[which]
+    assert ode.parameter_indices('I_ch_Na') == pidx['I_ch_Na'] and ode.state_indices('V') == iV
+    assert np.array_equal(ode.init_state_values(), init_s()) and np.array_equal(ode.init_parameter_values(), init_p())
+    mm = MembraneModel(ode, facet_f=f, tag=1, V=Q)
+    mm.set_parameter_values({'Cm': lambda x: Cm})
+    assert mm.attach_device(dev) and mm.on_device
+    for name, val in fields.items():
+        mm.set_parameter(name, FacetFunction(Q, val))
+    n = mm.nodes
+    st = np.tile(init_s(), (n, 1))
+    pr = np.tile(init_p(), (n, 1))
+    pr[:, pidx['Cm']] = Cm
+    for name, val in fields.items():
+        pr[:, pidx[name]] = val[mm.indices]
+    mask = np.fromiter(map(locator, mm.dof_locations), dtype=bool, count=n)
+    assert 0 < mask.sum() < n
+    v0 = st[:, iV].copy()
+    for k in range(25):
+        mm.step_lsoda(dt=dt, stimulus={'stim_amplitude': amp}, stimulus_locator=locator)
+        mo.step_lsoda_model(which, st, pr, k * dt, dt, stimulus={'stim_amplitude': amp}, stimulus_mask=mask)
+    sd, pd = mm.states, mm.parameters
+    assert np.abs(sd - st).max() < 1e-6 * np.abs(st).max(), np.abs(sd - st).max()
+    cur = [pidx['I_ch_Na'], pidx['I_ch_K']]
+    assert np.abs(pd[:, cur] - pr[:, cur]).max() < 1e-5 * np.abs(pr[:, cur]).max()
+    assert np.abs(st[:, iV] - v0).max() > 1e-3 * np.abs(v0).max()             # the rows moved: the comparison is not of a rest state
+    if which != "glial":                                                     # the glial model has no stimulus term
+        assert np.abs(st[mask, iV] - v0[mask]).max() > 2 * np.abs(st[~mask, iV] - v0[~mask]).max()
+    dev.close()
+
+
 def test_stimulus_is_reimposed_every_step(hip_lib):
     """The reference overwrites the stimulus parameters on the masked rows at the start of every step_lsoda call
     (membrane.py:98-104): a hook that rewrites the whole parameter table between steps must not lose the stimulus."""

@@ -315,6 +315,58 @@ def test_partitioned_kernels_on_one_gpu(hip_lib, monkeypatch, world, p):
         dev.close()
 
 
+def test_emix_mesh_vs_oracle(hip_lib):
+    """BASELINE configs[4] on its REAL mesh against the oracle: the reference's bundled tissue reconstruction (121 617 unstructured
+    tets, three subdomain classes, slivers, glial + neuronal membrane tags, membranes between equal-tag cells; parameters of
+    examples/emix-simulations/run_EMIx_simulation.py:56-170 in cm / ms / mV) -- both operator applies against the oracle's assembled
+    CSR matrices, both right-hand sides in both splitting modes, the step-III projections and the update_ode traces, on seeded
+    inputs.  Runs the coordinate-path kernels (no geometry classes on this mesh)."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "emix_simulations"))
+    from emix_common import load_mesh
+    from knpemidg import _abi as A
+    m, s, f = load_mesh()
+    pb = ko.build_emix(m, s.array(), f.array())
+    assert m.num_cells() == 121617 and len(np.unique(pb.cell_tags)) == 3 and set(np.unique(pb.facet_tags[pb.mem])) == {1, 2}
+    x = synthetic_state(pb, volt=1.0e3)
+    dev = device_for(pb)
+    try:
+        assert dev.n_geometry_classes == 0
+        push_state(dev, pb)
+        dev.update_kappa(); dev.update_dnphi()
+        assert relerr(dev.download(A.F_KAPPA), pb.kappa()) < 1e-14
+        Aemi, _, _ = ko.assemble_emi(pb, want_B=False)
+        dev.upload(A.F_X, x[0]); dev.emi_apply(A.F_X, A.F_Y)
+        assert relerr(dev.download(A.F_Y, 0, pb.ndof), Aemi @ x[0].ravel()) < TOL
+        del Aemi
+        dev.upload(A.F_X, x); dev.knp_apply(A.F_X, A.F_Y)
+        y = dev.download(A.F_Y).reshape(pb.N_ions, -1)
+        for k in range(pb.N_ions):
+            assert relerr(y[k], ko.assemble_knp(pb, k) @ x[k].ravel()) < TOL
+        z = [ion["z"] for ion in pb.ions]
+        D = np.stack([ion["D"] for ion in pb.ions])
+        for splitting in (False, True):
+            pb.splitting = splitting
+            dev.set_params(pb.C_M, pb.dt, pb.F, pb.R, pb.T, pb.C_phi, pb.tau, pb.tau, z, D, rho=pb.rho, splitting=splitting)
+            dev.emi_rhs(); dev.knp_rhs()
+            assert relerr(dev.download(A.F_B_EMI), ko.emi_rhs(pb)) < TOL
+            b = dev.download(A.F_B_KNP).reshape(pb.N_ions, -1)
+            for k in range(pb.N_ions):
+                assert relerr(b[k], ko.knp_rhs(pb, k)) < TOL
+        K_e = dev.facet_trace(A.F_C, 0, 0)
+        assert relerr(K_e[pb.mem], ko.facet_average(pb, pb.mem, lambda plus, minus: plus(pb.c[0]), pb.p)) < 1e-14
+        Na_i = dev.facet_trace(A.F_C_ELIM, 0, 1)
+        assert relerr(Na_i[pb.mem], ko.facet_average(pb, pb.mem, lambda plus, minus: minus(pb.c_elim), pb.p)) < 1e-14
+        dev.step_updates()
+        assert relerr(dev.download(A.F_PHI_M)[pb.mem], ko.update_phi_M(pb).copy()) < 1e-13
+        assert relerr(dev.download(A.F_C_ELIM), ko.update_c_elim(pb)) < 1e-14
+        E = dev.download(A.F_E).reshape(len(pb.ions), -1)
+        for k in range(len(pb.ions)):
+            assert relerr(E[k][pb.mem], ko.nernst(pb, k)) < 1e-12
+    finally:
+        dev.close()
+
+
 def test_partitioned_emix_mesh_on_one_gpu(hip_lib, monkeypatch):
     """BASELINE configs[4] mesh (121 617 unstructured tets) cut into 4 parts by recursive coordinate bisection: a rank's owned +
     ghost context (ghost values as the halo exchange delivers them) reproduces the owned rows of the single-context applies,

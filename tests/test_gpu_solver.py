@@ -607,3 +607,46 @@ def test_result_file_has_the_reference_datasets(hip_lib, tmp_path):
     assert np.array_equal(f.read("surfaces/values"), S.surfaces.array())
     assert os.path.exists(prefix + "solver/emi_niter_0.txt")
     S.dev.close()
+
+
+@pytest.mark.parametrize("dim,degree", [(2, 1), (3, 1), (2, 2)])
+def test_f_source_array_and_callable_vs_oracle(hip_lib, dim, degree):
+    """ion['f_source'] is any UFL coefficient in the reference (`L += ion['f_source'] * v_c * dx(0)`, solver.py:599): a Constant in
+    the idealized examples, a box-and-time-window Expression in examples/local-astrocyte-depolarization/run_tortuosity.py:180-200.
+    Here: a per-cell array for one species and a callable f(x, t) with exactly that shape for the other; L_knp on the device
+    against the oracle's, inside and outside the time window, and the source's own contribution (difference to the source-free
+    right-hand side) at the apply tolerance."""
+    from idealized_common import make_solver, solver_parameters
+    from knpemidg import _abi as A
+    mt = None if dim == 2 else small_3d()
+    S = make_solver(dim=dim, resolution=0, n_axons=1, degree=degree, mesh_tuple=mt)
+    mesh = S.mesh
+    lo, hi = mesh.coords.min(axis=0), mesh.coords.max(axis=0)
+    a, b = lo + 0.2 * (hi - lo), lo + 0.7 * (hi - lo)
+    g_syn, t0, t1 = 40.0, 2.0e-4, 6.0e-4
+
+    def box(X, t):
+        inside = np.all((X >= a) & (X <= b), axis=-1)
+        return g_syn * inside * (t0 <= t) * (t <= t1) * (1.0 + 0.3 * np.sin(4.0e5 * X[..., 0]))
+    rng = np.random.default_rng(8)
+    per_cell = rng.uniform(-5.0, 5.0, mesh.num_cells())
+    pb = ko.build_idealized(mesh, S.subdomains.array(), S.surfaces.array(), p=degree, membrane_tags=(1,))
+    base = [ko.knp_rhs(pb, k) for k in range(2)]
+    S.ion_list[0]['f_source'] = box
+    S.ion_list[1]['f_source'] = per_cell
+    pb.f_source = [box, per_cell]
+    S._unpack_solver_params(solver_parameters(dim, 0))
+    S.splitting_scheme = True
+    S.setup_varform_emi()
+    for t, active in ((0.0, False), (3.0e-4, True)):
+        S._update_sources(t)
+        pb.t = t
+        S.dev.knp_rhs()
+        got = S.dev.download(A.F_B_KNP).reshape(2, -1)
+        for k in range(2):
+            ref = ko.knp_rhs(pb, k).ravel()
+            assert relerr(got[k], ref) < 1e-11
+            d_ref = ref - base[k].ravel()
+            assert relerr(got[k] - base[k].ravel(), d_ref) < 1e-9
+            assert (np.abs(d_ref).max() > 0) == (active or k == 1)
+    S.dev.close()

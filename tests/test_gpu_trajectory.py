@@ -86,6 +86,57 @@ def test_pde_parity_along_oracle_trajectory(hip_lib, name, dim, degree):
     S.dev.close()
 
 
+def test_emix_pde_parity_along_oracle_trajectory(hip_lib):
+    """BASELINE configs[4] physics against the ORACLE's own run (tests/golden/traj_emix_sub_P1.npz: assembled forms + sparse direct
+    solves + scipy-LSODA on the oracle's restatements of mm_glial / the EMIx mm_hh, 25 steps of 0.1 ms with the synaptic stimulus
+    on x < 3e-4 cm) on a 17 920-tet piece of the real tissue mesh (tests/emix_sub.py): three subdomain classes, glial and neuronal
+    membranes, unstructured slivers, cm / ms / mV units.  Part 1 feeds the oracle's ODE outputs to the HIP PDE step (tight
+    tolerances: c <= 1e-8, phi <= 1e-6); part 2 runs the product alone -- device ODE integrator, shipped tolerances -- and holds it
+    to north_star's bounds (c <= 1e-6, phi, phi_M <= 1e-4) at every step."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "emix_simulations"))
+    from emix_common import make_solver, solver_parameters, Constant
+    from emix_sub import emix_submesh
+    from knpemidg import _abi as A
+    g = np.load(os.path.join(GOLD, "traj_emix_sub_P1.npz"))
+    mt = emix_submesh()
+    n_steps = int(g["n_steps"])
+    for tight in (True, False):
+        S = make_solver(mesh_tuple=mt)
+        sp = solver_parameters()
+        if tight:
+            sp = sp._replace(rtol_emi=1e-11, rtol_knp=1e-13)
+        S._unpack_solver_params(sp)
+        S.save_fields = S.save_solver_stats = False
+        S.splitting_scheme = True
+        S.setup_varform_emi(); S.setup_varform_knp(); S.setup_solver_emi(); S.setup_solver_knp()
+        assert S.dev.n_geometry_classes == 0 and S.mesh.num_cells() == 17920
+        vol = _cell_volumes(S.mesh)
+        nf = S.mesh.num_facets()
+        mem = g["mem"]
+        t = Constant(0.0)
+        worst = {}
+        for k in range(n_steps):
+            if tight:
+                pm = np.zeros(nf); pm[mem] = g["ode_phi_M"][k]
+                Ich = np.zeros((len(S.ion_list), nf)); Ich[:, mem] = g["ode_I_ch"][k]
+                S.dev.upload(A.F_PHI_M, pm)
+                S.dev.upload(A.F_I_CH, Ich)
+            else:
+                S.step_membrane_models(k)
+            S.solve_for_time_step(k, t)
+            e = _errors(S, g, k, vol)
+            for key, v in e.items():
+                worst[key] = max(worst.get(key, 0.0), v)
+            if tight:
+                assert e["phi"] < 1e-6 and e["c"] < 1e-8 and e["c_elim"] < 1e-8 and e["phi_M"] < 1e-6 and e["E"] < 1e-7, (k, e)
+            else:
+                assert e["c"] < 1e-6 and e["c_elim"] < 1e-6 and e["phi"] < 1e-4 and e["phi_M"] < 1e-4, (k, e, S.emi_niter[-3:], S.knp_niter[-3:])
+        print("emix sub-mesh", "tight" if tight else "production", "worst:", worst)
+        S.dev.close()
+    # the stimulated neuronal membrane really moves (rest -74.4 mV), the glial one stays near -83 mV
+    assert g["phi_M"].max() > -70.0 and g["phi_M"].min() < -80.0
+
+
 @pytest.mark.parametrize("name,dim", [("traj_2D_r2_P1", 2), ("traj_3D_r0_4axon_P1", 3)])
 def test_production_tolerances_through_action_potential(hip_lib, name, dim):
     """The shipped configuration (rtol_emi 1e-5 on the preconditioned norm, rtol_knp 1e-7, lagged AMG hierarchy, device

@@ -141,3 +141,23 @@ def test_iterative_matches_direct(pb2d):
     ko.solve_knp(a, direct=True)
     ko.solve_knp(b, direct=False, rtol=1e-12)
     assert relerr(a.c, b.c) < 1e-8
+
+
+@pytest.mark.parametrize("which", ["2D", "3D"])
+def test_oracle_connectivity_agrees_with_the_mesh_tables(which):
+    """oracle/connectivity.py (dictionary matching, no facet tables) against the facet tables the oracle's forms run on
+    (Mesh.facet_cells / facet_local, facet_orientation): two derivations of the same integer tables, equal entry for entry."""
+    import connectivity as oc
+    from knpemidg.mesh import make_mesh_2D, make_mesh_3D
+    mesh, sub, surf = make_mesh_2D(0) if which == "2D" else make_mesh_3D(0, n_axons=4)
+    mtags = (1,) if which == "2D" else (1, 2, 3, 4)
+    T = oc.derive_tables(mesh.cells, sub.array(), mesh.facets, surf.array(), mtags)
+    fc, fl = mesh.facet_cells.astype(np.int64), mesh.facet_local.astype(np.int64)
+    e_side = ko.facet_orientation(mesh, sub.array())
+    for f in np.nonzero(fc[:, 1] >= 0)[0]:
+        (c0, c1), (l0, l1) = fc[f], fl[f]
+        assert T["nbr"][c0, l0] == c1 and T["nbr"][c1, l1] == c0 and T["nloc"][c0, l0] == l1 and T["nloc"][c1, l1] == l0
+        assert T["fid"][c0, l0] == f and T["fid"][c1, l1] == f
+        assert T["plus"][c0, l0] == (e_side[f] == 0) and T["plus"][c1, l1] == (e_side[f] == 1)
+    assert (T["nbr"] < 0).sum() == (fc[:, 1] < 0).sum()
+    assert len(T["mem"]) == np.isin(surf.array()[fc[:, 1] >= 0], mtags).sum() > 0
