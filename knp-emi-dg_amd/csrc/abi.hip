@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include "krylov.hpp"
 #include <cstring>
+#include <unordered_map>
 #include <algorithm>
 #include <cmath>
 
@@ -28,6 +29,11 @@ struct Fields {
     double bj_lmax_emi = 0.0;
     int bj_lmax_emi_age = 0;
     int nh_emi = 0, nh_knp = 0;            // valid history entries of the extrapolated initial guesses
+    // KNP block-Jacobi table (structured meshes): 0 = not built yet, 1 = ready, -1 = unavailable for this context
+    int bj_tab_state = 0;
+    uint16_t* bj_idx = nullptr;            // [nc_owned]
+    bjreal* bj_tab = nullptr;              // [entries][n_sys][nd*nd]
+    int bj_entries = 0;
 };
 
 // initial guess from the last solutions: nh = number of valid history entries (h1 = previous, h2 = the one before)
@@ -179,6 +185,7 @@ int knp_ctx_create(knp_ctx** out, int device, int dim, int degree, int n_ions, i
         for (int a = 0; a < NV; ++a)
             if (cfacet[k * NV + a] < 0) { g_err = "owned cell with a facet missing from the facet table"; delete c; return -1; }
 
+    c->h_fflag = fflag;
     MeshDev& m = c->m;
     m.dim = dim; m.nv = nv; m.nc = nc; m.nc_owned = nc_owned; m.nf = nf; m.nmf = (int64_t)mf.size() / 6;
     m.c_begin = 0; m.c_end = nc_owned; m.n_interior = nc_owned;
@@ -292,7 +299,7 @@ void knp_ctx_destroy(knp_ctx* c) {
     Fields* fl = g_fields[c];
     if (fl) {
         for (int i = 0; i < KNP_F_COUNT; ++i) hipFree(fl->f[i]);
-        hipFree(fl->binv_emi); hipFree(fl->binv_knp);
+        hipFree(fl->binv_emi); hipFree(fl->binv_knp); hipFree(fl->bj_idx); hipFree(fl->bj_tab);
         double* wk[] = {fl->r, fl->z, fl->p, fl->w, fl->rhat, fl->v, fl->y, fl->hist_emi, fl->hist_knp, fl->tmp_knp, fl->tmp_emi};
         for (auto p : wk) hipFree(p);
         delete fl;
@@ -328,6 +335,30 @@ int knp_set_params(knp_ctx* c, double C_M, double dt, double Fc, double R, doubl
     }
     if (!(dt > 0.0)) { c->err = "dt must be positive"; return -1; }
     HIPCHK(c, hipMemcpy(c->D, D, sizeof(double) * p.n_ions * c->m.nc, hipMemcpyHostToDevice));
+    if (g_fields.count(c)) F(c)->bj_tab_state = 0;                          // D / dt may have changed: rebuild the block-Jacobi table
+    {   // distinct D tuples over the cells (any dimension / degree): one of the keys of the KNP block-Jacobi table
+        const int64_t nc = c->m.nc;
+        const int ni = p.n_ions;
+        c->h_mat.assign((size_t)nc, 0);
+        std::vector<double> seen;                                           // [id][ni]
+        bool ok = true;
+        for (int64_t k = 0; k < nc && ok; ++k) {
+            const int nm = (int)(seen.size() / ni);
+            int id = -1;
+            for (int q = nm - 1; q >= 0 && id < 0; --q) {
+                bool same = true;
+                for (int i = 0; i < ni && same; ++i) same = seen[(size_t)q * ni + i] == D[(int64_t)i * nc + k];
+                if (same) id = q;
+            }
+            if (id < 0) {
+                if (nm >= 256) { ok = false; break; }
+                for (int i = 0; i < ni; ++i) seen.push_back(D[(int64_t)i * nc + k]);
+                id = nm;
+            }
+            c->h_mat[(size_t)k] = (uint16_t)id;
+        }
+        if (!ok) c->h_mat.clear();
+    }
     c->nmat = 0;
     if (c->m.dim == 3 && c->degree == 1 && c->m.hb_stride) {
         // material ids: distinct coefficient tuples (D_0 .. D_{n_ions-1}) over the cells, in order of first appearance
@@ -384,12 +415,16 @@ int knp_set_geometry_classes(knp_ctx* c, int ncls, const uint16_t* cls, const do
     if (!c) return -1;
     hipFree(c->m.cls); hipFree(c->m.cls_table);
     c->m.cls = nullptr; c->m.cls_table = nullptr; c->m.ncls = 0;
+    c->h_cls.clear();
+    if (g_fields.count(c)) F(c)->bj_tab_state = 0;
     if (ncls <= 0) return 0;
     if (ncls > 65535 || !cls || !table) { c->err = "geometry classes: bad arguments"; return -1; }
     for (int64_t k = 0; k < c->m.nc; ++k)
         if (cls[k] >= ncls) { c->err = "geometry class id out of range"; return -1; }
     HIPCHK(c, hipMalloc((void**)&c->m.cls, sizeof(uint16_t) * c->m.nc));
     HIPCHK(c, hipMemcpy(c->m.cls, cls, sizeof(uint16_t) * c->m.nc, hipMemcpyHostToDevice));
+    c->h_cls.assign(cls, cls + c->m.nc);
+    if (g_fields.count(c)) F(c)->bj_tab_state = 0;
     HIPCHK(c, hipMalloc((void**)&c->m.cls_table, sizeof(double) * (size_t)ncls * KNP_CLS_STRIDE));
     HIPCHK(c, hipMemcpy(c->m.cls_table, table, sizeof(double) * (size_t)ncls * KNP_CLS_STRIDE, hipMemcpyHostToDevice));
     c->m.ncls = ncls;
@@ -476,7 +511,7 @@ int knp_upload(knp_ctx* c, int field, const double* src, int64_t offset, int64_t
     HIPCHK(c, hipStreamSynchronize(c->stream));
     // a caller-supplied state may be far from the one the lagged block-Jacobi inverses were built for
     if (field == KNP_F_C || field == KNP_F_C_ELIM || field == KNP_F_PHI || field == KNP_F_KAPPA) reset_lagged(F(c));
-    if (field == KNP_F_PHI) F(c)->nh_emi = 0;          // a caller-supplied state is not a point of the solution history
+    if (field == KNP_F_PHI) { F(c)->nh_emi = 0; c->last_peclet = -1.0f; }   // a caller-supplied state is not a point of the solution history
     if (field == KNP_F_C) F(c)->nh_knp = 0;
     return 0;
 }
@@ -502,9 +537,33 @@ int knp_update_kappa(knp_ctx* c) {
     return launch_kappa(c, f->f[KNP_F_C], f->f[KNP_F_C_ELIM], f->f[KNP_F_KAPPA]);
 }
 
+// cell Peclet number of the drift term, max over the owned cells of  psi max|z| (max - min nodal phi): decides whether the
+// drift-free block-Jacobi table is a good preconditioner (build_bj_table).  Written as float bits into a status word that travels
+// with the solvers' status polls -- no synchronisation of its own.
+__global__ void k_cell_peclet(int64_t nc_owned, int nd, const double* __restrict__ phi, double scale, int* __restrict__ out) {
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    float pe = 0.0f;
+    if (c < nc_owned) {
+        double lo = phi[c * nd], hi = lo;
+        for (int a = 1; a < nd; ++a) { const double v = phi[c * nd + a]; lo = fmin(lo, v); hi = fmax(hi, v); }
+        pe = (float)(scale * (hi - lo));
+        if (!(pe >= 0.0f)) pe = 3.0e38f;                                     // NaN / inf potentials: never trust the table
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) pe = fmaxf(pe, __shfl_down(pe, off, 64));
+    if ((threadIdx.x & 63) == 0 && pe > 0.0f) atomicMax(out, __float_as_int(pe));    // non-negative floats order like their bit patterns
+}
+
 int knp_update_dnphi(knp_ctx* c) {
     if (!c) return -1;
     Fields* f = F(c);
+    double zmax = 0.0;
+    for (int i = 0; i < c->p.n_sys; ++i) zmax = std::max(zmax, std::fabs(c->p.z[i]));
+    HIPCHK(c, hipMemsetAsync(c->status + KNP_PECLET_SLOT, 0, sizeof(int), c->stream));
+    if (c->m.nc_owned)
+        hipLaunchKernelGGL(k_cell_peclet, dim3((unsigned)((c->m.nc_owned + 255) / 256)), dim3(256), 0, c->stream, c->m.nc_owned, c->nd,
+                           (const double*)f->f[KNP_F_PHI], c->p.psi * zmax, c->status + KNP_PECLET_SLOT);
+    HIPCHK(c, hipGetLastError());
     return launch_dnphi(c, f->f[KNP_F_PHI], f->f[KNP_F_DNPHI]);
 }
 
@@ -581,17 +640,100 @@ int knp_emi_solve(knp_ctx* c, double rtol, double atol, int maxit, int check_eve
     return 0;
 }
 
+// KNP block-Jacobi TABLE.  On a (block-)structured mesh the cell-diagonal block of A_knp without its drift part -- M / dt + the SIPG
+// volume, consistency and penalty terms of the cell's own D -- is decided by the cell's geometry class (own shape, neighbour
+// apexes and diameters), its material (D tuple) and the kinds of its facets: a few hundred distinct blocks for 10^6 cells.  The
+// Krylov vector kernels then read a 2-byte index per cell and the block through the caches instead of 4 nd^2 bytes per cell and
+// species from HBM (64 B against 32 B per cell vector for P1, 400 B against 80 B for P2: 18 % / 50 % of the bytes the fused BiCGStab
+// kernels move).  Dropping the drift from the PRECONDITIONER's blocks changes no iteration count (tools/precond_experiment.py:
+// the drift is 1e-3 of the operator at +-70 mV random nodal potentials), and the blocks no longer depend on the state: built once
+// per coefficient set instead of every 8th solve.  KNP_BJ_TABLE=0 keeps the per-cell inverses.
+__global__ void k_bj_gather(int nent, const int32_t* __restrict__ rep, int nsys, int64_t nc, int nn, const bjreal* __restrict__ binv,
+                            bjreal* __restrict__ tab) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)nent * nsys * nn) return;
+    const int e = (int)(i % nn), s = (int)((i / nn) % nsys), k = (int)(i / ((int64_t)nn * nsys));
+    tab[i] = binv[((int64_t)s * nc + rep[k]) * nn + e];
+}
+
+static int build_bj_table(knp_ctx* c, Fields* f) {
+    f->bj_tab_state = -1;
+    static const bool enabled = !(getenv("KNP_BJ_TABLE") && atoi(getenv("KNP_BJ_TABLE")) == 0);
+    const int64_t nc = c->m.nc, n_own = c->m.nc_owned;
+    if (!enabled || c->h_cls.size() != (size_t)nc || c->h_mat.size() != (size_t)nc || c->h_fflag.size() != (size_t)nc || c->p.splitting == 2 ||
+        c->p.n_sys > 4 || n_own == 0 || (c->degree != 1 && p2_assembled()))
+        return 0;
+    // key: class (16 bits) | material (8) | kind of each facet (4 x 2 bits)
+    std::unordered_map<uint64_t, int> ids;
+    std::vector<int32_t> rep;
+    std::vector<uint16_t> idx((size_t)n_own);
+    const int NVf = c->m.dim + 1;
+    for (int64_t k = 0; k < n_own; ++k) {
+        uint64_t kinds = 0;
+        for (int a = 0; a < NVf; ++a) kinds |= (uint64_t)((c->h_fflag[k] >> (8 * a + 2)) & 3u) << (2 * a);
+        const uint64_t key = (uint64_t)c->h_cls[k] | ((uint64_t)c->h_mat[k] << 16) | (kinds << 32);
+        auto it = ids.find(key);
+        if (it == ids.end()) {
+            if (rep.size() >= 8192) return 0;                                 // not structured enough: keep the per-cell inverses
+            it = ids.emplace(key, (int)rep.size()).first;
+            rep.push_back((int32_t)k);
+        }
+        idx[(size_t)k] = (uint16_t)it->second;
+    }
+    const int nn = c->nd * c->nd, ns = c->p.n_sys, nent = (int)rep.size();
+    // drift-free inverses of all cells (one launch of the kernel that builds the per-cell array), then the representatives' blocks
+    HIPCHK(c, hipMemsetAsync(f->w, 0, sizeof(double) * nc * c->nd, c->stream));
+    int rc = launch_knp_blockjacobi(c, f->w, f->binv_knp);
+    if (rc) return rc;
+    hipFree(f->bj_idx); hipFree(f->bj_tab);
+    f->bj_idx = nullptr; f->bj_tab = nullptr;
+    int32_t* drep = nullptr;
+    HIPCHK(c, hipMalloc((void**)&drep, sizeof(int32_t) * nent));
+    HIPCHK(c, hipMemcpyAsync(drep, rep.data(), sizeof(int32_t) * nent, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMalloc((void**)&f->bj_tab, sizeof(bjreal) * (size_t)nent * ns * nn));
+    HIPCHK(c, hipMalloc((void**)&f->bj_idx, sizeof(uint16_t) * (size_t)n_own));
+    HIPCHK(c, hipMemcpyAsync(f->bj_idx, idx.data(), sizeof(uint16_t) * (size_t)n_own, hipMemcpyHostToDevice, c->stream));
+    const int64_t tot = (int64_t)nent * ns * nn;
+    hipLaunchKernelGGL(k_bj_gather, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream, nent, (const int32_t*)drep, ns, nc, nn,
+                       (const bjreal*)f->binv_knp, f->bj_tab);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    hipFree(drep);
+    f->bj_entries = nent;
+    f->bj_tab_state = 1;
+    if (getenv("KNP_DEBUG")) fprintf(stderr, "[knp] KNP block-Jacobi table: %d entries for %lld cells\n", nent, (long long)n_own);
+    return 0;
+}
+
 int knp_knp_solve(knp_ctx* c, double rtol, double atol, int maxit, int min_it, int check_every, int* niter, double* res) {
     if (!c || !niter || !res) return -1;
     Fields* f = F(c);
     static const int bj_lag = getenv("KNP_BJ_LAG") ? atoi(getenv("KNP_BJ_LAG")) : 8;
     int rc = 0;
-    if (f->bj_age_knp % (bj_lag > 0 ? bj_lag : 1) == 0) rc = launch_knp_blockjacobi(c, f->f[KNP_F_DNPHI], f->binv_knp);
-    ++f->bj_age_knp;
+    if (f->bj_tab_state == 0 && (rc = build_bj_table(c, f))) return rc;
+    // the table ignores the drift: good while the potential varies little over a cell (psi |z| dphi << 1: 0.01-0.05 through an action
+    // potential on the reference's meshes), poor when the drift dominates (seeded random potentials of the tests: 5).  The cell
+    // Peclet number arrives with the status polls (knp_update_dnphi), i.e. one solve late; the first solve reads it itself.
+    static const double pe_limit = getenv("KNP_BJ_TABLE_PECLET") ? atof(getenv("KNP_BJ_TABLE_PECLET")) : 0.5;
+    bool use_tab = f->bj_tab_state == 1;
+    if (use_tab && c->last_peclet < 0.0f) {
+        int bits = 0;
+        HIPCHK(c, hipMemcpyAsync(&bits, c->status + KNP_PECLET_SLOT, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        memcpy(&c->last_peclet, &bits, sizeof(float));
+    }
+    if (use_tab && !(c->last_peclet <= pe_limit)) use_tab = false;
+    if (use_tab) {
+        f->bj_age_knp = 0;                        // a later fall-back to the per-cell array starts with a rebuild (its content is the drift-free one)
+    } else {
+        if (f->bj_age_knp % (bj_lag > 0 ? bj_lag : 1) == 0) rc = launch_knp_blockjacobi(c, f->f[KNP_F_DNPHI], f->binv_knp);
+        ++f->bj_age_knp;
+    }
     if (rc) return rc;
     if ((rc = extrapolate_guess(c, f->f[KNP_F_C], &f->hist_knp, &f->nh_knp, f->n[KNP_F_C], false))) return rc;
     KrylovVecs kv{};
     kv.x = f->f[KNP_F_C]; kv.b = f->f[KNP_F_B_KNP]; kv.coef = f->f[KNP_F_DNPHI]; kv.binv = f->binv_knp;
+    if (use_tab) { kv.bj_idx = f->bj_idx; kv.bj_tab = f->bj_tab; }
     kv.r = f->r; kv.z = f->z; kv.p = f->p; kv.w = f->w; kv.rhat = f->rhat; kv.v = f->v; kv.y = f->y;
     // DG-level smoother of the KNP preconditioner: two-step Chebyshev iteration on Binv A instead of one block-Jacobi
     // application (one more operator apply per preconditioner application; BiCGStab iterations 14-20 -> 9-13 through an

@@ -312,15 +312,17 @@ __global__ __launch_bounds__(256) void k_dense_mv(int n, const float* __restrict
 // G lanes per conforming dof (a vertex is shared by ~24 tets); fixed summation tree -> deterministic
 template <int G>
 __global__ __launch_bounds__(256) void k_dg_restrict(int64_t ncg, const int32_t* __restrict__ ptr, const int32_t* __restrict__ idx,
-                                                     const double* __restrict__ r, double* __restrict__ rc, int64_t r_stride, int nil) {
+                                                     const double* __restrict__ r, double* __restrict__ rc, int64_t r_stride, int nil,
+                                                     const double* __restrict__ t, double ct) {
     r += (int64_t)blockIdx.y * r_stride;
+    if (t) t += (int64_t)blockIdx.y * r_stride;
     rc += (int64_t)(blockIdx.y / nil) * nil * ncg + (blockIdx.y % nil);          // column blockIdx.y of the interleaved level vector
     const int64_t v = ((int64_t)blockIdx.x * 256 + threadIdx.x) / G;
     const int lane = threadIdx.x % G;
     double s = 0.0;
     if (v < ncg) {
         const int e = ptr[v + 1];
-        for (int k = ptr[v] + lane; k < e; k += G) s += r[idx[k]];
+        for (int k = ptr[v] + lane; k < e; k += G) s += t ? fma(-ct, t[idx[k]], r[idx[k]]) : r[idx[k]];
     }
 #pragma unroll
     for (int off = G / 2; off > 0; off >>= 1) s += __shfl_down(s, off, G);
@@ -333,23 +335,36 @@ __global__ __launch_bounds__(256) void k_dg_restrict(int64_t ncg, const int32_t*
 __global__ __launch_bounds__(256) void k_restrict_tiles(int64_t ndof_owned, int tile_dofs, const int32_t* __restrict__ tile_off,
                                                         const int32_t* __restrict__ slot_ptr, const uint16_t* __restrict__ slot_idx,
                                                         const double* __restrict__ r, int64_t r_stride, double* __restrict__ part,
-                                                        int64_t nslots) {
+                                                        int64_t nslots, const double* __restrict__ t, double ct) {
+    // t != null: the restricted vector is r - ct t (the residual left by the first step of the DG-level Chebyshev smoother, whose
+    // operator product t = A Binv r exists anyway: krylov.hip, hybrid two-level preconditioner)
     extern __shared__ double s_r[];
     r += (int64_t)blockIdx.y * r_stride;
+    if (t) t += (int64_t)blockIdx.y * r_stride;
     part += (int64_t)blockIdx.y * nslots;
     const int64_t d0 = (int64_t)blockIdx.x * tile_dofs;
     const int n = (int)((ndof_owned - d0 < tile_dofs) ? (ndof_owned - d0) : tile_dofs);
     const double* src = r + d0;
     if ((reinterpret_cast<uintptr_t>(src) & 15u) == 0) {                        // 16-byte aligned column: pairs (tile_dofs is even)
         const double2* src2 = reinterpret_cast<const double2*>(src);
-        for (int i = threadIdx.x; 2 * i + 1 < n; i += 256) {
-            const double2 v = src2[i];
-            s_r[2 * i] = v.x;
-            s_r[2 * i + 1] = v.y;
+        if (t) {
+            const double2* t2 = reinterpret_cast<const double2*>(t + d0);
+            for (int i = threadIdx.x; 2 * i + 1 < n; i += 256) {
+                const double2 v = src2[i], w = t2[i];
+                s_r[2 * i] = fma(-ct, w.x, v.x);
+                s_r[2 * i + 1] = fma(-ct, w.y, v.y);
+            }
+            if ((n & 1) && threadIdx.x == 0) s_r[n - 1] = fma(-ct, t[d0 + n - 1], src[n - 1]);
+        } else {
+            for (int i = threadIdx.x; 2 * i + 1 < n; i += 256) {
+                const double2 v = src2[i];
+                s_r[2 * i] = v.x;
+                s_r[2 * i + 1] = v.y;
+            }
+            if ((n & 1) && threadIdx.x == 0) s_r[n - 1] = src[n - 1];
         }
-        if ((n & 1) && threadIdx.x == 0) s_r[n - 1] = src[n - 1];
     } else {
-        for (int i = threadIdx.x; i < n; i += 256) s_r[i] = src[i];
+        for (int i = threadIdx.x; i < n; i += 256) s_r[i] = t ? fma(-ct, t[d0 + i], src[i]) : src[i];
     }
     __syncthreads();
     const int p1 = tile_off[blockIdx.x + 1];
@@ -472,7 +487,8 @@ int amg_vcycle(knp_ctx* c, AmgHierarchy& H, hipStream_t on_stream) {
     return amg_vcycle_eager(c, H);      // eager fallback always runs on the context's stream
 }
 
-int amg_restrict_from_dg(knp_ctx* c, AmgHierarchy& H, const double* r_dg, hipStream_t on_stream, int64_t r_stride) {
+int amg_restrict_from_dg(knp_ctx* c, AmgHierarchy& H, const double* r_dg, hipStream_t on_stream, int64_t r_stride, const double* t_dg,
+                         double ct) {
     if (on_stream && c->dist) { c->err = "amg: the all-reduced restriction runs on the context's stream"; return -1; }
     s_ncol = H.ncol;
     struct Reset { ~Reset() { s_ncol = 1; } } reset_on_exit;
@@ -486,11 +502,11 @@ int amg_restrict_from_dg(knp_ctx* c, AmgHierarchy& H, const double* r_dg, hipStr
             H.part_cols = H.ncol;
         }
         hipLaunchKernelGGL(k_restrict_tiles, dim3((unsigned)H.ntiles, (unsigned)H.ncol), dim3(256), sizeof(double) * tile_dofs, st,
-                           c->m.nc_owned * c->nd, tile_dofs, H.tile_off, H.slot_ptr, H.slot_idx, r_dg, r_stride, H.part, H.nslots);
+                           c->m.nc_owned * c->nd, tile_dofs, H.tile_off, H.slot_ptr, H.slot_idx, r_dg, r_stride, H.part, H.nslots, t_dg, ct);
         hipLaunchKernelGGL(k_restrict_sum, GRIDX((H.ncg + 255) / 256), dim3(256), 0, st, H.ncg, H.part_ptr, H.part_idx,
                            (const double*)H.part, H.nslots, H.levels[0].b, (H.ncol % 2 == 0) ? 2 : 1);
     } else {
-        hipLaunchKernelGGL(k_dg_restrict<8>, GRIDX((H.ncg * 8 + 255) / 256), dim3(256), 0, st, H.ncg, H.cg_ptr, H.cg_idx, r_dg, H.levels[0].b, r_stride, (H.ncol % 2 == 0) ? 2 : 1);
+        hipLaunchKernelGGL(k_dg_restrict<8>, GRIDX((H.ncg * 8 + 255) / 256), dim3(256), 0, st, H.ncg, H.cg_ptr, H.cg_idx, r_dg, H.levels[0].b, r_stride, (H.ncol % 2 == 0) ? 2 : 1, t_dg, ct);
     }
     // multi-GPU: the conforming hierarchy is replicated on every rank; the restricted residual is the sum of the
     // ranks' owned-cell contributions (one all-reduce), after which every rank runs the same V-cycle.  When the finest

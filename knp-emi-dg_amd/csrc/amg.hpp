@@ -44,5 +44,7 @@ struct AmgHierarchy {
 
 struct knp_ctx;
 int amg_vcycle(knp_ctx* c, AmgHierarchy& H, hipStream_t on_stream = nullptr);
-int amg_restrict_from_dg(knp_ctx* c, AmgHierarchy& H, const double* r_dg, hipStream_t on_stream = nullptr, int64_t r_stride = 0);
+// restricts r_dg, or r_dg - ct * t_dg when t_dg is given
+int amg_restrict_from_dg(knp_ctx* c, AmgHierarchy& H, const double* r_dg, hipStream_t on_stream = nullptr, int64_t r_stride = 0,
+                         const double* t_dg = nullptr, double ct = 0.0);
 void amg_free(AmgHierarchy& H);

@@ -18,7 +18,8 @@ typedef float bjreal;
 #define KNP_BLOCK 256
 #define KNP_MAX_RED 8           // partial sums per block per system in one reduction pass
 #define KNP_ODE_FAIL_SLOT (2 * KNP_MAX_SYS)   // word of knp_ctx::status raised by k_ode_step (read back with the solver status)
-#define KNP_STATUS_WORDS (2 * KNP_MAX_SYS + 1)
+#define KNP_PECLET_SLOT (2 * KNP_MAX_SYS + 1)     // bits of a float: max over the owned cells of psi max|z| (max - min nodal phi), set by knp_update_dnphi
+#define KNP_STATUS_WORDS (2 * KNP_MAX_SYS + 2)
 
 // facet kinds stored in bits 2..3 of the per-(cell, local facet) flag byte
 enum : uint32_t { FK_SIPG = 0u, FK_MEMBRANE = 1u, FK_EXTERIOR = 2u, FK_INACTIVE = 3u };
@@ -90,6 +91,10 @@ struct knp_ctx {
     uint8_t* nmat4 = nullptr;      // [nc][4] material id of the neighbour behind every facet (3D)
     double* dtab = nullptr;        // [n_ions][KNP_MAX_MAT]
     int nmat = 0;
+    // host copies of what decides a cell's KNP block-Jacobi block on a structured mesh (abi.hip: build_bj_table): geometry class,
+    // material (distinct D tuple, any count up to 65535; empty = too many), flag bytes (facet kinds)
+    std::vector<uint16_t> h_cls, h_mat;
+    std::vector<uint32_t> h_fflag;
     int* halo_ctr = nullptr;       // [2 operators][2 sets][64 queues] block counters of the persistent halo-staged applies (apply_p1.hip)
     int halo_flip[2] = {0, 0};
     double* rho = nullptr;         // [nc]
@@ -114,6 +119,7 @@ struct knp_ctx {
     void* pinned = nullptr;        // host pinned mirror for status/scalars
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int last_it_emi = 0, last_it_knp = 0;   // iteration counts of the previous solves (chunking of the status polls)
+    float last_peclet = -1.0f;              // cell Peclet number of the drift seen by the last status poll (< 0: not read yet)
     // auxiliary-space AMG hierarchies: [0] EMI, [1 + k] KNP species k
     std::vector<AmgHierarchy> amg;
     std::vector<hipStream_t> aux_streams;   // one per extra KNP species: their V-cycles run concurrently

@@ -9,6 +9,7 @@
 #include "cell_geom.hpp"
 #include "krylov.hpp"
 #include <cstdlib>
+#include <cstring>
 
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
@@ -91,7 +92,16 @@ template <int NV> __device__ __forceinline__ void block_matvec(const bjreal* __r
 struct VecDims {
     int64_t nc_owned, nc;   // vectors are [nsys][nc*NV]; only owned cells are updated / reduced
     int nsys;
+    // block-Jacobi table (KNP on structured meshes, abi.hip: build_bj_table): the cell's inverse block is entry bj_idx[c] of a small
+    // table instead of 4 NV^2 bytes per cell and species read from HBM in every vector kernel; null -> per-cell inverses
+    const uint16_t* bj_idx;
+    const bjreal* bj_tab;   // [n_entries][nsys][NV*NV]
 };
+
+// inverse block of system s, cell c: from the table when there is one, else from the per-cell array binv [nsys][nc][NV*NV]
+template <int NV> __device__ __forceinline__ const bjreal* bj_block(const VecDims& d, const bjreal* __restrict__ binv, int s, int64_t c) {
+    return d.bj_idx ? d.bj_tab + ((int64_t)d.bj_idx[c] * d.nsys + s) * (NV * NV) : binv + ((int64_t)s * d.nc + c) * (NV * NV);
+}
 
 #define SYS_PTR(p, s) ((p) + (int64_t)(s) * d.nc * NV)
 
@@ -407,12 +417,13 @@ __global__ __launch_bounds__(KNP_BLOCK) void k_prolong_add(VecDims d, const int*
 // z = Binv r (plain block-Jacobi apply, used to precondition b on init when the AMG term is active)
 template <int NV>
 __global__ __launch_bounds__(KNP_BLOCK) void k_bj_apply(VecDims d, const bjreal* __restrict__ binv, const double* __restrict__ r,
-                                                        double* __restrict__ z) {
+                                                        double* __restrict__ z, int s = 0) {
+    // binv: the [nsys][nc][NV*NV] array (system s is selected here); r, z: the system's own vectors
     const int64_t c = (int64_t)blockIdx.x * KNP_BLOCK + threadIdx.x;
     if (c >= d.nc_owned) return;
     double rv[NV], zv[NV];
     ldv<NV>(r, c, rv);
-    block_matvec<NV>(binv, c, rv, zv);
+    block_matvec<NV>(bj_block<NV>(d, binv, s, c), 0, rv, zv);
     stv<NV>(z, c, zv);
 }
 
@@ -471,7 +482,7 @@ __global__ __launch_bounds__(KNP_BLOCK) void k_bi_p(VecDims d, const double* __r
     ldv<NV>(SYS_PTR(p, s), c, pv);
 #pragma unroll
     for (int a = 0; a < NV; ++a) pv[a] = rv[a] + beta * (pv[a] - omega * vv[a]);
-    block_matvec<NV>(binv + (int64_t)s * d.nc * NV * NV, c, pv, yv);
+    block_matvec<NV>(bj_block<NV>(d, binv, s, c), 0, pv, yv);
     stv<NV>(SYS_PTR(p, s), c, pv);
     stv<NV>(SYS_PTR(y, s), c, yv);
 }
@@ -491,7 +502,7 @@ __global__ __launch_bounds__(KNP_BLOCK) void k_bi_s(VecDims d, const double* __r
     ldv<NV>(SYS_PTR(v, s), c, vv);
 #pragma unroll
     for (int a = 0; a < NV; ++a) rv[a] -= alpha * vv[a];
-    block_matvec<NV>(binv + (int64_t)s * d.nc * NV * NV, c, rv, zv);
+    block_matvec<NV>(bj_block<NV>(d, binv, s, c), 0, rv, zv);
     stv<NV>(SYS_PTR(r, s), c, rv);
     stv<NV>(SYS_PTR(z, s), c, zv);
 }
@@ -511,7 +522,7 @@ __global__ __launch_bounds__(KNP_BLOCK) void k_bj_cheb2(VecDims d, const int* __
     ldv<NV>(SYS_PTR(t, s), c, tv);
 #pragma unroll
     for (int a = 0; a < NV; ++a) rv[a] = cr * rv[a] - ctt * tv[a];
-    block_matvec<NV>(binv + (int64_t)s * d.nc * NV * NV, c, rv, yv);
+    block_matvec<NV>(bj_block<NV>(d, binv, s, c), 0, rv, yv);
     stv<NV>(SYS_PTR(y, s), c, yv);
 }
 
@@ -630,6 +641,7 @@ static int poll_status(knp_ctx* c, int nsys, int* host_status) {
     HIPCHK(c, hipMemcpyAsync(c->pinned, c->status, sizeof(int) * KNP_STATUS_WORDS, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     for (int i = 0; i < 2 * nsys; ++i) host_status[i] = ((int*)c->pinned)[i];
+    { int bits = ((int*)c->pinned)[KNP_PECLET_SLOT]; float pe; memcpy(&pe, &bits, sizeof(pe)); c->last_peclet = pe; }
     if (((int*)c->pinned)[KNP_ODE_FAIL_SLOT]) {      // raised by k_ode_step earlier in this time step (`assert success`, membrane.py:113)
         hipMemsetAsync(c->status + KNP_ODE_FAIL_SLOT, 0, sizeof(int), c->stream);
         c->err = "ODE integrator did not reach the end time";
@@ -651,12 +663,29 @@ static inline int next_chunk(int it, int maxit, int check_every, int predicted) 
     return (maxit - it < chunk) ? (maxit - it) : chunk;
 }
 
+// KNP (BiCGStab takes any preconditioner): HYBRID two-level form -- the coarse correction acts on r1 = r - t / theta, the residual left
+// by the FIRST step of the DG-level Chebyshev smoother (t = A Binv r is the operator product that smoother computes anyway), instead of
+// on r:  z = S2(r) + P Ac^+ P^T r1.  Same cost per application (the restriction reads t next to r), fewer iterations: 15 instead
+// of 19 BiCGStab iterations to 1e-6 on the oracle's KNP matrix at the r=2 diffusion number (tools/precond_experiment.py).  The EMI
+// system keeps the additive (symmetric) form PCG needs.  KNP_HYBRID=0 restores the additive form.
+static bool knp_hybrid() {
+    static const bool on = !(getenv("KNP_HYBRID") && atoi(getenv("KNP_HYBRID")) == 0);
+    return on;
+}
+template <bool EMI> static double bj_lmin_frac() {
+    // lower end of the Chebyshev interval as a fraction of lambda_max(Binv A): 0.05 measured best over 30 steps at r=2 for the additive
+    // form (0.03..0.06) and for the hybrid one (0.05: 9.06, 0.08: 9.13, 0.12: 9.44 ms/step; profiles/r03_hybrid_ab.txt)
+    static const double v = getenv("KNP_BJ_LMIN") ? atof(getenv("KNP_BJ_LMIN")) : 0.05;
+    return v;
+}
+template <bool EMI> static double bj_theta(const KrylovVecs& kv) { return 0.5 * (1.0 + bj_lmin_frac<EMI>()) * kv.bj_lmax; }
+
 // y (= Binv r on entry) <- two-step Chebyshev block-Jacobi of r:  costs one operator apply and one fused vector kernel
 template <int NV, bool EMI>
 static int bj_cheb2(knp_ctx* c, const VecDims& d, const KrylovVecs& kv, const double* r, double* y, bool use_status = true) {
     int rc;
     if ((rc = dist_apply(c, EMI ? 0 : 1, y, kv.coef, kv.tmp))) return rc;
-    static const double lmin_frac = getenv("KNP_BJ_LMIN") ? atof(getenv("KNP_BJ_LMIN")) : 0.05;   // measured best over 30 steps at r=2 (0.03..0.06)
+    const double lmin_frac = bj_lmin_frac<EMI>();
     const double lmax = kv.bj_lmax, lmin = lmin_frac * lmax;
     const double theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin), sigma = theta / delta, rho0 = 1.0 / sigma;
     const double rho1 = 1.0 / (2.0 * sigma - rho0);
@@ -672,7 +701,7 @@ template <int NV, bool EMI>
 static int bj_lambda_max_impl(knp_ctx* c, KrylovVecs& kv, int iters, double* out) {
     const int ns = EMI ? 1 : c->p.n_sys;
     if (ns > 4) { *out = 0.0; return 0; }
-    VecDims d{c->m.nc_owned, c->m.nc, ns};
+    VecDims d{c->m.nc_owned, c->m.nc, ns, EMI ? nullptr : kv.bj_idx, EMI ? nullptr : kv.bj_tab};
     const dim3 g((unsigned)grid_for(c->m.nc_owned), (unsigned)ns), b(KNP_BLOCK);
     const int64_t n_owned = c->m.nc_owned * NV, stride = c->m.nc * NV;
     const dim3 gs((unsigned)((n_owned + 255) / 256), (unsigned)ns);
@@ -685,8 +714,8 @@ static int bj_lambda_max_impl(knp_ctx* c, KrylovVecs& kv, int iters, double* out
     for (int it = 0; it < iters; ++it) {
         if ((rc = dist_apply(c, EMI ? 0 : 1, kv.v, kv.coef, kv.w))) return rc;
         for (int s = 0; s < ns; ++s)
-            hipLaunchKernelGGL(k_bj_apply<NV>, dim3(g.x), b, 0, c->stream, d, kv.binv + (int64_t)s * c->m.nc * NV * NV,
-                               (const double*)(kv.w + (int64_t)s * stride), kv.y + (int64_t)s * stride);
+            hipLaunchKernelGGL(k_bj_apply<NV>, dim3(g.x), b, 0, c->stream, d, (const bjreal*)kv.binv,
+                               (const double*)(kv.w + (int64_t)s * stride), kv.y + (int64_t)s * stride, s);
         double ny = 0.0;
         if ((rc = max_abs_diff(c, kv.y, kv.z, ns, &ny))) return rc;
         lam = ny / nv;
@@ -711,7 +740,7 @@ int knp_bj_lambda_max(knp_ctx* c, KrylovVecs& kv, int iters, double* out, bool e
 
 template <int NV>
 static int pcg_impl(knp_ctx* c, KrylovVecs& kv, double rtol, double atol, int maxit, int check_every, int* niter, double* res) {
-    VecDims d{c->m.nc_owned, c->m.nc, 1};
+    VecDims d{c->m.nc_owned, c->m.nc, 1, nullptr, nullptr};
     const dim3 g((unsigned)grid_for(c->m.nc_owned)), b(KNP_BLOCK);
     int rc;
     if ((rc = dist_apply(c, 0, kv.x, kv.coef, kv.w))) return rc;
@@ -787,7 +816,7 @@ int pcg_solve(knp_ctx* c, KrylovVecs& kv, double rtol, double atol, int maxit, i
 // independent chains of tiny latency-bound kernels: species 0 runs on the context's stream, every further species
 // on its own auxiliary stream (fork / join with events), so the chains overlap.
 template <int NV>
-static int knp_coarse_correction(knp_ctx* c, const VecDims& d, const double* in, double* out) {
+static int knp_coarse_correction(knp_ctx* c, const VecDims& d, const double* in, double* out, const double* t = nullptr, double ct = 0.0) {
     const dim3 g1((unsigned)grid_for(c->m.nc_owned)), b(KNP_BLOCK);
     int active[KNP_MAX_SYS], na = 0;
     for (int s = 0; s < d.nsys; ++s)
@@ -797,7 +826,7 @@ static int knp_coarse_correction(knp_ctx* c, const VecDims& d, const double* in,
     if (c->amg[1].ready && c->amg[1].ncol == d.nsys) {
         // shared hierarchy: one restriction, one V-cycle and one prolongation carry all species as right-hand-side columns
         AmgHierarchy& H = c->amg[1];
-        if ((rc = amg_restrict_from_dg(c, H, in, nullptr, d.nc * NV))) return rc;
+        if ((rc = amg_restrict_from_dg(c, H, in, nullptr, d.nc * NV, t, ct))) return rc;
         if ((rc = amg_vcycle(c, H))) return rc;
         if (d.nsys % 2 == 0)
             hipLaunchKernelGGL(k_prolong_add_pair<NV>, dim3(g1.x, (unsigned)(d.nsys / 2)), b, 0, c->stream, d, c->status, H.dg2cg,
@@ -816,7 +845,7 @@ static int knp_coarse_correction(knp_ctx* c, const VecDims& d, const double* in,
     if (!fork_all)
         for (int i = 0; i < na; ++i) {
             const int s = active[i];
-            if ((rc = amg_restrict_from_dg(c, c->amg[1 + s], in + (int64_t)s * d.nc * NV))) return rc;
+            if ((rc = amg_restrict_from_dg(c, c->amg[1 + s], in + (int64_t)s * d.nc * NV, nullptr, 0, t ? t + (int64_t)s * d.nc * NV : nullptr, ct))) return rc;
         }
     if (fork) {
         while ((int)c->aux_streams.size() < na - 1) {
@@ -838,7 +867,7 @@ static int knp_coarse_correction(knp_ctx* c, const VecDims& d, const double* in,
             st = c->aux_streams[i - 1];
             HIPCHK(c, hipStreamWaitEvent(st, c->fork_event, 0));
         }
-        if (fork_all && (rc = amg_restrict_from_dg(c, H, in + (int64_t)s * d.nc * NV, st))) return rc;
+        if (fork_all && (rc = amg_restrict_from_dg(c, H, in + (int64_t)s * d.nc * NV, st, 0, t ? t + (int64_t)s * d.nc * NV : nullptr, ct))) return rc;
         if ((rc = amg_vcycle(c, H, st))) return rc;
         if (fork_all || !st)
             hipLaunchKernelGGL(k_prolong_add<NV>, g1, b, 0, st ? st : c->stream, d, c->status, s, H.dg2cg, H.levels[0].x,
@@ -860,7 +889,7 @@ template <int NV>
 static int bicgstab_impl(knp_ctx* c, KrylovVecs& kv, double rtol, double atol, int maxit, int min_it, int check_every,
                          int* niter, double* res) {
     const int ns = c->p.n_sys;
-    VecDims d{c->m.nc_owned, c->m.nc, ns};
+    VecDims d{c->m.nc_owned, c->m.nc, ns, kv.bj_idx, kv.bj_tab};
     const dim3 g((unsigned)grid_for(c->m.nc_owned), (unsigned)ns), b(KNP_BLOCK);
     int rc;
     if ((rc = dist_apply(c, 1, kv.x, kv.coef, kv.w))) return rc;
@@ -874,15 +903,17 @@ static int bicgstab_impl(knp_ctx* c, KrylovVecs& kv, double rtol, double atol, i
         const int chunk = next_chunk(it, maxit, check_every, c->last_it_knp);
         for (int k = 0; k < chunk; ++k) {
             hipLaunchKernelGGL(k_bi_p<NV>, g, b, 0, c->stream, d, c->scal, c->status, kv.r, kv.v, kv.binv, kv.p, kv.y);
+            const bool hyb = kv.bj_lmax > 0.0 && knp_hybrid();
+            const double ct = hyb ? 1.0 / bj_theta<false>(kv) : 0.0;
             if (kv.bj_lmax > 0.0 && (rc = bj_cheb2<NV, false>(c, d, kv, kv.p, kv.y))) return rc;
-            if ((rc = knp_coarse_correction<NV>(c, d, kv.p, kv.y))) return rc;
+            if ((rc = knp_coarse_correction<NV>(c, d, kv.p, kv.y, hyb ? kv.tmp : nullptr, ct))) return rc;
             if ((rc = dist_apply(c, 1, kv.y, kv.coef, kv.v))) return rc;
             hipLaunchKernelGGL(k_dot2<NV>, g, b, 0, c->stream, d, kv.rhat, kv.v, (const double*)nullptr, (const double*)nullptr,
                                c->partial, c->status);
             if ((rc = finalize(c, OP_BI_ALPHA, ns, 1, rtol, atol, min_it))) return rc;
             hipLaunchKernelGGL(k_bi_s<NV>, g, b, 0, c->stream, d, c->scal, c->status, kv.v, kv.binv, kv.r, kv.z);
             if (kv.bj_lmax > 0.0 && (rc = bj_cheb2<NV, false>(c, d, kv, kv.r, kv.z))) return rc;
-            if ((rc = knp_coarse_correction<NV>(c, d, kv.r, kv.z))) return rc;
+            if ((rc = knp_coarse_correction<NV>(c, d, kv.r, kv.z, hyb ? kv.tmp : nullptr, ct))) return rc;
             if ((rc = dist_apply(c, 1, kv.z, kv.coef, kv.w))) return rc;
             hipLaunchKernelGGL(k_dot2<NV>, g, b, 0, c->stream, d, kv.w, kv.r, kv.w, kv.w, c->partial, c->status);
             if ((rc = finalize(c, OP_BI_OMEGA, ns, 2, rtol, atol, min_it))) return rc;

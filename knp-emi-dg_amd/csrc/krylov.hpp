@@ -6,7 +6,9 @@ enum { KS_RHO = 0, KS_RHO_OLD, KS_ALPHA, KS_BETA, KS_OMEGA, KS_RES, KS_RES0, KS_
 
 struct KrylovVecs {
     double *x, *b, *coef;                  // unknown, rhs, operator coefficient (kappa | dnphi)
-    bjreal* binv;                          // block-Jacobi inverses (fp32 storage)
+    bjreal* binv;                          // block-Jacobi inverses (fp32 storage), [nsys][nc][nd*nd]
+    const uint16_t* bj_idx = nullptr;      // KNP on structured meshes: per-cell entry of the inverse-block table (instead of binv)
+    const bjreal* bj_tab = nullptr;        // [entries][nsys][nd*nd]
     double *r, *z, *p, *w;                 // PCG
     double *rhat, *v, *y;                  // BiCGStab extras (t aliases w)
     double* tmp = nullptr;                 // scratch of the Chebyshev block-Jacobi smoother (BiCGStab), or null
