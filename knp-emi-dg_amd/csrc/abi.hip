@@ -34,6 +34,8 @@ struct Fields {
     uint16_t* bj_idx = nullptr;            // [nc_owned]
     bjreal* bj_tab = nullptr;              // [entries][n_sys][nd*nd]
     int bj_entries = 0;
+    float* ivol = nullptr;                 // [nc] 1 / cell volume: weights of the residual norms of the stopping tests (krylov.hip)
+    double emi_r_abs = 0.0;                // knp_emi_residual_target: > 0 -> PCG stops on ||b - A phi||_w <= this
 };
 
 // initial guess from the last solutions: nh = number of valid history entries (h1 = previous, h2 = the one before)
@@ -212,6 +214,19 @@ int knp_ctx_create(knp_ctx** out, int device, int dim, int degree, int n_ions, i
             }
         hcell[k] = std::sqrt(h2);
     }
+    // 1 / cell volume (weights of the residual norms)
+    std::vector<float> ivol((size_t)nc, 1.0f);
+    for (int64_t k = 0; k < nc; ++k) {
+        double e[3][3] = {{0.0}};
+        for (int a = 0; a < dim; ++a)
+            for (int q = 0; q < dim; ++q)
+                e[a][q] = coords[(int64_t)cells[k * NV + a + 1] * dim + q] - coords[(int64_t)cells[k * NV] * dim + q];
+        const double det = dim == 2 ? e[0][0] * e[1][1] - e[0][1] * e[1][0]
+                                    : e[0][0] * (e[1][1] * e[2][2] - e[1][2] * e[2][1]) - e[0][1] * (e[1][0] * e[2][2] - e[1][2] * e[2][0]) +
+                                      e[0][2] * (e[1][0] * e[2][1] - e[1][1] * e[2][0]);
+        const double vol = std::fabs(det) / (dim == 2 ? 2.0 : 6.0);
+        ivol[(size_t)k] = vol > 0.0 ? (float)(1.0 / vol) : 0.0f;
+    }
     int rc = 0;
     rc |= dev_alloc_copy(c, &m.h, hcell.data(), hcell.size());
     rc |= dev_alloc_copy(c, &m.coords, csrc, (size_t)nv * cstride);
@@ -281,6 +296,7 @@ int knp_ctx_create(knp_ctx** out, int device, int dim, int degree, int n_ions, i
     if (!rc) hipMemset(c->status, 0, sizeof(int) * KNP_STATUS_WORDS);
     if (!rc && hipHostMalloc(&c->pinned, 4096) != hipSuccess) rc = -2;
     if (rc) { g_err = "device allocation failed: " + c->err; delete fl; delete c; return -2; }
+    if (dev_alloc_copy(c, &fl->ivol, ivol.data(), ivol.size())) { g_err = "device allocation failed: " + c->err; delete fl; delete c; return -2; }
     g_fields[c] = fl;
     *out = c;
     return 0;
@@ -299,7 +315,7 @@ void knp_ctx_destroy(knp_ctx* c) {
     Fields* fl = g_fields[c];
     if (fl) {
         for (int i = 0; i < KNP_F_COUNT; ++i) hipFree(fl->f[i]);
-        hipFree(fl->binv_emi); hipFree(fl->binv_knp); hipFree(fl->bj_idx); hipFree(fl->bj_tab);
+        hipFree(fl->binv_emi); hipFree(fl->binv_knp); hipFree(fl->bj_idx); hipFree(fl->bj_tab); hipFree(fl->ivol);
         double* wk[] = {fl->r, fl->z, fl->p, fl->w, fl->rhat, fl->v, fl->y, fl->hist_emi, fl->hist_knp, fl->tmp_knp, fl->tmp_emi};
         for (auto p : wk) hipFree(p);
         delete fl;
@@ -551,7 +567,16 @@ __global__ void k_cell_peclet(int64_t nc_owned, int nd, const double* __restrict
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) pe = fmaxf(pe, __shfl_down(pe, off, 64));
-    if ((threadIdx.x & 63) == 0 && pe > 0.0f) atomicMax(out, __float_as_int(pe));    // non-negative floats order like their bit patterns
+    __shared__ float s_pe[4];
+    if ((threadIdx.x & 63) == 0) s_pe[threadIdx.x >> 6] = pe;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        pe = fmaxf(fmaxf(s_pe[0], s_pe[1]), fmaxf(s_pe[2], s_pe[3]));
+        // one atomic per workgroup, and only when it would raise the value: atomics on one line retire at ~13 ns chip-wide (one per wave
+        // cost 180 us at r=2); non-negative floats order like their bit patterns
+        const int bits = __float_as_int(pe);
+        if (bits > __atomic_load_n(out, __ATOMIC_RELAXED)) atomicMax(out, bits);
+    }
 }
 
 int knp_update_dnphi(knp_ctx* c) {
@@ -601,6 +626,19 @@ int knp_knp_rhs(knp_ctx* c) {
                           f->f[KNP_F_I_CH], f->f[KNP_F_B_KNP]);
 }
 
+// Error-controlled stop of the EMI solve (round 3; replaces the per-mesh factors on rtol_emi).  PCG stops when the residual b - A phi,
+// in the cell-volume-weighted norm ||r||_w^2 = sum_K |r_K|^2 / vol_K, falls below r_abs.  The caller derives r_abs from the accuracy it
+// wants for the CONCENTRATIONS: the potential enters the KNP step through the drift form int z_k psi D_k c_k grad(phi).grad(v), which
+// is alpha_k / (F z_k) times a_emi(phi, v) (kappa = F psi sum_j z_j^2 D_j c_j, alpha_k = z_k^2 D_k c_k / sum_j ... <= 1): an EMI residual
+// r perturbs the KNP load vector by alpha_k r / (F z_k), i.e. the concentrations by about |r| / (F |z_k| |b_knp,k|) relative
+// (b_knp,k ~ M c_k / dt, the KNP right-hand side).  r_abs = theta eps_c F min_k |z_k| ||b_knp,k||_w (knpemidg/solver.py).
+// 0 restores PETSc's test on the preconditioned norm (rtol, atol of knp_emi_solve).
+int knp_emi_residual_target(knp_ctx* c, double r_abs) {
+    if (!c || !(r_abs >= 0.0)) return -1;
+    F(c)->emi_r_abs = r_abs;
+    return 0;
+}
+
 int knp_emi_solve(knp_ctx* c, double rtol, double atol, int maxit, int check_every, int* niter, double* res) {
     if (!c || !niter || !res) return -1;
     Fields* f = F(c);
@@ -614,6 +652,8 @@ int knp_emi_solve(knp_ctx* c, double rtol, double atol, int maxit, int check_eve
     if ((rc = extrapolate_guess(c, f->f[KNP_F_PHI], &f->hist_emi, &f->nh_emi, f->n[KNP_F_PHI], true))) return rc;
     KrylovVecs kv{};
     kv.x = f->f[KNP_F_PHI]; kv.b = f->f[KNP_F_B_EMI]; kv.coef = f->f[KNP_F_KAPPA]; kv.binv = f->binv_emi;
+    kv.ivol = f->ivol; kv.r_abs = f->emi_r_abs;
+    kv.d8 = !(getenv("KNP_KNP_NORM2") && atoi(getenv("KNP_KNP_NORM2")) == 1);   // the residual target is a density norm of order 8, like the KNP test
     kv.r = f->r; kv.z = f->z; kv.p = f->p; kv.w = f->w; kv.rhat = f->rhat; kv.v = f->v; kv.y = f->y;
     // the same two-step Chebyshev block-Jacobi smoother for EMI (KNP_EMI_CHEB=0 disables): at the effective tolerance the
     // parity bounds need (rtol 2e-8, knpemidg/solver.py) it cuts the PCG iterations from 5.2 to 4.2 per step and the
@@ -734,6 +774,14 @@ int knp_knp_solve(knp_ctx* c, double rtol, double atol, int maxit, int min_it, i
     KrylovVecs kv{};
     kv.x = f->f[KNP_F_C]; kv.b = f->f[KNP_F_B_KNP]; kv.coef = f->f[KNP_F_DNPHI]; kv.binv = f->binv_knp;
     if (use_tab) { kv.bj_idx = f->bj_idx; kv.bj_tab = f->bj_tab; }
+    kv.ivol = f->ivol;
+    // Stopping test on the order-8 norms of the residual / load densities (krylov.hip): the max-norm error of the concentrations was
+    // measured at 0.03-0.055 of that ratio on both mesh families, so  ratio <= KNP_D8_FACTOR * rtol  asks for an estimated max-norm
+    // error of about rtol (profiles/r03_knp_norms_*.txt).  KNP_KNP_NORM2=1: plain rtol on the cell-volume-weighted 2-norm instead.
+    static const bool d8 = !(getenv("KNP_KNP_NORM2") && atoi(getenv("KNP_KNP_NORM2")) == 1);
+    static const double d8_factor = getenv("KNP_D8_FACTOR") ? atof(getenv("KNP_D8_FACTOR")) : 20.0;
+    kv.d8 = d8;
+    if (d8) rtol *= d8_factor;
     kv.r = f->r; kv.z = f->z; kv.p = f->p; kv.w = f->w; kv.rhat = f->rhat; kv.v = f->v; kv.y = f->y;
     // DG-level smoother of the KNP preconditioner: two-step Chebyshev iteration on Binv A instead of one block-Jacobi
     // application (one more operator apply per preconditioner application; BiCGStab iterations 14-20 -> 9-13 through an

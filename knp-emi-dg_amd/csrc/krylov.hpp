@@ -2,7 +2,7 @@
 #pragma once
 #include "knpemi_internal.hpp"
 
-enum { KS_RHO = 0, KS_RHO_OLD, KS_ALPHA, KS_BETA, KS_OMEGA, KS_RES, KS_RES0, KS_BNORM, KS_TOL, KS_N = 12 };
+enum { KS_RHO = 0, KS_RHO_OLD, KS_ALPHA, KS_BETA, KS_OMEGA, KS_RES, KS_RES0, KS_BNORM, KS_TOL, KS_RNORM, KS_N = 12 };   // KS_RNORM: ||b - A x|| in the cell-volume-weighted norm (PCG)
 
 struct KrylovVecs {
     double *x, *b, *coef;                  // unknown, rhs, operator coefficient (kappa | dnphi)
@@ -13,6 +13,9 @@ struct KrylovVecs {
     double *rhat, *v, *y;                  // BiCGStab extras (t aliases w)
     double* tmp = nullptr;                 // scratch of the Chebyshev block-Jacobi smoother (BiCGStab), or null
     double bj_lmax = 0.0;                  // > 0: lambda_max(Binv A) estimate -> two-step Chebyshev block-Jacobi
+    const float* ivol = nullptr;           // [nc] 1 / cell volume: weights of the residual norms (see krylov.hip: weighted norms)
+    bool d8 = false;                       // BiCGStab: stop on the order-8 norms of the residual / load densities (krylov.hip) instead of ||.||_w
+    double r_abs = 0.0;                    // PCG: > 0 -> converged when ||b - A x||_w <= r_abs instead of the preconditioned-norm test
 };
 
 int pcg_solve(knp_ctx* c, KrylovVecs& kv, double rtol, double atol, int maxit, int check_every, int* niter, double* res);

@@ -7,13 +7,13 @@
 #include "../../include/knpemi_hip.h"
 #include "knpemi_internal.hpp"
 
-#define ODE_MAX_STATES 4
+#define ODE_MAX_STATES 11
 #define ODE_MAX_PARAMS 20
 #define ODE_MAX_STIM 4
 #define ODE_MAX_OPS 12
 
 struct OdeSet {
-    int model = 0;              // 1 = HH with synaptic stimulus, 2 = HH without, 3 = EMIx HH (cm/ms/mV), 4 = glial, 5 = passive leak
+    int model = 0;              // 1 = HH with synaptic stimulus, 2 = HH without, 3 = EMIx HH (cm/ms/mV), 4 = glial, 5 = passive leak, 6 = EMIx calibration system
     int ns = 0, np = 0;
     int64_t n = 0;
     int32_t* facet = nullptr;   // [n] facet id of every node
@@ -122,12 +122,61 @@ __device__ __forceinline__ void leak_rhs(double t, const double* y, double* p, d
     dy[0] = (-i_K - i_Na) / p[4];
 }
 
+// EMIx calibration system: the neuronal HH membrane and the glial membrane above coupled through the ECS / neuron / glia compartment
+// concentrations their currents change; integrated alone until stationary it yields the initial state of the full run
+// (reference: examples/emix-simulations/mm_calibration.py:143-255, run_calibration.py:13-90).
+// states: m h n V_n V_g K_e K_n K_g Na_e Na_n Na_g ; parameters: 0 g_Na_bar 1 g_K_bar 2 g_leak_Na_n 3 g_leak_K_n 4 g_leak_Na_g
+//  5 g_leak_K_g 6 Cm 7 stim_amplitude 8 m_K 9 m_Na 10 I_max_n 11 I_max_g
+__device__ __forceinline__ void calibration_rhs(double t, const double* y, double* p, double* dy) {
+    const double m = y[0], h = y[1], n = y[2], Vn = y[3], Vg = y[4];
+    const double K_e = y[5], K_n = y[6], K_g = y[7], Na_e = y[8], Na_n = y[9], Na_g = y[10];
+    const double c = 8.314e3 * 300e3 / 96485e3;
+    const double ICS_vol = 3.42e-11 / 2.0, ECS_vol = 7.08e-11, surface = 2.29e-6, F = 96485e3;
+    const double K_g_init = 102.74050220804774, K_e_init = 3.32597273958481;
+    const double E_Na_n = c * log(Na_e / Na_n), E_K_n = c * log(K_e / K_n);
+    const double E_Na_g = c * log(Na_e / Na_g), E_K_g = c * log(K_e / K_g);
+    const double E_K_init = c * log(K_e_init / K_g_init);
+    const double alpha_m = 0.1 * (Vn + 40.0) / (1.0 - exp(-(Vn + 40.0) / 10.0));
+    const double beta_m = 4.0 * exp(-(Vn + 65.0) / 18.0);
+    const double alpha_h = 0.07 * exp(-(Vn + 65.0) / 20.0);
+    const double beta_h = 1.0 / (1.0 + exp(-(Vn + 35.0) / 10.0));
+    const double alpha_n = 0.01 * (Vn + 55.0) / (1.0 - exp(-(Vn + 55.0) / 10.0));
+    const double beta_n = 0.125 * exp(-(Vn + 65.0) / 80.0);
+    dy[0] = (1 - m) * alpha_m - m * beta_m;
+    dy[1] = (1 - h) * alpha_h - h * beta_h;
+    dy[2] = (1 - n) * alpha_n - n * beta_n;
+    const double g_stim = p[7] * exp(-fmod(t, 20.0) / 2.0);
+    const double a = 1 + p[8] / K_e, bn = 1 + p[9] / Na_n, bg = 1 + p[9] / Na_g;
+    const double i_pump_n = p[10] / (a * a * bn * bn * bn);
+    const double i_pump_g = p[11] / (a * a * bg * bg * bg);
+    const double A = 1 + exp(18.4 / 42.4);
+    const double B = 1 + exp(-(0.1186e3 + E_K_init) / 0.0441e3);
+    const double C = 1 + exp((Vg - E_K_g + 0.0185e3) / 0.0425e3);
+    const double D = 1 + exp(-(0.1186e3 + Vg) / 0.0441e3);
+    const double i_Kir = p[5] * sqrt(K_e / K_e_init) * (A * B) / (C * D) * (Vg - E_K_g);
+    const double i_Na_n = (p[2] + p[0] * h * m * m * m + g_stim) * (Vn - E_Na_n) + 3 * i_pump_n;
+    const double n2 = n * n;
+    const double i_K_n = (p[3] + p[1] * n2 * n2) * (Vn - E_K_n) - 2 * i_pump_n;
+    const double i_Na_g = p[4] * (Vg - E_Na_g) + 3 * i_pump_g;
+    const double i_K_g = i_Kir - 2 * i_pump_g;
+    dy[3] = (-i_K_n - i_Na_n) / p[6];
+    dy[4] = (-i_K_g - i_Na_g) / p[6];
+    const double ke = surface / (F * ECS_vol), ki = surface / (F * ICS_vol);
+    dy[5] = (i_K_n + i_K_g) * ke;
+    dy[6] = -i_K_n * ki;
+    dy[7] = -i_K_g * ki;
+    dy[8] = (i_Na_n + i_Na_g) * ke;
+    dy[9] = -i_Na_n * ki;
+    dy[10] = -i_Na_g * ki;
+}
+
 template <int MODEL> __device__ __forceinline__ void model_rhs(double t, const double* y, double* p, double* dy) {
     if (MODEL == 1) hh_rhs<true>(t, y, p, dy);
     else if (MODEL == 2) hh_rhs<false>(t, y, p, dy);
     else if (MODEL == 3) hh_emix_rhs(t, y, p, dy);
     else if (MODEL == 4) glial_rhs(t, y, p, dy);
-    else leak_rhs(t, y, p, dy);
+    else if (MODEL == 5) leak_rhs(t, y, p, dy);
+    else calibration_rhs(t, y, p, dy);
 }
 
 template <int MODEL, int NS, int NP>
@@ -270,10 +319,11 @@ extern "C" {
 int knp_ode_create(knp_ctx* c, int model, int64_t n, const int32_t* facets, int ns, int np, const double* states,
                    const double* params) {
     if (!c) return -1;
-    if (model < 1 || model > 5) { c->err = "ode: unknown device model id"; return -1; }
+    if (model < 1 || model > 6) { c->err = "ode: unknown device model id"; return -1; }
     if (model <= 3 && (ns != 4 || np != 17)) { c->err = "ode: HH models have 4 states and 17 parameters"; return -1; }
     if (model == 4 && (ns != 1 || np != 19)) { c->err = "ode: the glial model has 1 state and 19 parameters"; return -1; }
     if (model == 5 && (ns != 1 || np != 15)) { c->err = "ode: the leak model has 1 state and 15 parameters"; return -1; }
+    if (model == 6 && (ns != 11 || np != 12)) { c->err = "ode: the calibration system has 11 states and 12 parameters"; return -1; }
     for (int64_t i = 0; i < n; ++i)
         if (facets[i] < 0 || facets[i] >= c->m.nf) { c->err = "ode: facet id out of range"; return -1; }
     OdeSet S;
@@ -386,7 +436,8 @@ int knp_ode_step(knp_ctx* c, int handle, double t0, double dt, double rtol, doub
     else if (S->model == 2) ODE_LAUNCH(2, 4, 17);
     else if (S->model == 3) ODE_LAUNCH(3, 4, 17);
     else if (S->model == 4) ODE_LAUNCH(4, 1, 19);
-    else ODE_LAUNCH(5, 1, 15);
+    else if (S->model == 5) ODE_LAUNCH(5, 1, 15);
+    else ODE_LAUNCH(6, 11, 12);
 #undef ODE_LAUNCH
     HIPCHK(c, hipGetLastError());
     return 0;

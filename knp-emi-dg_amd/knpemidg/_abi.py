@@ -49,6 +49,7 @@ SIGNATURES = {
     "knp_knp_apply": (C.c_int, [_ctxp, C.c_int, C.c_int]),
     "knp_emi_rhs": (C.c_int, [_ctxp]),
     "knp_knp_rhs": (C.c_int, [_ctxp]),
+    "knp_emi_residual_target": (C.c_int, [_ctxp, C.c_double]),
     "knp_emi_solve": (C.c_int, [_ctxp, C.c_double, C.c_double, C.c_int, C.c_int, C.POINTER(C.c_int), _f64p]),
     "knp_knp_solve": (C.c_int, [_ctxp, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), _f64p]),
     "knp_step_updates": (C.c_int, [_ctxp]),
@@ -420,6 +421,10 @@ class Device:
 
     def knp_rhs(self):
         self._chk(self.lib.knp_knp_rhs(self.ctx), "knp_knp_rhs")
+
+    def emi_residual_target(self, r_abs):
+        """r_abs > 0: the following EMI solves stop on ||b - A phi||_w <= r_abs (include/knpemi_hip.h); 0: preconditioned-norm test."""
+        self._chk(self.lib.knp_emi_residual_target(self.ctx, float(r_abs)), "knp_emi_residual_target")
 
     def emi_solve(self, rtol, atol=1e-40, maxit=1000, check_every=25):
         it = C.c_int(0)

@@ -12,6 +12,7 @@ sides restate the gotran-generated models of the reference:
     hh_emix         examples/emix-simulations/mm_hh.py:118-161        (cm / ms / mV; configs[4] neurons)
     glial           examples/emix-simulations/mm_glial.py:117-170     (cm / ms / mV; configs[4] glia, Kir 4.1)
     leak            examples/rat-neuron/mm_leak.py:107-133            (SI; passive dendrite / soma membrane)
+    calibration     examples/emix-simulations/mm_calibration.py:143-255 (cm / ms / mV; ODE-only system behind configs[4]'s ICs)
 
 State / parameter column layouts are the reference's (mm_hh.py:7-72).  The channel currents I_ch_k are a side
 effect of the reference's last right-hand-side evaluation (mm_hh.py:154-159), i.e. tolerance-level quantities;
@@ -182,6 +183,70 @@ def leak_rhs(t, y, p):
     i_Na = (p[0] + i_stim) * (V - p[2]) + 3.0 * i_pump
     i_K = p[1] * (V - p[3]) - 2.0 * i_pump
     return [(-i_K - i_Na) / p[4]], (i_Na, i_K, 0.0)
+
+
+def calibration_init_states():
+    """examples/emix-simulations/mm_calibration.py:19-33 (m h n V_n V_g K_e K_n K_g Na_e Na_n Na_g)"""
+    return np.array([0.01, 0.85, 0.18, -74.38, -83.08, 3.32, 124.15, 102.75, 100.71, 12.83, 12.39])
+
+
+def calibration_init_parameters():
+    """examples/emix-simulations/mm_calibration.py:55-75"""
+    return np.array([120.0, 36.0, 0.1, 0.4, 0.1, 1.7, 2.0, 0.0, 2.0, 7.7, 44.9, 50.0])
+
+
+CALIBRATION_P_IDX = {"g_Na_bar": 0, "g_K_bar": 1, "g_leak_Na_n": 2, "g_leak_K_n": 3, "g_leak_Na_g": 4, "g_leak_K_g": 5, "Cm": 6,
+                     "stim_amplitude": 7, "m_K": 8, "m_Na": 9, "I_max_n": 10, "I_max_g": 11}
+
+
+def calibration_rhs(t, y, p):
+    """examples/emix-simulations/mm_calibration.py:143-255: neuronal HH + glial Kir membranes with compartment concentrations as
+    states (Nernst potentials follow them); returns (dy, (neuronal Na current, neuronal K current, glial K current))."""
+    temperature, R, F = 300e3, 8.314e3, 96485e3
+    ICS_vol, ECS_vol, surface = 3.42e-11 / 2.0, 7.08e-11, 2.29e-6
+    K_g_init, K_e_init = 102.74050220804774, 3.32597273958481
+    m, h, n, Vn, Vg, K_e, K_n, K_g, Na_e, Na_n, Na_g = y
+    E_Na_n = R * temperature / F * math.log(Na_e / Na_n)
+    E_K_n = R * temperature / F * math.log(K_e / K_n)
+    E_Na_g = R * temperature / F * math.log(Na_e / Na_g)
+    E_K_g = R * temperature / F * math.log(K_e / K_g)
+    E_K_init = R * temperature / F * math.log(K_e_init / K_g_init)
+    alpha_m = 0.1 * (Vn + 40.0) / (1.0 - math.exp(-(Vn + 40.0) / 10.0))
+    beta_m = 4.0 * math.exp(-(Vn + 65.0) / 18.0)
+    alpha_h = 0.07 * math.exp(-(Vn + 65.0) / 20.0)
+    beta_h = 1.0 / (1.0 + math.exp(-(Vn + 35.0) / 10.0))
+    alpha_n = 0.01 * (Vn + 55.0) / (1.0 - math.exp(-(Vn + 55.0) / 10.0))
+    beta_n = 0.125 * math.exp(-(Vn + 65) / 80.0)
+    i_Stim = p[7] * math.exp(-math.fmod(t, 20.0) / 2.0)
+    i_pump_n = p[10] / ((1 + p[8] / K_e) ** 2 * (1 + p[9] / Na_n) ** 3)
+    i_pump_g = p[11] / ((1 + p[8] / K_e) ** 2 * (1 + p[9] / Na_g) ** 3)
+    dphi = Vg - E_K_g
+    A = 1 + math.exp(18.4 / 42.4)
+    B = 1 + math.exp(-(0.1186e3 + E_K_init) / 0.0441e3)
+    C = 1 + math.exp((dphi + 0.0185e3) / 0.0425e3)
+    D = 1 + math.exp(-(0.1186e3 + Vg) / 0.0441e3)
+    g_Kir = math.sqrt(K_e / K_e_init) * (A * B) / (C * D)
+    I_Kir = p[5] * g_Kir * (Vg - E_K_g)
+    i_Na_n = (p[2] + p[0] * h * math.pow(m, 3) + i_Stim) * (Vn - E_Na_n) + 3 * i_pump_n
+    i_K_n = (p[3] + p[1] * math.pow(n, 4)) * (Vn - E_K_n) - 2 * i_pump_n
+    i_Na_g = p[4] * (Vg - E_Na_g) + 3 * i_pump_g
+    i_K_g = I_Kir - 2 * i_pump_g
+    dy = [(1 - m) * alpha_m - m * beta_m, (1 - h) * alpha_h - h * beta_h, (1 - n) * alpha_n - n * beta_n,
+          (-i_K_n - i_Na_n) / p[6], (-i_K_g - i_Na_g) / p[6],
+          i_K_n * surface / (F * ECS_vol) + i_K_g * surface / (F * ECS_vol), -i_K_n * surface / (F * ICS_vol),
+          -i_K_g * surface / (F * ICS_vol), i_Na_n * surface / (F * ECS_vol) + i_Na_g * surface / (F * ECS_vol),
+          -i_Na_n * surface / (F * ICS_vol), -i_Na_g * surface / (F * ICS_vol)]
+    return dy, (i_Na_n, i_K_n, i_K_g)
+
+
+def step_lsoda_plain(rhs, states, params, t0, dt, rtol=1.0e-8, atol=0.0):
+    """One LSODA call per row for systems that keep no currents in their parameter table (the calibration system)."""
+    for row in range(states.shape[0]):
+        p = params[row]
+        sol = solve_ivp(lambda t, y: rhs(t, y, p)[0], (t0, t0 + dt), states[row], method="LSODA", rtol=rtol, atol=max(atol, 1e-300))
+        assert sol.success
+        states[row] = sol.y[:, -1]
+    return states
 
 
 # name -> (initial states, initial parameters, rhs(t, y, p) -> (dy, currents), parameter index table, state index of V)

@@ -324,6 +324,53 @@ def test_device_ode_other_models_match_lsoda_oracle(hip_lib, which):
     dev.close()
 
 
+def test_calibration_system_matches_lsoda_oracle_and_reaches_the_emix_initial_state(hip_lib):
+    """The ODE-only calibration run of BASELINE configs[4] ("calibrated ICs"; reference:
+    examples/emix-simulations/run_calibration.py:13-90 with mm_calibration.py:143-255) on the device (k_ode_step model 6):
+    (1) 25 steps from perturbed states against the oracle's scalar restatement stepped by scipy LSODA (rtol 1e-8 / atol 0) ->
+    1e-6; (2) the driver run to stationarity reproduces the initial values the reference hard-codes in mm_hh.py:11-14 (m, h, n,
+    phi_M of the neuron: all printed digits) and, to the 3-4 digits that survive the reference's own parameter revisions, the
+    concentrations of run_EMIx_simulation.py:76-84."""
+    import membrane_oracle as mo
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "emix_simulations"))
+    import run_calibration as rc
+    from knpemidg import _abi as A
+    from knpemidg.mesh import RectangleMesh, MeshFunction
+    from knpemidg.functions import FacetSpace
+    from knpemidg.membrane import MembraneModel
+    from knpemidg.models import mm_calibration as ode
+    assert np.array_equal(ode.init_state_values(), mo.calibration_init_states())
+    assert np.array_equal(ode.init_parameter_values(), mo.calibration_init_parameters())
+    mesh = RectangleMesh((0.0, 0.0), (1.0, 1.0), 2, 2)
+    facet_f = MeshFunction(mesh, 1, 0)
+    dev = A.Device(mesh, np.zeros(mesh.num_cells(), dtype=np.uint32), facet_f.array(), (), 3)
+    mm = MembraneModel(ode, facet_f=facet_f, tag=0, V=FacetSpace(mesh))
+    assert mm.attach_device(dev)
+    n = mm.nodes
+    rng = np.random.default_rng(4)
+    st = np.tile(mo.calibration_init_states(), (n, 1)) * (1 + 0.02 * rng.uniform(-1, 1, (n, 11)))
+    pr = np.tile(mo.calibration_init_parameters(), (n, 1))
+    pr[:, mo.CALIBRATION_P_IDX["stim_amplitude"]] = 3.0
+    mm.states = st.copy()
+    for k in range(25):
+        mm.step_lsoda(dt=0.1, stimulus={'stim_amplitude': 3.0})
+        mo.step_lsoda_plain(mo.calibration_rhs, st, pr, k * 0.1, 0.1)
+    sd = mm.states
+    assert np.abs(sd - st).max() < 1e-6 * np.abs(st).max(), np.abs(sd - st).max()
+    assert np.abs(st[:, 3] + 74.38).max() > 1.0                        # the stimulated neuron moved: not a comparison of rest states
+    dev.close()
+    # (2) the driver; 40 000 steps of 0.1 ms = 4 s (stationary to 1e-9 after ~3 s; the reference runs 100 000)
+    out, states = rc.calibrate(40000, verbose=False)
+    assert np.abs(states - states[0]).max() == 0.0                     # every node integrates the same system
+    hh = dict(m_init=0.016651023270342777, h_init=0.8541791472445746, n_init=0.18821645700362638, phi_M_n_init=-74.3848784437955)
+    for key, ref in hh.items():                                        # examples/emix-simulations/mm_hh.py:11-14
+        assert abs(out[key] - ref) < 2e-7 * abs(ref), (key, out[key], ref)
+    near = dict(phi_M_g_init=-83.08511451850003, K_e_init=3.3236967382613933, K_n_init=124.15397583492471, K_g_init=102.75563828644862,
+                Na_e_init=100.71925900028181, Na_n_init=12.838513108606818, Na_g_init=12.39731187972181)
+    for key, ref in near.items():                                      # mm_glial.py:11, run_EMIx_simulation.py:76-84
+        assert abs(out[key] - ref) < 2e-4 * abs(ref), (key, out[key], ref)
+
+
 def test_stimulus_is_reimposed_every_step(hip_lib):
     """The reference overwrites the stimulus parameters on the masked rows at the start of every step_lsoda call
     (membrane.py:98-104): a hook that rewrites the whole parameter table between steps must not lose the stimulus."""

@@ -14,7 +14,9 @@ def run(tight, override=None):
     if tight:
         sp = sp._replace(rtol_emi=1e-11, rtol_knp=1e-13)
     elif override is not None:
-        sp = sp._replace(emi_rtol_scale=override[0], rtol_knp=override[1], knp_rtol_scale=1.0)
+        from collections import namedtuple
+        fields = dict(sp._asdict(), emi_rtol_scale=override[0], rtol_knp=override[1], knp_rtol_scale=1.0)   # the round-2 test with explicit factors
+        sp = namedtuple("solver_params", fields.keys())(*fields.values())
     S._unpack_solver_params(sp)
     S.save_fields = S.save_solver_stats = False
     S.splitting_scheme = True
