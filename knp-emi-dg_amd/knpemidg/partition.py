@@ -46,7 +46,9 @@ class Partition:
     """method "slab": contiguous chunks of the cells sorted by centroid coordinate `axis` (idealized BoxMesh geometries: <= 2
     peers per rank); "rcb": recursive coordinate bisection (unstructured meshes, e.g. the EMIx reconstruction)."""
 
-    def __init__(self, mesh, world, axis=0, method="slab"):
+    def __init__(self, mesh, world, axis=0, method="slab", fractions=None):
+        # fractions (slab only): world + 1 increasing numbers from 0 to 1, the share of the sorted cells below every cut (default:
+        # equal parts); lets a test build a rank so thin that ALL its cells touch a cut
         self.mesh = mesh
         self.world = int(world)
         nc = mesh.num_cells()
@@ -56,7 +58,9 @@ class Partition:
             cm = mesh.cell_midpoints()[:, axis]
             order = np.argsort(cm, kind="stable")
             owner = np.empty(nc, dtype=np.int32)
-            bounds = [(nc * r) // self.world for r in range(self.world + 1)]
+            bounds = [(nc * r) // self.world for r in range(self.world + 1)] if fractions is None else \
+                [int(round(nc * float(f))) for f in fractions]
+            assert len(bounds) == self.world + 1 and bounds[0] == 0 and bounds[-1] == nc and all(b1 > b0 for b0, b1 in zip(bounds, bounds[1:]))
             for r in range(self.world):
                 owner[order[bounds[r]:bounds[r + 1]]] = r
         else:
@@ -149,14 +153,14 @@ class LocalMesh:
         return arr
 
 
-def distribute_solver(solver_factory, mesh_tuple, ode_models, stim_params, rank, world, local_rank, dist, method="rcb"):
+def distribute_solver(solver_factory, mesh_tuple, ode_models, stim_params, rank, world, local_rank, dist, method="rcb", fractions=None):
     """Any `Solver` subclass on `world` GPUs of one node.  `solver_factory()` returns a fresh, un-set-up solver (its params and
     ion list inside); `mesh_tuple` = (mesh, subdomains, surfaces) of the GLOBAL mesh, which every rank holds (host memory only);
     `ode_models` = {membrane facet tag: ODE module}.  Every rank keeps its part + one ghost layer, creates its device context,
     joins the two RCCL communicators (reductions / halo exchanges) and receives its halo tables."""
     from knpemidg import _abi
     mesh, subdomains, surfaces = mesh_tuple
-    part = Partition(mesh, world, method=method)
+    part = Partition(mesh, world, method=method, fractions=fractions)
     loc = part.local(rank)
     sub_l, surf_l = loc.localize(subdomains, surfaces, ode_models.keys())
     S = solver_factory()

@@ -26,8 +26,13 @@ else:
     mesh_tuple = make_mesh_3D(0, n_axons=n_axons)
     ode_models = {1: mm_hh, 2: mm_hh_no_stim} if n_axons > 1 else {1: mm_hh}
     params, ion_list, stim_params = physical_setup(1.0e-4)
+    # "thin": three slabs, the middle one 2 % of the cells -- every cell of that rank touches a cut (n_interior == 0), its peers have
+    # interior cells: all three must take the same (overlapped) exchange channel (comm.hip dist_apply)
+    fractions = [0.0, 0.49, 0.51, 1.0] if method == "thin" else None
     S = distribute_solver(lambda: SolverIdealized(params, ion_list, degree_emi=1, degree_knp=1), mesh_tuple, ode_models, stim_params,
-                          rank, world, 0, None, method=method)
+                          rank, world, 0, None, method="slab" if method == "thin" else method, fractions=fractions)
+    if method == "thin":
+        assert (S.dev.n_interior == 0) == (rank == 1), (rank, S.dev.n_interior)
     S._unpack_solver_params(solver_parameters(3, 0)._replace(rtol_emi=1e-10, rtol_knp=1e-12))
 S.save_fields = S.save_solver_stats = False
 S.splitting_scheme = True

@@ -44,7 +44,7 @@ def _single_rank(n_axons, steps, method):
     return out
 
 
-@pytest.mark.parametrize("world,method,n_axons", [(2, "slab", 4), (3, "slab", 4), (3, "rcb", 1), (3, "emix", 0)])
+@pytest.mark.parametrize("world,method,n_axons", [(2, "slab", 4), (3, "slab", 4), (3, "rcb", 1), (3, "emix", 0), (3, "thin", 4)])
 def test_partitioned_solver_with_several_ranks_on_one_gpu(hip_lib, tmp_path, world, method, n_axons):
     steps = 3
     name = "/knp_%s" % uuid.uuid4().hex[:16]
