@@ -258,9 +258,10 @@ def main():
     # (counters cannot be read from inside this process); null when the workload differs
     cls = bool(S.dev.n_geometry_classes)
     if args.degree == 1:
-        emi_name = "k_emi_apply_cls_staged<3,256>" if cls else "k_emi_apply<3,3>"
+        emi_name = {3: "k_emi_apply_ring", 1: "k_emi_apply_cls_staged<3,256>"}.get(S.dev.apply_variant(0), "k_emi_apply<3,3>")
         kv = S.dev.apply_variant(1)
-        knp_name = {2: "k_knp_apply_halo<2,false>", 6: "k_knp_apply_halo<2,true>", 1: "k_knp_apply_cls_staged<3,2,256>"}.get(kv, "k_knp_apply<3,2>")
+        knp_name = {7: "k_knp_apply_ring<2>", 2: "k_knp_apply_halo<2,false>", 6: "k_knp_apply_halo<2,true>",
+                    1: "k_knp_apply_cls_staged<3,2,256>"}.get(kv, "k_knp_apply<3,2>")
     else:
         emi_name = "k_emi_apply_p2<3,256,%s>" % ("true" if cls else "false")
         knp_name = "k_knp_apply_p2<3,256,%s>" % ("true" if cls else "false")

@@ -131,8 +131,8 @@ enum knp_debug_table_id {
     KNP_DT_CFACET = 3,  /* int32  [nc][dim+1]  facet id behind local facet i                                                  */
     KNP_DT_MF = 4,      /* int32  [nmf][6]     membrane facets: plus cell, minus cell, their local facet indices, facet id,
                                                1 if a side is an owned cell                                                     */
-    KNP_DT_HB_SRC = 5,  /* int32  [nblk][hs]   halo-staged apply: per 256-cell block, 4 * cell + local facet of every SIPG
-                                               neighbour outside the block, in (cell, facet) order, -1 padded (0 bytes if unused) */
+    KNP_DT_HB_SRC = 5,  /* int32  [nblk][hs]   halo- / ring-staged applies: per 256-cell block, 4 * cell + local facet of every
+                                               coupled (SIPG or membrane) neighbour outside the block, in (cell, facet) order, -1 padded (0 bytes if unused) */
     KNP_DT_HB_LOC = 6,  /* uint16 [nc_owned][4] LDS entry of the neighbour behind facet i: < 256 in-block, else 256 + list position */
     KNP_DT_META = 7     /* int64  [8]          nc, nc_owned, nf, nmf, hb_stride, hb_long0, n_interior, dim                     */
 };
@@ -253,7 +253,8 @@ int knp_apply_timing_read(knp_ctx* ctx, int which, float* avg_ms, int* count);
 
 /* Which kernel knp_emi_apply (which = 0) / knp_knp_apply (which = 1) currently dispatches to, so that a measurement can name it:
  * 0 coordinate path (any mesh), 1 geometry classes + LDS staging (structured 3D P1), 2 halo-staged persistent kernel, 6 the same
- * with D read through the material table (knp_set_params found <= 16 distinct coefficient tuples), 8 matrix-free P2,
+ * with D read through the material table (knp_set_params found <= 16 distinct coefficient tuples), 3 (EMI) / 7 (KNP) ring-staged
+ * kernels (loader wave + LDS-DMA ring + consumer waves, csrc/apply_ring.hip; the default on structured 3D P1 meshes), 8 matrix-free P2,
  * 9 assembled P2 blocks (KNP_P2_ASSEMBLED=1).  Negative on bad arguments.  No reference counterpart (measurement only). */
 int knp_apply_variant(knp_ctx* ctx, int which);
 

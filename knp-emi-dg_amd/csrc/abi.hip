@@ -81,8 +81,13 @@ thread_local std::string g_err;
 
 Fields* F(knp_ctx* c) { return g_fields[c]; }
 
+// KNP_DMA_PAD zero bytes follow every table: the ring-staged applies (apply_ring.hip) read whole 256-cell blocks of the per-cell
+// tables with 16-byte DMA granules, also where the last block runs past the end of the mesh
+#define KNP_DMA_PAD 4096
 template <typename T> int dev_alloc_copy(knp_ctx* c, T** dst, const T* src, size_t n) {
-    HIPCHK(c, hipMalloc((void**)dst, std::max<size_t>(n, 1) * sizeof(T)));
+    const size_t bytes = std::max<size_t>(n, 1) * sizeof(T);
+    HIPCHK(c, hipMalloc((void**)dst, bytes + KNP_DMA_PAD));
+    HIPCHK(c, hipMemset((char*)*dst + bytes, 0, KNP_DMA_PAD));
     if (src && n) HIPCHK(c, hipMemcpy(*dst, src, n * sizeof(T), hipMemcpyHostToDevice));
     return 0;
 }
@@ -236,7 +241,7 @@ int knp_ctx_create(knp_ctx** out, int device, int dim, int degree, int n_ions, i
     rc |= dev_alloc_copy(c, &m.cfacet, cfacet.data(), cfacet.size());
     rc |= dev_alloc_copy(c, &m.mf, mf.data(), mf.size());
     if (dim == 3 && degree == 1 && nc_owned > 0 && nc < (int64_t(1) << 29)) {
-        // halo-staged KNP apply: per block of 256 consecutive cells, the SIPG neighbours outside the block
+        // halo- / ring-staged applies: per block of 256 consecutive cells, the coupled (SIPG or membrane: a_emi couples both) neighbours outside the block
         const int64_t B = KNP_HALO_BLK, nblk = (nc_owned + B - 1) / B;
         std::vector<int32_t> hcnt(nblk, 0);
         std::vector<std::vector<int32_t>> lists((size_t)nblk);
@@ -248,7 +253,7 @@ int knp_ctx_create(knp_ctx** out, int device, int dim, int degree, int n_ions, i
                 for (int a = 0; a < 4; ++a) {
                     const uint32_t kind = (fb[k * 4 + a] >> 2) & 3u;
                     const int64_t nbk = nbr[k * 4 + a];
-                    if (kind != FK_SIPG || nbk < 0) continue;
+                    if ((kind != FK_SIPG && kind != FK_MEMBRANE) || nbk < 0) continue;
                     if (nbk / B == b) { hloc[k * 4 + a] = (uint16_t)(nbk - b * B); continue; }
                     hloc[k * 4 + a] = (uint16_t)(B + L.size());
                     L.push_back((int32_t)(nbk * 4 + (fb[k * 4 + a] & 3u)));
@@ -322,7 +327,7 @@ void knp_ctx_destroy(knp_ctx* c) {
         g_fields.erase(c);
     }
     hipFree(c->m.hb_src); hipFree(c->m.hb_loc);
-    hipFree(c->m.cls); hipFree(c->m.cls_table); hipFree(c->m.coords); hipFree(c->m.h); hipFree(c->m.cells); hipFree(c->m.nbr); hipFree(c->m.fflag); hipFree(c->m.cfacet); hipFree(c->m.mf);
+    hipFree(c->m.cls); hipFree(c->m.cls_table); hipFree(c->m.cls_ext); hipFree(c->m.coords); hipFree(c->m.h); hipFree(c->m.cells); hipFree(c->m.nbr); hipFree(c->m.fflag); hipFree(c->m.cfacet); hipFree(c->m.mf);
     hipFree(c->mat); hipFree(c->nmat4); hipFree(c->dtab); hipFree(c->halo_ctr);
     hipFree(c->D); hipFree(c->rho); hipFree(c->fsrc); hipFree(c->mms_C); hipFree(c->extra_emi); hipFree(c->extra_knp); hipFree(c->partial); hipFree(c->scal); hipFree(c->status);
     hipFree(c->halo_send_idx); hipFree(c->halo_sendbuf);
@@ -399,8 +404,8 @@ int knp_set_params(knp_ctx* c, double C_M, double dt, double Fc, double R, doubl
             mat[k] = (uint8_t)id;
         }
         if (ok) {
-            if (!c->mat) HIPCHK(c, hipMalloc((void**)&c->mat, (size_t)nc));
-            if (!c->nmat4) HIPCHK(c, hipMalloc((void**)&c->nmat4, (size_t)nc * 4));
+            if (!c->mat) { HIPCHK(c, hipMalloc((void**)&c->mat, (size_t)nc + KNP_DMA_PAD)); HIPCHK(c, hipMemset(c->mat, 0, (size_t)nc + KNP_DMA_PAD)); }
+            if (!c->nmat4) { HIPCHK(c, hipMalloc((void**)&c->nmat4, (size_t)nc * 4 + KNP_DMA_PAD)); HIPCHK(c, hipMemset(c->nmat4, 0, (size_t)nc * 4 + KNP_DMA_PAD)); }
             if (!c->dtab) HIPCHK(c, hipMalloc((void**)&c->dtab, sizeof(double) * KNP_MAX_IONS * KNP_MAX_MAT));
             HIPCHK(c, hipMemcpy(c->mat, mat.data(), (size_t)nc, hipMemcpyHostToDevice));
             HIPCHK(c, hipMemcpy(c->dtab, tab.data(), sizeof(double) * tab.size(), hipMemcpyHostToDevice));
@@ -429,20 +434,49 @@ static int chk_field(knp_ctx* c, int field) {
 
 int knp_set_geometry_classes(knp_ctx* c, int ncls, const uint16_t* cls, const double* table) {
     if (!c) return -1;
-    hipFree(c->m.cls); hipFree(c->m.cls_table);
-    c->m.cls = nullptr; c->m.cls_table = nullptr; c->m.ncls = 0;
+    hipFree(c->m.cls); hipFree(c->m.cls_table); hipFree(c->m.cls_ext);
+    c->m.cls = nullptr; c->m.cls_table = nullptr; c->m.cls_ext = nullptr; c->m.ncls = 0;
     c->h_cls.clear();
     if (g_fields.count(c)) F(c)->bj_tab_state = 0;
     if (ncls <= 0) return 0;
     if (ncls > 65535 || !cls || !table) { c->err = "geometry classes: bad arguments"; return -1; }
     for (int64_t k = 0; k < c->m.nc; ++k)
         if (cls[k] >= ncls) { c->err = "geometry class id out of range"; return -1; }
-    HIPCHK(c, hipMalloc((void**)&c->m.cls, sizeof(uint16_t) * c->m.nc));
+    HIPCHK(c, hipMalloc((void**)&c->m.cls, sizeof(uint16_t) * c->m.nc + KNP_DMA_PAD));
+    HIPCHK(c, hipMemset(c->m.cls, 0, sizeof(uint16_t) * c->m.nc + KNP_DMA_PAD));
     HIPCHK(c, hipMemcpy(c->m.cls, cls, sizeof(uint16_t) * c->m.nc, hipMemcpyHostToDevice));
     c->h_cls.assign(cls, cls + c->m.nc);
     if (g_fields.count(c)) F(c)->bj_tab_state = 0;
     HIPCHK(c, hipMalloc((void**)&c->m.cls_table, sizeof(double) * (size_t)ncls * KNP_CLS_STRIDE));
     HIPCHK(c, hipMemcpy(c->m.cls_table, table, sizeof(double) * (size_t)ncls * KNP_CLS_STRIDE, hipMemcpyHostToDevice));
+    // derived per-facet coefficients of the classed P1 applies, so that no lane recomputes what only depends on the class:
+    //   [8 i + 0] gr = G_ii / L_i          [8 i + 1..3] G_{a_m i} - L_{a_m} gr  (neighbour's gradient through the own basis, cell_geom.hpp)
+    //   [8 i + 4] (2 / (h + h')) sqrt(G_ii) D vol   [8 i + 5] -L_i D vol (the neighbour's D vol')   [8 i + 6] sqrt(G_ii) D vol   [8 i + 7] 0
+    std::vector<double> ext((size_t)ncls * KNP_CLS_EXT, 0.0);
+    for (int q = 0; q < ncls; ++q) {
+        const double* rec = table + (size_t)q * KNP_CLS_STRIDE;
+        double G[4][4];
+        int k = 1;
+        for (int a = 0; a < 4; ++a)
+            for (int b = a; b < 4; ++b) { G[a][b] = rec[k]; G[b][a] = rec[k]; ++k; }
+        const double DV = 3.0 * rec[0];
+        for (int i = 0; i < 4; ++i) {
+            const double* L = rec + 11 + 6 * i;
+            const double sqG = L[4], hinv = L[5];
+            double* e = ext.data() + (size_t)q * KNP_CLS_EXT + 8 * i;
+            if (L[i] != 0.0) {
+                const double gr = G[i][i] / L[i];
+                e[0] = gr;
+                for (int mm = 0; mm < 3; ++mm) { const int a = mm + (mm >= i); e[1 + mm] = G[a][i] - L[a] * gr; }
+            }
+            e[4] = hinv * sqG * DV;
+            e[5] = -L[i] * DV;
+            e[6] = sqG * DV;
+        }
+    }
+    hipFree(c->m.cls_ext); c->m.cls_ext = nullptr;
+    HIPCHK(c, hipMalloc((void**)&c->m.cls_ext, sizeof(double) * ext.size()));
+    HIPCHK(c, hipMemcpy(c->m.cls_ext, ext.data(), sizeof(double) * ext.size(), hipMemcpyHostToDevice));
     c->m.ncls = ncls;
     return 0;
 }

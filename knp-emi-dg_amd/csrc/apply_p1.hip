@@ -11,9 +11,6 @@
 #include "cell_geom.hpp"
 #include <cstdlib>
 
-template <int D> struct FacetConst;
-template <> struct FacetConst<3> { static constexpr double mass = 1.0 / 12.0, trip = 1.0 / 60.0; };
-template <> struct FacetConst<2> { static constexpr double mass = 1.0 / 6.0, trip = 1.0 / 24.0; };
 
 // grad(w') . g_i for the neighbour's P1 function w' (values wn[], neighbour local facet j)
 template <int D, int I>
@@ -155,22 +152,18 @@ __device__ __forceinline__ void emi_facet_cls(const MeshDev& m, const CellGeom<D
         sdu += du[mm];
     }
     const double DV = (double)D * K.vol;
-    const double sqG = st.lrec[11 + 6 * I + 4];
+    const lds_double* ft = st.lext + 8 * I;                                // class-level coefficients (MeshDev::cls_ext)
     if (kind == FK_MEMBRANE) {
-        const double w = C_phi * sqG * DV * FacetConst<D>::mass;
+        const double w = C_phi * ft[6] * FacetConst<D>::mass;
 #pragma unroll
         for (int mm = 0; mm < D; ++mm) y[mm + (mm >= I)] = fma(w, sdu + du[mm], y[mm + (mm >= I)]);
         return;
     }
-    double L[NV];
-#pragma unroll
-    for (int a = 0; a < NV; ++a) L[a] = st.lrec[11 + 6 * I + a];
-    const double gr = K.G[I][I] * fast_rcp(L[I]);
-    double s_own = 0.0, s_nb = xap * gr;
+    double s_own = 0.0, s_nb = xap * ft[0];
 #pragma unroll
     for (int a = 0; a < NV; ++a) s_own = fma(xv[a], K.G[a][I], s_own);
 #pragma unroll
-    for (int mm = 0; mm < D; ++mm) s_nb = fma(xf[mm], fma(-L[mm + (mm >= I)], gr, K.G[mm + (mm >= I)][I]), s_nb);
+    for (int mm = 0; mm < D; ++mm) s_nb = fma(xf[mm], ft[1 + mm], s_nb);
     double kf[D], sk = 0.0, skn = 0.0, q = 0.0;
 #pragma unroll
     for (int mm = 0; mm < D; ++mm) {
@@ -183,7 +176,7 @@ __device__ __forceinline__ void emi_facet_cls(const MeshDev& m, const CellGeom<D
     q *= hm;
 #pragma unroll
     for (int a = 0; a < NV; ++a) y[a] = fma(K.G[a][I], q, y[a]);
-    const double pw = tau * st.lrec[11 + 6 * I + 5] * sqG * DV * FacetConst<D>::trip;
+    const double pw = tau * ft[4] * FacetConst<D>::trip;
     double kb[D], skb = 0.0, skd = 0.0;
 #pragma unroll
     for (int mm = 0; mm < D; ++mm) {
@@ -234,12 +227,14 @@ __global__ __launch_bounds__(BLK) void k_emi_apply_cls_staged(MeshDev m, const d
     constexpr int NV = D + 1;
     __shared__ __attribute__((aligned(16))) double s_x[BLK * NV];
     __shared__ __attribute__((aligned(16))) double s_k[BLK * NV];
-    __shared__ __attribute__((aligned(16))) double s_tab[CLS_MAX_LDS * KNP_CLS_STRIDE];
+    __shared__ __attribute__((aligned(16))) double s_tab[CLS_MAX_LDS * 11];                 // vol + Gram per class
+    __shared__ __attribute__((aligned(16))) double s_ext[CLS_MAX_LDS * (KNP_CLS_EXT + 1)];  // derived facet coefficients, odd stride
     const int64_t c0 = m.c_begin + xcd_block(blockIdx.x, gridDim.x) * BLK;
     if (c0 >= m.c_end) return;
     const int64_t c = c0 + threadIdx.x;
     const bool valid = c < m.c_end;
-    for (int i = threadIdx.x; i < m.ncls * KNP_CLS_STRIDE; i += BLK) s_tab[i] = m.cls_table[i];
+    for (int i = threadIdx.x; i < m.ncls * 11; i += BLK) s_tab[i] = m.cls_table[(i / 11) * KNP_CLS_STRIDE + (i % 11)];
+    for (int i = threadIdx.x; i < m.ncls * KNP_CLS_EXT; i += BLK) s_ext[(i / KNP_CLS_EXT) * (KNP_CLS_EXT + 1) + (i % KNP_CLS_EXT)] = m.cls_ext[i];
     int nb[NV];
     uint32_t flags = 0;
     unsigned cls = 0;
@@ -256,7 +251,7 @@ __global__ __launch_bounds__(BLK) void k_emi_apply_cls_staged(MeshDev m, const d
     }
     __syncthreads();
     if (!valid) return;
-    const lds_double* rec = TO_LDS(s_tab) + cls * KNP_CLS_STRIDE;
+    const lds_double* rec = TO_LDS(s_tab) + cls * 11;
     CellGeom<D> K;
     K.vol = rec[0];
     {
@@ -267,7 +262,7 @@ __global__ __launch_bounds__(BLK) void k_emi_apply_cls_staged(MeshDev m, const d
             for (int b = a; b < NV; ++b) { K.G[a][b] = rec[q]; K.G[b][a] = rec[q]; ++q; }
     }
     StageView<D> st{TO_LDS(s_x), TO_LDS(s_k), nullptr, nullptr, c0,
-                    (unsigned)((m.c_end - c0 < BLK) ? (m.c_end - c0) : BLK), nullptr, rec};
+                    (unsigned)((m.c_end - c0 < BLK) ? (m.c_end - c0) : BLK), nullptr, rec, TO_LDS(s_ext) + cls * (KNP_CLS_EXT + 1)};
     {
         double kbar = 0.0;
 #pragma unroll
@@ -384,11 +379,6 @@ __global__ __launch_bounds__(KNP_BLOCK) void k_emi_blockjacobi(MeshDev m, const 
 //   un = max(D grad(phi).n_own, 0).   `gphi[c][a]` = grad(phi)_c . grad(lambda_a) is precomputed
 //   once per KNP solve (phi is frozen during the solve):  area * grad(phi).n_i = -D vol gphi_i.
 // ------------------------------------------------------------------------------------------
-struct KnpArgs {
-    int ns;
-    double inv_dt, psi, tau;
-    double z[KNP_MAX_SYS];
-};
 
 template <int D, int NS, int I, bool DIAG>
 __device__ __forceinline__ void knp_facet(const MeshDev& m, const CellGeom<D>& K, const int* nb, uint32_t flags,
@@ -683,8 +673,8 @@ __global__ __launch_bounds__(BLK) void k_knp_apply_cls_staged(MeshDev m, const d
 //     staged kernels spends 70 % of its LDS cycles in bank conflicts), the class table has an odd stride;
 //   * D is read through a material table when the cells carry few distinct coefficient tuples (knp_set_params).
 // LDS entries [0,256) = the block's cells, [256, 256+nh) = halo entries (one per out-of-block coupled facet).
-#define HALO_FT 24       // per-class facet record kept in LDS: 4 x (L[4], sqrt(G_ii), 2/(h+h'))
-#define HALO_FTS 25      // its LDS stride (odd: lanes of different classes land on different banks)
+#define HALO_FT KNP_CLS_EXT   // per-class facet record kept in LDS: 4 x 8 derived coefficients (MeshDev::cls_ext)
+#define HALO_FTS 33      // its LDS stride (odd: lanes of different classes land on different banks)
 
 // vol + Gram matrix of the cell's class, straight from the (L1/L2-resident) table into registers
 __device__ __forceinline__ void load_class_gram(const double* __restrict__ table, unsigned cls, CellGeom<3>& K) {
@@ -749,17 +739,16 @@ __device__ __forceinline__ void knp_facet_halo(const CellGeom<3>& K, uint32_t fl
     const uint32_t fb = (flags >> (8 * I)) & 0xffu;
     if (((fb >> 2) & 3u) != FK_SIPG) return;
     const unsigned j = fb & 3u;
-    double L[NV];
+    // class-level coefficients (cls_ext): nothing geometric is recomputed per lane
+    const double gr = ft[8 * I], pen_geo = ft[8 * I + 4], nLI_DV = ft[8 * I + 5];
+    double cf[D];
 #pragma unroll
-    for (int a = 0; a < NV; ++a) L[a] = ft[6 * I + a];
-    const double sqG = ft[6 * I + 4], hinv = ft[6 * I + 5];
+    for (int mm = 0; mm < D; ++mm) cf[mm] = ft[8 * I + 1 + mm];
     const double gp_nb = s_g[loc < KNP_HALO_BLK ? j * KNP_HALO_BLK + loc : loc + (KNP_HALO_BLK * NV - KNP_HALO_BLK)];
-    const double rLi = fast_rcp(L[I]);
     const double DV = (double)D * K.vol;
     const double up_own = fmax(-gp[I], 0.0) * DV;
-    const double up_nb = fmax(-gp_nb, 0.0) * DV * (-L[I]);
-    const double penA = ka.tau * hinv * sqG * DV;
-    const double gr = K.G[I][I] * rLi;
+    const double up_nb = fmax(-gp_nb, 0.0) * nLI_DV;
+    const double penA = ka.tau * pen_geo;
 #pragma unroll
     for (int k = 0; k < NS; ++k) {
         const lds_double* xl = s_x + (unsigned)k * NV * ent + loc;                  // component-major: [k][a][entry]
@@ -773,7 +762,7 @@ __device__ __forceinline__ void knp_facet_halo(const CellGeom<3>& K, uint32_t fl
         for (int a = 0; a < NV; ++a) s_own = fma(xv[k][a], K.G[a][I], s_own);
         double s_nb = xap * gr;
 #pragma unroll
-        for (int mm = 0; mm < D; ++mm) s_nb = fma(xf[mm], fma(-L[mm + (mm >= I)], gr, K.G[mm + (mm >= I)][I]), s_nb);
+        for (int mm = 0; mm < D; ++mm) s_nb = fma(xf[mm], cf[mm], s_nb);
         const double zp = ka.z[k] * ka.psi;
         const double c_own = penA * Dk[k] - zp * Dk[k] * up_own;
         const double c_nb = penA * Dn - zp * Dn * up_nb;
@@ -812,7 +801,7 @@ __global__ __launch_bounds__(KNP_HALO_BLK) void k_knp_apply_halo(MeshDev m, cons
     const unsigned t = threadIdx.x;
     HaloWalk w(m, counters, flip_nq);
     if (w.cur >= w.last) return;
-    for (int i = t; i < m.ncls * HALO_FT; i += BLK) s_ft[(i / HALO_FT) * HALO_FTS + (i % HALO_FT)] = m.cls_table[(i / HALO_FT) * KNP_CLS_STRIDE + 11 + (i % HALO_FT)];
+    for (int i = t; i < m.ncls * HALO_FT; i += BLK) s_ft[(i / HALO_FT) * HALO_FTS + (i % HALO_FT)] = m.cls_ext[i];
     if (MAT && t < NS * KNP_MAX_MAT) s_D[t] = dtab[t];
     const bool hl = (int)t < m.hb_stride;
     int src = hl ? m.hb_src[(w.b_lo + w.cur) * m.hb_stride + t] : -1;
@@ -1078,15 +1067,23 @@ template <typename KernelT> static dim3 halo_grid(const MeshDev& m, int device, 
 
 static int emi_apply_impl(knp_ctx* c, const double* x, const double* kappa, double* y) {
     if (c->degree != 1) return p2_assembled() ? tab_apply(c, 0, x, y) : p2_emi_apply(c, x, kappa, y);
-    const int64_t n = c->m.c_end - c->m.c_begin;
-    if (n <= 0) return 0;
+    if (c->m.c_end - c->m.c_begin <= 0) return 0;
+    MeshDev m = c->m;                          // the cell range of this launch (the ring-staged kernel may take only its front part)
+    if (ring_usable(c, 0) && m.c_begin < c->m.hb_long0 * KNP_HALO_BLK) {
+        m.c_end = std::min<int64_t>(c->m.c_end, c->m.hb_long0 * KNP_HALO_BLK);
+        const int rc = ring_emi_apply(c, m, x, kappa, y);
+        if (rc || m.c_end >= c->m.c_end) return rc;
+        m.c_begin = m.c_end;                   // blocks with long neighbour lists (a partition's cut cells): LDS-staged kernel below
+        m.c_end = c->m.c_end;
+    }
+    const int64_t n = m.c_end - m.c_begin;
     const dim3 g((unsigned)grid8(n)), b(KNP_BLOCK);
     if (c->m.cls && c->m.dim == 3 && c->m.ncls <= CLS_MAX_LDS)
-        hipLaunchKernelGGL((k_emi_apply_cls_staged<3, 256>), g, b, 0, c->stream, c->m, x, kappa, y, c->p.C_phi, c->p.tau_emi);
+        hipLaunchKernelGGL((k_emi_apply_cls_staged<3, 256>), g, b, 0, c->stream, m, x, kappa, y, c->p.C_phi, c->p.tau_emi);
     else if (c->m.dim == 3)
-        hipLaunchKernelGGL(k_emi_apply<3>, g, b, 0, c->stream, c->m, x, kappa, y, c->p.C_phi, c->p.tau_emi);
+        hipLaunchKernelGGL(k_emi_apply<3>, g, b, 0, c->stream, m, x, kappa, y, c->p.C_phi, c->p.tau_emi);
     else
-        hipLaunchKernelGGL(k_emi_apply<2>, g, b, 0, c->stream, c->m, x, kappa, y, c->p.C_phi, c->p.tau_emi);
+        hipLaunchKernelGGL(k_emi_apply<2>, g, b, 0, c->stream, m, x, kappa, y, c->p.C_phi, c->p.tau_emi);
     HIPCHK(c, hipGetLastError());
     return 0;
 }
@@ -1105,10 +1102,12 @@ static bool knp_halo_usable(const knp_ctx* c, size_t* lds_bytes, bool* with_mate
 }
 
 // which kernel an operator apply runs (bench.py / tests name the kernel they measured): 0 coordinate path, 1 geometry classes +
-// LDS staging, 2 halo-staged persistent (+ 4 when D comes from the material table), 8 matrix-free P2, 9 assembled P2 blocks
+// LDS staging, 2 halo-staged persistent (+ 4 when D comes from the material table), 3 ring-staged (EMI) / 7 ring-staged (KNP,
+// material table), 8 matrix-free P2, 9 assembled P2 blocks
 int apply_variant(knp_ctx* c, int which) {
     if (c->degree != 1) return p2_assembled() ? 9 : 8;
     bool matp = false;
+    if ((which == 0 || which == 1) && ring_usable(c, which)) return which == 1 ? 7 : 3;
     if (which == 1 && knp_halo_usable(c, nullptr, &matp)) return matp ? 6 : 2;
     if (c->m.dim == 3 && c->m.cls && c->m.ncls <= CLS_MAX_LDS && (which == 0 || c->p.n_sys <= 3)) return 1;
     return 0;
@@ -1131,7 +1130,14 @@ template <int D> static int knp_apply_dispatch(knp_ctx* c, const double* x, cons
     size_t lds = 0;
     bool matp = false;
     MeshDev m = c->m;                          // the cell range of this launch (the halo-staged kernel may take only its front part)
-    if (D == 3 && knp_halo_usable(c, &lds, &matp) && m.c_begin < c->m.hb_long0 * KNP_HALO_BLK) {
+    if (D == 3 && ring_usable(c, 1) && m.c_begin < c->m.hb_long0 * KNP_HALO_BLK) {
+        m.c_end = std::min<int64_t>(c->m.c_end, c->m.hb_long0 * KNP_HALO_BLK);
+        const int reserve = (c->dist && c->halo_stream) ? env_int("KNP_HALO_RESERVE_CU", 8) : 0;
+        const int rc = ring_knp_apply(c, m, x, gphi, y, ka, reserve);
+        if (rc || m.c_end >= c->m.c_end) return rc;
+        m.c_begin = m.c_end;
+        m.c_end = c->m.c_end;
+    } else if (D == 3 && knp_halo_usable(c, &lds, &matp) && m.c_begin < c->m.hb_long0 * KNP_HALO_BLK) {
         const unsigned ent = halo_entries(c);
         const dim3 hb(KNP_HALO_BLK);
         int flip_nq = 0;

@@ -155,6 +155,8 @@ template <int D> __device__ __forceinline__ void load_cell_geometry(const MeshDe
 // coordinates): ~85 % of the neighbours of a Morton-ordered block live in the same block and are served
 // from LDS instead of per-lane L1 gathers.
 typedef __attribute__((address_space(3))) double lds_double;   // explicit LDS pointers: ds_read, never flat_load
+typedef __attribute__((address_space(3))) char lds_char;
+typedef __attribute__((address_space(3))) int lds_int;
 #define TO_LDS(p) ((const lds_double*)(p))
 
 template <int D> struct StageView {
@@ -166,6 +168,7 @@ template <int D> struct StageView {
     unsigned nvalid;        // 0 disables staging (setup kernels)
     const double* rec;      // geometry-class record of the cell (MODE 3), else null
     const lds_double* lrec; // the same record in LDS (MODE 4)
+    const lds_double* lext; // derived facet coefficients of the class in LDS (MeshDev::cls_ext), or null
 };
 
 template <int D> __device__ __forceinline__ void lds_nodal(const lds_double* base, unsigned idx, double* v) {

@@ -40,6 +40,7 @@ struct MeshDev {
     int32_t* mf = nullptr;         // [nmf][6]: cell_e, cell_i, lf_e, lf_i, facet, owner flag
     uint16_t* cls = nullptr;       // [nc] geometry class of every cell (structured meshes), or null
     double* cls_table = nullptr;   // [ncls][KNP_CLS_STRIDE]
+    double* cls_ext = nullptr;     // [ncls][KNP_CLS_EXT]: per facet 8 derived coefficients (abi.hip: knp_set_geometry_classes), read by the halo-staged KNP apply
     int ncls = 0;
     // per-256-cell-block neighbour tables of the halo-staged applies (3D P1; blocks are aligned at multiples of 256 from cell 0)
     int32_t* hb_src = nullptr;     // [nblk][hb_stride]: 4 * neighbour cell + its local facet, one entry per coupled facet whose neighbour lies
@@ -49,6 +50,7 @@ struct MeshDev {
     int64_t hb_long0 = 0;          // first block whose list is longer than one entry per thread (cut cells of a partition), else the block count
 };
 #define KNP_CLS_STRIDE 36
+#define KNP_CLS_EXT 32
 #define KNP_HALO_BLK 256
 #define KNP_MAX_MAT 16
 
@@ -154,6 +156,17 @@ struct knp_ctx {
         }                                                                        \
     } while (0)
 
+// scalars of the KNP operator, by value into the apply kernels
+struct KnpArgs {
+    int ns;
+    double inv_dt, psi, tau;
+    double z[KNP_MAX_SYS];
+};
+// closed-form P1 facet integrals: mass / triple-product entries of a (D-1)-simplex
+template <int D> struct FacetConst;
+template <> struct FacetConst<3> { static constexpr double mass = 1.0 / 12.0, trip = 1.0 / 60.0; };
+template <> struct FacetConst<2> { static constexpr double mass = 1.0 / 6.0, trip = 1.0 / 24.0; };
+
 // ---- launchers implemented in the .hip files --------------------------------------------
 int launch_emi_apply(knp_ctx* c, const double* x, const double* kappa, double* y);
 int launch_knp_apply(knp_ctx* c, const double* x, const double* dnphi, double* y);
@@ -183,6 +196,11 @@ int tab_step_updates(knp_ctx* c, const double* cc, double* celim, const double* 
 int tab_facet_trace(knp_ctx* c, const double* nodal, int side, double* out);
 void tab_free(knp_ctx* c);
 bool p2_assembled();                 // KNP_P2_ASSEMBLED=1: round-1 path (quadrature-assembled cell blocks) instead of the matrix-free applies
+
+// ring-staged P1 applies on structured 3D meshes (apply_ring.hip): loader wave + LDS-DMA ring + consumer waves
+bool ring_usable(const knp_ctx* c, int which);       // which: 0 EMI, 1 KNP
+int ring_emi_apply(knp_ctx* c, const MeshDev& m, const double* x, const double* kappa, double* y);
+int ring_knp_apply(knp_ctx* c, const MeshDev& m, const double* x, const double* gphi, double* y, const KnpArgs& ka, int reserve_cus);
 
 // matrix-free DG-P2 applies (apply_p2.hip)
 int p2_emi_apply(knp_ctx* c, const double* x, const double* kappa, double* y);

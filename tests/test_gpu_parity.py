@@ -85,12 +85,16 @@ def test_knp_apply(case):
         assert relerr(y[k], Ak @ x[k].ravel()) < TOL
 
 
-@pytest.mark.parametrize("env,variant", [({}, 6), ({"KNP_APPLY_MAT": "0"}, 2), ({"KNP_HALO_DYN": "0"}, 6), ({"KNP_HALO_NQ": "64"}, 6),
-                                         ({"KNP_HALO_WG_PER_CU": "1"}, 6), ({"KNP_APPLY_HALO": "0"}, 1)])
+_NORING = {"KNP_APPLY_RING": "0"}
+
+
+@pytest.mark.parametrize("env,variant", [({}, 7), (_NORING, 6), ({"KNP_APPLY_MAT": "0"}, 2), (dict(_NORING, KNP_HALO_DYN="0"), 6),
+                                         (dict(_NORING, KNP_HALO_NQ="64"), 6), (dict(_NORING, KNP_HALO_WG_PER_CU="1"), 6),
+                                         ({"KNP_APPLY_HALO": "0"}, 1)])
 def test_knp_apply_kernel_variants(hip_lib, monkeypatch, env, variant):
-    """Every selectable KNP apply kernel of the structured 3D P1 path against the oracle matrix: halo-staged persistent kernel with the
-    material table (default), with per-cell D, with strided instead of drawn blocks, other queue counts / one workgroup per CU
-    (many blocks per workgroup), and the LDS-staged kernel of round 1."""
+    """Every selectable KNP apply kernel of the structured 3D P1 path against the oracle matrix: the ring-staged kernel (loader wave +
+    LDS-DMA ring, default), the halo-staged persistent kernel with the material table, with per-cell D, with strided instead of drawn
+    blocks, other queue counts / one workgroup per CU (many blocks per workgroup), and the LDS-staged kernel of round 1."""
     from knpemidg import _abi as A
     pb = _problems()["3D_4axon_r0"]
     x = synthetic_state(pb)
@@ -110,10 +114,33 @@ def test_knp_apply_kernel_variants(hip_lib, monkeypatch, env, variant):
         dev.close()
 
 
-@pytest.mark.parametrize("names,variant", [(("K", "Cl"), 6), (("K", "Cl", "Na", "Ca"), 1)])
+@pytest.mark.parametrize("env,evariant", [({}, 3), ({"KNP_EMI_RING": "0"}, 1)])
+@pytest.mark.parametrize("which", ["3D_4axon_r0", "3D_1axon_r0"])
+def test_emi_apply_kernel_variants(hip_lib, monkeypatch, env, evariant, which):
+    """Both EMI apply kernels of the structured 3D P1 path (ring-staged: default; LDS-staged thread-per-cell kernel) against the
+    oracle matrix, on meshes with membrane facets of one and of four cells."""
+    from knpemidg import _abi as A
+    pb = _problems()[which]
+    x = synthetic_state(pb)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    dev = device_for(pb)
+    try:
+        push_state(dev, pb)
+        assert dev.apply_variant(0) == evariant
+        dev.update_kappa()
+        dev.upload(A.F_X, x[0])
+        dev.emi_apply(A.F_X, A.F_Y)
+        Aemi, _, _ = ko.assemble_emi(pb, want_B=False)
+        assert relerr(dev.download(A.F_Y, 0, pb.ndof), Aemi @ x[0].ravel()) < TOL
+    finally:
+        dev.close()
+
+
+@pytest.mark.parametrize("names,variant", [(("K", "Cl"), 7), (("K", "Cl", "Na", "Ca"), 1)])
 def test_knp_apply_with_one_and_three_solved_species(hip_lib, names, variant):
-    """Species counts other than the reference's two solved ions: ONE solved species runs the halo-staged kernel's NS = 1 instance,
-    THREE run the LDS-staged kernel (the halo-staged one carries at most two); same operators as the oracle's."""
+    """Species counts other than the reference's two solved ions: ONE solved species runs the ring-staged kernel's NS = 1 instance,
+    THREE run the LDS-staged kernel (the ring- and halo-staged ones carry at most two); same operators as the oracle's."""
     from knpemidg import _abi as A
     from knpemidg.mesh import make_mesh_3D
     m, s, f = make_mesh_3D(0)

@@ -33,7 +33,7 @@ def _mesh(which):
 
 def _expected_halo_tables(nbr_d, nloc_d, kind_d, nc_owned, B=256):
     """Layout contract of KNP_DT_HB_SRC / KNP_DT_HB_LOC (include/knpemi_hip.h), restated: per block of B consecutive device cells
-    the SIPG neighbours outside the block in (cell, facet) order."""
+    the coupled (SIPG or membrane) neighbours outside the block in (cell, facet) order."""
     nblk = (nc_owned + B - 1) // B
     loc = np.zeros((nc_owned, 4), dtype=np.uint16)
     lists = [[] for _ in range(nblk)]
@@ -41,7 +41,7 @@ def _expected_halo_tables(nbr_d, nloc_d, kind_d, nc_owned, B=256):
         b = k // B
         for a in range(4):
             n = nbr_d[k, a]
-            if kind_d[k, a] != oc.K_SIPG or n < 0:
+            if kind_d[k, a] not in (oc.K_SIPG, oc.K_MEMBRANE) or n < 0:
                 continue
             if n // B == b:
                 loc[k, a] = n - b * B
