@@ -265,6 +265,20 @@ def main():
     else:
         emi_name = "k_emi_apply_p2<3,256,%s>" % ("true" if cls else "false")
         knp_name = "k_knp_apply_p2<3,256,%s>" % ("true" if cls else "false")
+    # FP64 vector instructions per cell of the two apply kernels (static counts from the gfx950 ISA, loops fully unrolled: DESIGN.md
+    # sections 4.0 / 4b) against the chip's FP64 issue peak, 256 CUs x 4 SIMDs x 16 lanes per cycle at 2.4 GHz: the second roofline
+    # of these kernels (the P2 applies are bound by it, the P1 ring-staged applies sit between it and the HBM one)
+    fp64_per_cell = {"k_emi_apply_ring": 542, "k_knp_apply_ring<2>": 476, "k_emi_apply_p2<3,256,true>": 2755,
+                     "k_knp_apply_p2<3,256,true>": 2 * 2304}
+    FP64_PEAK_TINST = 256 * 4 * 16 * 2.4e9 / 1e12
+
+    def fp64_issue(name, ms):
+        n = fp64_per_cell.get(name)
+        if n is None:
+            return None
+        ach = n * nc_local / (ms * 1e-3) / 1e12
+        return {"fp64_instructions_per_cell": n, "achieved": ach, "peak": FP64_PEAK_TINST, "unit": "T lane-instructions/s",
+                "frac": ach / FP64_PEAK_TINST}
     traffic = traffic_emi = None
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
@@ -304,9 +318,11 @@ def main():
                          "frac": knp_gbs / HBM_PEAK_GBS, "traffic": traffic, "avg_kernel_us": knp_ms * 1e3,
                          "algorithmic_bytes_per_cell": knp_bpc, "cells_per_launch": nc_local,
                          "in_solver_us": knp_solver_ms * 1e3, "in_solver_launches": knp_n, "back_to_back_us": knp_b2b_ms * 1e3,
+                         "fp64_issue": fp64_issue(knp_name, knp_ms),
                          "emi_apply": {"kernel": emi_name, "achieved": emi_gbs, "frac": emi_gbs / HBM_PEAK_GBS, "traffic": traffic_emi,
                                        "avg_kernel_us": emi_ms * 1e3, "algorithmic_bytes_per_cell": emi_bpc,
                                        "in_solver_us": emi_solver_ms * 1e3, "in_solver_launches": emi_n,
+                                       "fp64_issue": fp64_issue(emi_name, emi_ms),
                                        "back_to_back_us": emi_b2b_ms * 1e3}},
         }
         if not args.no_cpu_baseline and world == 1:

@@ -168,6 +168,11 @@ int knp_knp_rhs(knp_ctx* ctx);             /* B_KNP <- L_knp(C, C_PREV, C_ELIM, 
 int knp_emi_residual_target(knp_ctx* ctx, double r_abs);
 int knp_emi_solve(knp_ctx* ctx, double rtol, double atol, int maxit, int check_every, int* niter, double* res);
 int knp_knp_solve(knp_ctx* ctx, double rtol, double atol, int maxit, int min_it, int check_every, int* niter, double* res);
+/* Krylov method of knp_knp_solve: 0 = BiCGStab (default: 4 operator applies and no stored basis per iteration), 1 = right-preconditioned
+ * restarted GMRES(restart), restart in 2..30 -- the reference's KSP type and restart length (ksp_type gmres, ksp_gmres_restart 30,
+ * src/knpemidg/solver.py:684-701); same preconditioner and the same stopping test on the true residual either way.  niter of a GMRES
+ * solve counts Arnoldi steps (= preconditioner applications). */
+int knp_set_knp_krylov(knp_ctx* ctx, int method, int restart);
 
 /* ---- auxiliary-space AMG preconditioner (stands in for pc_type hypre, solver.py:433, 688) ---------------
  * M^-1 = cell-block-Jacobi + P Ac^+ P^T with Ac the conforming (membrane-broken) P1 operator; the hierarchy is

@@ -296,7 +296,7 @@ int knp_ctx_create(knp_ctx** out, int device, int dim, int degree, int n_ions, i
     rc |= dev_zeros(c, &c->rho, nc);
     c->partial_blocks = grid_for(nc_owned) + 8;
     rc |= dev_zeros(c, &c->partial, (size_t)c->partial_blocks * KNP_MAX_SYS * KNP_MAX_RED);
-    rc |= dev_zeros(c, &c->scal, KNP_MAX_SYS * KS_N + KNP_MAX_SYS * KNP_MAX_RED);
+    rc |= dev_zeros(c, &c->scal, KNP_GM_OFFSET + KNP_MAX_SYS * KNP_GM_STRIDE);        // Krylov scalars, reduction results, GMRES state
     if (!rc && hipMalloc((void**)&c->status, sizeof(int) * KNP_STATUS_WORDS) != hipSuccess) rc = -2;
     if (!rc) hipMemset(c->status, 0, sizeof(int) * KNP_STATUS_WORDS);
     if (!rc && hipHostMalloc(&c->pinned, 4096) != hipSuccess) rc = -2;
@@ -329,7 +329,7 @@ void knp_ctx_destroy(knp_ctx* c) {
     hipFree(c->m.hb_src); hipFree(c->m.hb_loc);
     hipFree(c->m.cls); hipFree(c->m.cls_table); hipFree(c->m.cls_ext); hipFree(c->m.coords); hipFree(c->m.h); hipFree(c->m.cells); hipFree(c->m.nbr); hipFree(c->m.fflag); hipFree(c->m.cfacet); hipFree(c->m.mf);
     hipFree(c->mat); hipFree(c->nmat4); hipFree(c->dtab); hipFree(c->halo_ctr);
-    hipFree(c->D); hipFree(c->rho); hipFree(c->fsrc); hipFree(c->mms_C); hipFree(c->extra_emi); hipFree(c->extra_knp); hipFree(c->partial); hipFree(c->scal); hipFree(c->status);
+    hipFree(c->D); hipFree(c->rho); hipFree(c->fsrc); hipFree(c->mms_C); hipFree(c->extra_emi); hipFree(c->extra_knp); hipFree(c->partial); hipFree(c->scal); hipFree(c->status); hipFree(c->gm_V);
     hipFree(c->halo_send_idx); hipFree(c->halo_sendbuf);
     if (c->pinned) hipHostFree(c->pinned);
     if (c->ev0) hipEventDestroy(c->ev0);
@@ -836,10 +836,30 @@ int knp_knp_solve(knp_ctx* c, double rtol, double atol, int maxit, int min_it, i
         }
         kv.bj_lmax = f->bj_lmax_knp;
     }
-    rc = bicgstab_solve(c, kv, rtol, atol, maxit, min_it, check_every, niter, res);
+    if (c->knp_krylov == 1) {
+        const int m = std::min(std::max(c->gm_restart, 2), KNP_GM_MAX);
+        if (c->gm_alloc < m + 1) {
+            hipFree(c->gm_V); c->gm_V = nullptr; c->gm_alloc = 0;
+            HIPCHK(c, hipMalloc((void**)&c->gm_V, sizeof(double) * (size_t)(m + 1) * f->n[KNP_F_C]));
+            c->gm_alloc = m + 1;
+        }
+        kv.gm_V = c->gm_V; kv.gm_m = m;
+        rc = gmres_solve(c, kv, rtol, atol, maxit, min_it, check_every, niter, res);
+    } else {
+        rc = bicgstab_solve(c, kv, rtol, atol, maxit, min_it, check_every, niter, res);
+    }
     if (rc) return rc;
     if (f->it_ref_knp < 0) f->it_ref_knp = c->last_it_knp;
     if (c->dist) return halo_exchange(c, kv.x, c->p.n_sys);   // ghostUpdate (solver.py:789)
+    return 0;
+}
+
+int knp_set_knp_krylov(knp_ctx* c, int method, int restart) {
+    if (!c) return -1;
+    if (method != 0 && method != 1) { c->err = "knp_set_knp_krylov: method 0 (BiCGStab) or 1 (GMRES)"; return -1; }
+    if (method == 1 && (restart < 2 || restart > KNP_GM_MAX)) { c->err = "knp_set_knp_krylov: restart length 2.." + std::to_string(KNP_GM_MAX); return -1; }
+    c->knp_krylov = method;
+    if (method == 1) c->gm_restart = restart;
     return 0;
 }
 

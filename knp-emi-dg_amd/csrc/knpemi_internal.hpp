@@ -120,6 +120,10 @@ struct knp_ctx {
     int* status = nullptr;         // device: per system {converged flag, iterations}, then the ODE failure flag
     void* pinned = nullptr;        // host pinned mirror for status/scalars
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int knp_krylov = 0;            // KNP Krylov method: 0 BiCGStab (default), 1 restarted GMRES (knp_set_knp_krylov)
+    int gm_restart = 30;
+    double* gm_V = nullptr;        // GMRES basis, allocated at the first GMRES solve
+    int gm_alloc = 0;              // basis vectors allocated
     int last_it_emi = 0, last_it_knp = 0;   // iteration counts of the previous solves (chunking of the status polls)
     float last_peclet = -1.0f;              // cell Peclet number of the drift seen by the last status poll (< 0: not read yet)
     // auxiliary-space AMG hierarchies: [0] EMI, [1 + k] KNP species k

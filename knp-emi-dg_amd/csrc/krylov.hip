@@ -129,9 +129,12 @@ template <int NV> __device__ __forceinline__ const bjreal* bj_block(const VecDim
 
 // ---- second-stage reduction + scalar recurrences ------------------------------------------
 // op codes
-enum { OP_CG_INIT = 1, OP_CG_ALPHA, OP_CG_BETA, OP_BI_INIT, OP_BI_ALPHA, OP_BI_OMEGA, OP_BI_RHO, OP_SUM_ONLY };
+enum { OP_CG_INIT = 1, OP_CG_ALPHA, OP_CG_BETA, OP_BI_INIT, OP_BI_ALPHA, OP_BI_OMEGA, OP_BI_RHO, OP_SUM_ONLY,
+       OP_GM_INIT, OP_GM_RESTART, OP_GM_H, OP_GM_NORM, OP_GM_SOLVE };
+// status word of a system: 0 iterating, 1 converged, 2 breakdown, 3 NaN, 4 (GMRES) this restart cycle is complete, waiting for the update
 
-__device__ void scalar_op(int op, double* S, const double* R, int* flag, int* iter, double rtol, double atol, int min_it, double rabs, int norm8);
+__device__ void scalar_op(int op, double* S, const double* R, int* flag, int* iter, double rtol, double atol, int min_it, double rabs, int norm8,
+                          double* gm = nullptr, int aux = 0);
 
 // op > 0: the block's thread 0 also runs the scalar recurrence of its system (single-GPU: saves one launch per reduction
 // point; with a communicator the all-reduce sits between the two and k_scalar_op runs separately).
@@ -140,7 +143,8 @@ __device__ void scalar_op(int op, double* S, const double* R, int* flag, int* it
 #define KNP_REDUCE_BLOCK 1024
 template <int NR, int UR = 4>
 __global__ __launch_bounds__(KNP_REDUCE_BLOCK) void k_reduce(const double* __restrict__ partial, int64_t nblocks, int nsys, double* red, int op,
-                                                             double* scal, int* status, double rtol, double atol, int min_it, double rabs, int norm8) {
+                                                             double* scal, int* status, double rtol, double atol, int min_it, double rabs, int norm8,
+                                                             int aux) {
     // one block per system; deterministic order
     const int s = blockIdx.x;
     __shared__ double lds[KNP_REDUCE_BLOCK / 64][NR];
@@ -188,12 +192,99 @@ __global__ __launch_bounds__(KNP_REDUCE_BLOCK) void k_reduce(const double* __res
             red[s * KNP_MAX_RED + r] = v;
         }
         if (op > 0) {
-            scalar_op(op, S, R, &flag, &iter, rtol, atol, min_it, rabs, norm8);
+            scalar_op(op, S, R, &flag, &iter, rtol, atol, min_it, rabs, norm8, scal + KNP_GM_OFFSET + s * KNP_GM_STRIDE, aux);
 #pragma unroll
             for (int i = 0; i < KS_N; ++i) scal[s * KS_N + i] = S[i];
             status[2 * s] = flag;
             status[2 * s + 1] = iter;
         }
+    }
+}
+
+// ---- GMRES scalar work (one system): Hessenberg column, Givens rotations, least-squares right-hand side ------------------------------
+// gm: H[(m + 1) * m] column-major | cs[m] | sn[m] | g[m + 1] | y[m];  m = KNP_GM_MAX.  S[KS_GM_K] = columns of this cycle,
+// S[KS_GM_T2] = 2-norm the Arnoldi residual estimate has to reach before the true residual is looked at again, S[KS_ALPHA] = 1 / beta
+// and S[KS_OMEGA] = 1 / h_{j+1,j} (the scalings of the next basis vector), S[KS_RHO] = the current estimate.
+__device__ __forceinline__ void gm_new_cycle(double* S, const double* R, double* gm, int norm8) {
+    constexpr int M = KNP_GM_MAX;
+    const double beta = sqrt(R[0]);
+    S[KS_BETA] = beta;
+    S[KS_ALPHA] = beta > 0.0 ? 1.0 / beta : 0.0;
+    gm[(M + 1) * M + 2 * M] = beta;                       // g[0]
+    S[KS_GM_K] = 0.0;
+    // the stopping test is on the order-8 density norm (or the weighted 2-norm) of the true residual; the Arnoldi estimate is its plain
+    // 2-norm.  Ask the cycle for the reduction the test still needs (with a margin), then test the true residual and, if it is not
+    // there yet, start the next cycle from it.
+    const double need = S[KS_RES] > 0.0 ? S[KS_TOL] / S[KS_RES] : 1.0;
+    S[KS_GM_T2] = beta * fmin(0.5 * need, 0.1);
+    S[KS_RHO] = beta;
+}
+
+__device__ void gm_scalar_op(int op, double* S, const double* R, int* flag, int* iter, double rtol, double atol, int min_it, int norm8,
+                             double* gm, int aux) {
+    constexpr int M = KNP_GM_MAX;
+    double* H = gm;
+    double* cs = gm + (M + 1) * M;
+    double* sn = cs + M;
+    double* g = sn + M;
+    double* y = g + M + 1;
+    switch (op) {
+        case OP_GM_INIT:                 // R: r.r, ||r||_w^2 | ||r/vol||_8^8, ||b||_w^2 | ||b/vol||_8^8  (k_bi_init)
+        case OP_GM_RESTART: {
+            if (op == OP_GM_RESTART && (*flag == 1 || *flag == 2 || *flag == 3)) return;
+            const double rn = norm8 ? pow(R[1], 0.125) : sqrt(R[1]);
+            if (op == OP_GM_INIT) {
+                S[KS_RES0] = rn;
+                S[KS_BNORM] = norm8 ? pow(R[2], 0.125) : sqrt(R[2]);
+                S[KS_TOL] = fmax(rtol * S[KS_BNORM], atol);
+                *iter = 0;
+            }
+            S[KS_RES] = rn;
+            if (!(rn == rn)) { *flag = 3; return; }
+            if (R[0] == 0.0 || (rn <= S[KS_TOL] && *iter >= min_it)) { *flag = 1; return; }
+            *flag = 0;
+            gm_new_cycle(S, R, gm, norm8);
+        } break;
+        case OP_GM_H: {                  // R[0 .. cnt): w . V_{j0 + i};  aux = j0 | j << 8 | cnt << 16
+            if (*flag) return;
+            const int j0 = aux & 0xff, j = (aux >> 8) & 0xff, cnt = (aux >> 16) & 0xff;
+            for (int i = 0; i < cnt; ++i) H[j0 + i + (M + 1) * j] = R[i];
+        } break;
+        case OP_GM_NORM: {               // R[0] = ||w - sum_i h_ij V_i||^2;  aux = j | cycle length m << 8
+            if (*flag) return;
+            const int j = aux & 0xff, m = (aux >> 8) & 0xff;
+            double* h = H + (M + 1) * j;
+            const double hn = sqrt(R[0]);
+            h[j + 1] = hn;
+            for (int i = 0; i < j; ++i) {                        // previous rotations on the new column
+                const double t = cs[i] * h[i] + sn[i] * h[i + 1];
+                h[i + 1] = -sn[i] * h[i] + cs[i] * h[i + 1];
+                h[i] = t;
+            }
+            const double den = sqrt(h[j] * h[j] + hn * hn);
+            cs[j] = den > 0.0 ? h[j] / den : 1.0;
+            sn[j] = den > 0.0 ? hn / den : 0.0;
+            h[j] = den;
+            g[j + 1] = -sn[j] * g[j];
+            g[j] = cs[j] * g[j];
+            S[KS_OMEGA] = hn > 0.0 ? 1.0 / hn : 0.0;
+            S[KS_GM_K] = (double)(j + 1);
+            S[KS_RHO] = fabs(g[j + 1]);
+            *iter += 1;
+            if (!(den == den)) { *flag = 3; return; }
+            if (((S[KS_RHO] <= S[KS_GM_T2] || hn == 0.0) && *iter >= min_it) || j + 1 >= m) *flag = 4;     // cycle complete
+        } break;
+        case OP_GM_SOLVE: {              // back substitution of the cycle's k columns; the system takes part in the update (flag 4 -> 0)
+            if (*flag != 0 && *flag != 4) return;
+            const int k = (int)S[KS_GM_K];
+            for (int i = k - 1; i >= 0; --i) {
+                double t = g[i];
+                for (int l = i + 1; l < k; ++l) t -= H[i + (M + 1) * l] * y[l];
+                y[i] = H[i + (M + 1) * i] != 0.0 ? t / H[i + (M + 1) * i] : 0.0;
+            }
+            *flag = 0;
+        } break;
+        default: break;
     }
 }
 
@@ -209,7 +300,9 @@ __device__ __forceinline__ bool cg_converged(const double* S, double rabs) {
 }
 
 // S: the system's KS_N scalars, R: its reduced sums, flag / iter: its two status words (global memory or local copies)
-__device__ void scalar_op(int op, double* S, const double* R, int* flag, int* iter, double rtol, double atol, int min_it, double rabs, int norm8) {
+__device__ void scalar_op(int op, double* S, const double* R, int* flag, int* iter, double rtol, double atol, int min_it, double rabs, int norm8,
+                          double* gm, int aux) {
+    if (op >= OP_GM_INIT) { gm_scalar_op(op, S, R, flag, iter, rtol, atol, min_it, norm8, gm, aux); return; }
     if (op != OP_CG_INIT && op != OP_BI_INIT && *flag) return;
     switch (op) {
         case OP_CG_INIT: {              // R: rz, zz, (Minv b).(Minv b), ||r||_w^2
@@ -269,9 +362,10 @@ __device__ void scalar_op(int op, double* S, const double* R, int* flag, int* it
 }
 
 __global__ void k_scalar_op(int op, int nsys, const double* __restrict__ red, double* __restrict__ scal, int* __restrict__ status,
-                            double rtol, double atol, int min_it, double rabs, int norm8) {
+                            double rtol, double atol, int min_it, double rabs, int norm8, int aux) {
     const int s = threadIdx.x;
-    if (s < nsys) scalar_op(op, scal + s * KS_N, red + s * KNP_MAX_RED, status + 2 * s, status + 2 * s + 1, rtol, atol, min_it, rabs, norm8);
+    if (s < nsys) scalar_op(op, scal + s * KS_N, red + s * KNP_MAX_RED, status + 2 * s, status + 2 * s + 1, rtol, atol, min_it, rabs, norm8,
+                            scal + KNP_GM_OFFSET + s * KNP_GM_STRIDE, aux);
 }
 
 // ---- PCG kernels ----------------------------------------------------------------------------
@@ -664,7 +758,7 @@ int max_abs_diff(knp_ctx* c, const double* a, const double* b, int nsys, double*
 // ---- host drivers ---------------------------------------------------------------------------------
 
 
-static int finalize(knp_ctx* c, int op, int nsys, int nred, double rtol, double atol, int min_it, double rabs = 0.0, int norm8 = 0) {
+static int finalize(knp_ctx* c, int op, int nsys, int nred, double rtol, double atol, int min_it, double rabs = 0.0, int norm8 = 0, int aux = 0) {
     const int64_t nb = grid_for(c->m.nc_owned);
     double* red = c->scal + KNP_MAX_SYS * KS_N;
     const int dop = c->dist ? 0 : op;
@@ -674,22 +768,23 @@ static int finalize(knp_ctx* c, int op, int nsys, int nred, double rtol, double 
 #define KNP_REDUCE(NR_)                                                                                                                  \
     do {                                                                                                                                 \
         if (deep) hipLaunchKernelGGL((k_reduce<NR_, 8>), dim3(nsys), dim3(KNP_REDUCE_BLOCK), 0, c->stream, c->partial, nb, nsys, red, dop,  \
-                                     c->scal, c->status, rtol, atol, min_it, rabs, norm8);                                               \
+                                     c->scal, c->status, rtol, atol, min_it, rabs, norm8, aux);                                          \
         else hipLaunchKernelGGL((k_reduce<NR_, 4>), dim3(nsys), dim3(KNP_REDUCE_BLOCK), 0, c->stream, c->partial, nb, nsys, red, dop,       \
-                                c->scal, c->status, rtol, atol, min_it, rabs, norm8);                                                    \
+                                c->scal, c->status, rtol, atol, min_it, rabs, norm8, aux);                                               \
     } while (0)
     switch (nred) {
         case 1: KNP_REDUCE(1); break;
         case 2: KNP_REDUCE(2); break;
         case 3: KNP_REDUCE(3); break;
         case 4: KNP_REDUCE(4); break;
+        case 8: KNP_REDUCE(8); break;
         default: c->err = "finalize: unsupported number of partial sums"; return -1;
     }
 #undef KNP_REDUCE
     if (c->dist) {
         int rc = allreduce_red(c, red, nsys * KNP_MAX_RED);
         if (rc) return rc;
-        hipLaunchKernelGGL(k_scalar_op, dim3(1), dim3(64), 0, c->stream, op, nsys, red, c->scal, c->status, rtol, atol, min_it, rabs, norm8);
+        hipLaunchKernelGGL(k_scalar_op, dim3(1), dim3(64), 0, c->stream, op, nsys, red, c->scal, c->status, rtol, atol, min_it, rabs, norm8, aux);
     }
     HIPCHK(c, hipGetLastError());
     return 0;
@@ -996,6 +1091,221 @@ static int bicgstab_impl(knp_ctx* c, KrylovVecs& kv, double rtol, double atol, i
     }
     if (bad) { c->err = "KNP BiCGStab did not converge (status " + std::to_string(bad) + ")"; return -3; }
     return 0;
+}
+
+// ---- restarted GMRES (right preconditioning) ------------------------------------------------------------------------------------
+// The reference solves the KNP system with PETSc GMRES(30) + BoomerAMG (solver.py:684-701, 767-771).  Same preconditioner and same
+// stopping test on the true residual as bicgstab_solve; classical Gram-Schmidt with up to eight inner products per pass over w.
+// Systems (species) run in lockstep; a system whose cycle is complete (status 4) idles until the others are, then all of them
+// update x, look at their true residual and either stop or start the next cycle from it.
+
+// v *= scal[slot] (the normalisation of the next basis vector)
+template <int NV>
+__global__ __launch_bounds__(KNP_BLOCK) void k_gm_scale(VecDims d, const int* __restrict__ status, const double* __restrict__ scal, int slot,
+                                                        double* __restrict__ v) {
+    const int s = blockIdx.y;
+    if (status[2 * s]) return;
+    const double a = scal[s * KS_N + slot];
+    const int64_t c = (int64_t)blockIdx.x * KNP_BLOCK + threadIdx.x;
+    if (c >= d.nc_owned) return;
+    double vv[NV];
+    ldv<NV>(SYS_PTR(v, s), c, vv);
+#pragma unroll
+    for (int a_ = 0; a_ < NV; ++a_) vv[a_] *= a;
+    stv<NV>(SYS_PTR(v, s), c, vv);
+}
+
+// y = Binv v
+template <int NV>
+__global__ __launch_bounds__(KNP_BLOCK) void k_gm_binv(VecDims d, const int* __restrict__ status, const bjreal* __restrict__ binv,
+                                                       const double* __restrict__ v, double* __restrict__ y) {
+    const int s = blockIdx.y;
+    if (status[2 * s]) return;
+    const int64_t c = (int64_t)blockIdx.x * KNP_BLOCK + threadIdx.x;
+    if (c >= d.nc_owned) return;
+    double vv[NV], yv[NV];
+    ldv<NV>(SYS_PTR(v, s), c, vv);
+    block_matvec<NV>(bj_block<NV>(d, binv, s, c), 0, vv, yv);
+    stv<NV>(SYS_PTR(y, s), c, yv);
+}
+
+// partial[r] = w . V_{j0 + r}, r < cnt <= 8 (the rest zero)
+template <int NV>
+__global__ __launch_bounds__(KNP_BLOCK) void k_gm_dots(VecDims d, const int* __restrict__ status, const double* __restrict__ w,
+                                                       const double* __restrict__ V, int64_t vstride, int j0, int cnt,
+                                                       double* __restrict__ partial) {
+    const int s = blockIdx.y;
+    const int64_t c = (int64_t)blockIdx.x * KNP_BLOCK + threadIdx.x;
+    double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (!status[2 * s] && c < d.nc_owned) {
+        double wv[NV], vv[NV];
+        ldv<NV>(SYS_PTR(w, s), c, wv);
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+            if (r < cnt) {
+                ldv<NV>(SYS_PTR(V + (int64_t)(j0 + r) * vstride, s), c, vv);
+                double t = 0.0;
+#pragma unroll
+                for (int a = 0; a < NV; ++a) t += wv[a] * vv[a];
+                acc[r] = t;
+            }
+    }
+    write_partials<8>(partial, d.nsys, acc);
+}
+
+// w -= sum_{i <= j} H[i, j] V_i ;  partial[0] = ||w||^2
+template <int NV>
+__global__ __launch_bounds__(KNP_BLOCK) void k_gm_update(VecDims d, const int* __restrict__ status, const double* __restrict__ scal,
+                                                         double* __restrict__ w, const double* __restrict__ V, int64_t vstride, int j,
+                                                         double* __restrict__ partial) {
+    const int s = blockIdx.y;
+    const int64_t c = (int64_t)blockIdx.x * KNP_BLOCK + threadIdx.x;
+    double acc[1] = {0.0};
+    if (!status[2 * s] && c < d.nc_owned) {
+        const double* h = scal + KNP_GM_OFFSET + (int64_t)s * KNP_GM_STRIDE + (int64_t)(KNP_GM_MAX + 1) * j;
+        double wv[NV], vv[NV];
+        ldv<NV>(SYS_PTR(w, s), c, wv);
+        for (int i = 0; i <= j; ++i) {
+            const double hi = h[i];
+            ldv<NV>(SYS_PTR(V + (int64_t)i * vstride, s), c, vv);
+#pragma unroll
+            for (int a = 0; a < NV; ++a) wv[a] -= hi * vv[a];
+        }
+#pragma unroll
+        for (int a = 0; a < NV; ++a) acc[0] += wv[a] * wv[a];
+        stv<NV>(SYS_PTR(w, s), c, wv);
+    }
+    write_partials<1>(partial, d.nsys, acc);
+}
+
+// u = sum_{i < k} y_i V_i  (k = the system's column count)
+template <int NV>
+__global__ __launch_bounds__(KNP_BLOCK) void k_gm_lincomb(VecDims d, const int* __restrict__ status, const double* __restrict__ scal,
+                                                          const double* __restrict__ V, int64_t vstride, double* __restrict__ u) {
+    const int s = blockIdx.y;
+    if (status[2 * s]) return;
+    const int64_t c = (int64_t)blockIdx.x * KNP_BLOCK + threadIdx.x;
+    if (c >= d.nc_owned) return;
+    const int k = (int)scal[s * KS_N + KS_GM_K];
+    const double* y = scal + KNP_GM_OFFSET + (int64_t)s * KNP_GM_STRIDE + (KNP_GM_MAX + 1) * KNP_GM_MAX + 3 * KNP_GM_MAX + 1;
+    double uv[NV], vv[NV];
+#pragma unroll
+    for (int a = 0; a < NV; ++a) uv[a] = 0.0;
+    for (int i = 0; i < k; ++i) {
+        const double yi = y[i];
+        ldv<NV>(SYS_PTR(V + (int64_t)i * vstride, s), c, vv);
+#pragma unroll
+        for (int a = 0; a < NV; ++a) uv[a] += yi * vv[a];
+    }
+    stv<NV>(SYS_PTR(u, s), c, uv);
+}
+
+// x += z
+template <int NV>
+__global__ __launch_bounds__(KNP_BLOCK) void k_gm_xpy(VecDims d, const int* __restrict__ status, const double* __restrict__ z,
+                                                      double* __restrict__ x) {
+    const int s = blockIdx.y;
+    if (status[2 * s]) return;
+    const int64_t c = (int64_t)blockIdx.x * KNP_BLOCK + threadIdx.x;
+    if (c >= d.nc_owned) return;
+    double zv[NV], xv[NV];
+    ldv<NV>(SYS_PTR(z, s), c, zv);
+    ldv<NV>(SYS_PTR(x, s), c, xv);
+#pragma unroll
+    for (int a = 0; a < NV; ++a) xv[a] += zv[a];
+    stv<NV>(SYS_PTR(x, s), c, xv);
+}
+
+template <int NV>
+static int gmres_impl(knp_ctx* c, KrylovVecs& kv, double rtol, double atol, int maxit, int min_it, int check_every, int* niter, double* res) {
+    const int ns = c->p.n_sys, m = kv.gm_m;
+    VecDims d{c->m.nc_owned, c->m.nc, ns, kv.bj_idx, kv.bj_tab, kv.ivol, (kv.d8 && kv.ivol) ? 1 : 0};
+    const dim3 g((unsigned)grid_for(c->m.nc_owned), (unsigned)ns), b(KNP_BLOCK);
+    const int64_t vstride = (int64_t)ns * c->m.nc * NV;
+    double* V = kv.gm_V;
+    int rc;
+    const bool hyb = kv.bj_lmax > 0.0 && knp_hybrid();
+    const double ct = hyb ? 1.0 / bj_theta<false>(kv) : 0.0;
+    // out = M^-1 in : cell-block-Jacobi (two-step Chebyshev) + auxiliary-space coarse correction, as in bicgstab_impl
+    auto precond = [&](const double* in, double* out) -> int {
+        hipLaunchKernelGGL(k_gm_binv<NV>, g, b, 0, c->stream, d, (const int*)c->status, kv.binv, in, out);
+        int r;
+        if (kv.bj_lmax > 0.0 && (r = bj_cheb2<NV, false>(c, d, kv, in, out))) return r;
+        return knp_coarse_correction<NV>(c, d, in, out, hyb ? kv.tmp : nullptr, ct);
+    };
+    // r = b - A x into V_0 (unnormalised), norms of the true residual -> convergence test / next cycle
+    auto residual = [&](int op) -> int {
+        int r;
+        if ((r = dist_apply(c, 1, kv.x, kv.coef, kv.w))) return r;
+        hipLaunchKernelGGL(k_bi_init<NV>, g, b, 0, c->stream, d, kv.b, kv.w, V, kv.rhat, kv.p, kv.v, c->partial);
+        return finalize(c, op, ns, 3, rtol, atol, min_it, 0.0, d.d8);
+    };
+    if ((rc = residual(OP_GM_INIT))) return rc;
+    int hs[2 * KNP_MAX_SYS];
+    auto any_running = [&]() { for (int s = 0; s < ns; ++s) if (hs[2 * s] == 0) return true; return false; };
+    auto all_done = [&]() { for (int s = 0; s < ns; ++s) if (hs[2 * s] == 0 || hs[2 * s] == 4) return false; return true; };
+    if ((rc = poll_status(c, ns, hs))) return rc;
+    int it = 0;
+    while (!all_done() && it < maxit) {
+        // one restart cycle
+        hipLaunchKernelGGL(k_gm_scale<NV>, g, b, 0, c->stream, d, (const int*)c->status, (const double*)c->scal, (int)KS_ALPHA, V);
+        int j = 0;
+        while (j < m && any_running() && it < maxit) {
+            int chunk = next_chunk(it, maxit, check_every, c->last_it_knp);
+            if (chunk > m - j) chunk = m - j;
+            for (int k = 0; k < chunk; ++k, ++j) {
+                double* w = V + (int64_t)(j + 1) * vstride;
+                if ((rc = precond(V + (int64_t)j * vstride, kv.y))) return rc;
+                if ((rc = dist_apply(c, 1, kv.y, kv.coef, w))) return rc;
+                for (int j0 = 0; j0 <= j; j0 += 8) {
+                    const int cnt = std::min(8, j + 1 - j0);
+                    hipLaunchKernelGGL(k_gm_dots<NV>, g, b, 0, c->stream, d, (const int*)c->status, (const double*)w, (const double*)V, vstride, j0,
+                                       cnt, c->partial);
+                    if ((rc = finalize(c, OP_GM_H, ns, 8, rtol, atol, min_it, 0.0, 0, j0 | (j << 8) | (cnt << 16)))) return rc;
+                }
+                hipLaunchKernelGGL(k_gm_update<NV>, g, b, 0, c->stream, d, (const int*)c->status, (const double*)c->scal, w, (const double*)V,
+                                   vstride, j, c->partial);
+                if ((rc = finalize(c, OP_GM_NORM, ns, 1, rtol, atol, min_it, 0.0, 0, j | (m << 8)))) return rc;
+                hipLaunchKernelGGL(k_gm_scale<NV>, g, b, 0, c->stream, d, (const int*)c->status, (const double*)c->scal, (int)KS_OMEGA, w);
+            }
+            it += chunk;
+            if ((rc = poll_status(c, ns, hs))) return rc;
+        }
+        // x += M^-1 (V y) for every system that iterated in this cycle; then its true residual decides
+        hipLaunchKernelGGL(k_scalar_op, dim3(1), dim3(64), 0, c->stream, (int)OP_GM_SOLVE, ns, (const double*)(c->scal + KNP_MAX_SYS * KS_N),
+                           c->scal, c->status, rtol, atol, min_it, 0.0, 0, 0);
+        hipLaunchKernelGGL(k_gm_lincomb<NV>, g, b, 0, c->stream, d, (const int*)c->status, (const double*)c->scal, (const double*)V, vstride, kv.z);
+        if ((rc = precond(kv.z, kv.y))) return rc;
+        hipLaunchKernelGGL(k_gm_xpy<NV>, g, b, 0, c->stream, d, (const int*)c->status, (const double*)kv.y, kv.x);
+        if ((rc = residual(OP_GM_RESTART))) return rc;
+        if ((rc = poll_status(c, ns, hs))) return rc;
+    }
+    double hscal[KNP_MAX_SYS * KS_N];
+    HIPCHK(c, hipMemcpy(hscal, c->scal, sizeof(double) * KS_N * ns, hipMemcpyDeviceToHost));
+    int bad = 0;
+    for (int s = 0; s < ns; ++s) {
+        niter[s] = hs[2 * s + 1];
+        if (s == 0 || niter[s] > c->last_it_knp) c->last_it_knp = niter[s];
+        res[3 * s + 0] = hscal[s * KS_N + KS_RES0];
+        res[3 * s + 1] = hscal[s * KS_N + KS_RES];
+        res[3 * s + 2] = hscal[s * KS_N + KS_BNORM];
+        if (hs[2 * s] != 1) bad = hs[2 * s] ? hs[2 * s] : -1;
+    }
+    if (bad) { c->err = "KNP GMRES did not converge (status " + std::to_string(bad) + ")"; return -3; }
+    return 0;
+}
+
+int gmres_solve(knp_ctx* c, KrylovVecs& kv, double rtol, double atol, int maxit, int min_it, int check_every, int* niter, double* res) {
+    if (check_every < 1) check_every = 1;
+    if (!kv.gm_V || kv.gm_m < 2 || kv.gm_m > KNP_GM_MAX) { c->err = "gmres: no basis storage"; return -1; }
+    switch (c->nd) {
+        case 3: return gmres_impl<3>(c, kv, rtol, atol, maxit, min_it, check_every, niter, res);
+        case 4: return gmres_impl<4>(c, kv, rtol, atol, maxit, min_it, check_every, niter, res);
+        case 6: return gmres_impl<6>(c, kv, rtol, atol, maxit, min_it, check_every, niter, res);
+        case 10: return gmres_impl<10>(c, kv, rtol, atol, maxit, min_it, check_every, niter, res);
+    }
+    c->err = "gmres: unsupported dofs per cell";
+    return -1;
 }
 
 int bicgstab_solve(knp_ctx* c, KrylovVecs& kv, double rtol, double atol, int maxit, int min_it, int check_every, int* niter,

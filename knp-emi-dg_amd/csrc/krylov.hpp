@@ -2,7 +2,13 @@
 #pragma once
 #include "knpemi_internal.hpp"
 
-enum { KS_RHO = 0, KS_RHO_OLD, KS_ALPHA, KS_BETA, KS_OMEGA, KS_RES, KS_RES0, KS_BNORM, KS_TOL, KS_RNORM, KS_N = 12 };   // KS_RNORM: ||b - A x|| in the cell-volume-weighted norm (PCG)
+enum { KS_RHO = 0, KS_RHO_OLD, KS_ALPHA, KS_BETA, KS_OMEGA, KS_RES, KS_RES0, KS_BNORM, KS_TOL, KS_RNORM, KS_GM_T2, KS_GM_K, KS_N = 12 };   // KS_RNORM: ||b - A x|| in the cell-volume-weighted norm (PCG)
+
+// restarted GMRES (gmres_solve): per system the Hessenberg matrix (column-major, leading dimension m + 1), the Givens rotations, the
+// rotated right-hand side g and the solution y of the small least-squares problem live behind the Krylov scalars in knp_ctx::scal
+#define KNP_GM_MAX 30
+#define KNP_GM_STRIDE ((KNP_GM_MAX + 1) * KNP_GM_MAX + 3 * KNP_GM_MAX + KNP_GM_MAX + 1 + 5)
+#define KNP_GM_OFFSET (KNP_MAX_SYS * KS_N + KNP_MAX_SYS * KNP_MAX_RED)      // doubles in front of the GMRES state in knp_ctx::scal
 
 struct KrylovVecs {
     double *x, *b, *coef;                  // unknown, rhs, operator coefficient (kappa | dnphi)
@@ -15,6 +21,8 @@ struct KrylovVecs {
     double bj_lmax = 0.0;                  // > 0: lambda_max(Binv A) estimate -> two-step Chebyshev block-Jacobi
     const float* ivol = nullptr;           // [nc] 1 / cell volume: weights of the residual norms (see krylov.hip: weighted norms)
     bool d8 = false;                       // BiCGStab: stop on the order-8 norms of the residual / load densities (krylov.hip) instead of ||.||_w
+    double* gm_V = nullptr;                // GMRES: Krylov basis [gm_m + 1][nsys][nc*nd]
+    int gm_m = 0;                          // GMRES: restart length (<= KNP_GM_MAX)
     double r_abs = 0.0;                    // PCG: > 0 -> converged when ||b - A x||_w <= r_abs instead of the preconditioned-norm test
 };
 
@@ -22,3 +30,6 @@ int pcg_solve(knp_ctx* c, KrylovVecs& kv, double rtol, double atol, int maxit, i
 int knp_bj_lambda_max(knp_ctx* c, KrylovVecs& kv, int iters, double* out, bool emi = false);
 int bicgstab_solve(knp_ctx* c, KrylovVecs& kv, double rtol, double atol, int maxit, int min_it, int check_every, int* niter,
                    double* res);
+// right-preconditioned restarted GMRES(m) with the same preconditioner and the same stopping test on the true residual as bicgstab_solve
+// (the reference's KNP solver is PETSc GMRES(30), solver.py:684-701)
+int gmres_solve(knp_ctx* c, KrylovVecs& kv, double rtol, double atol, int maxit, int min_it, int check_every, int* niter, double* res);

@@ -52,6 +52,7 @@ SIGNATURES = {
     "knp_emi_residual_target": (C.c_int, [_ctxp, C.c_double]),
     "knp_emi_solve": (C.c_int, [_ctxp, C.c_double, C.c_double, C.c_int, C.c_int, C.POINTER(C.c_int), _f64p]),
     "knp_knp_solve": (C.c_int, [_ctxp, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), _f64p]),
+    "knp_set_knp_krylov": (C.c_int, [_ctxp, C.c_int, C.c_int]),
     "knp_step_updates": (C.c_int, [_ctxp]),
     "knp_nernst": (C.c_int, [_ctxp]),
     "knp_picard_updates": (C.c_int, [_ctxp]),
@@ -439,6 +440,11 @@ class Device:
         rc = self.lib.knp_knp_solve(self.ctx, rtol, atol, maxit, min_it, check_every, it, _p(res, _f64p))
         self._chk(rc, "knp_knp_solve")
         return list(it)[:self.n_sys], res.reshape(self.n_sys, 3)
+
+    def set_knp_krylov(self, method, restart=30):
+        """KNP Krylov method: 'bicgstab' (default) or 'gmres' (restarted, the reference's GMRES(30): solver.py:684-701)."""
+        code = {"bicgstab": 0, "gmres": 1}[method] if isinstance(method, str) else int(method)
+        self._chk(self.lib.knp_set_knp_krylov(self.ctx, code, int(restart)), "knp_set_knp_krylov")
 
     def step_updates(self):
         self._chk(self.lib.knp_step_updates(self.ctx), "knp_step_updates")

@@ -560,6 +560,12 @@ class Solver:
                 ("residual target %.2e x F min|z| ||b_knp||" % self._emi_target) if self._emi_target else "rtol %.2e" % self._rtol_emi,
                 self._rtol_knp))
         self._atol_knp = 1e-40 if self.direct_knp else float(self.atol_knp)
+        # KNP Krylov method: the device default is BiCGStab; `knp_krylov = "gmres"` (+ `gmres_restart`, default 30) in solver_params,
+        # or KNP_KNP_KRYLOV=gmres, selects the reference's restarted GMRES (ksp_type gmres / ksp_gmres_restart 30, solver.py:684-701)
+        meth = getattr(sp, "knp_krylov", None) or os.environ.get("KNP_KNP_KRYLOV", "bicgstab")
+        if self.dev is not None and meth != getattr(self, "_knp_krylov", "bicgstab"):
+            self.dev.set_knp_krylov(meth, int(getattr(sp, "gmres_restart", None) or os.environ.get("KNP_GMRES_RESTART", 30)))
+            self._knp_krylov = meth
 
     def _sync_membrane_to_device(self):
         """phi_M and I_ch_k facet fields produced by the ODE step -> device."""

@@ -68,6 +68,32 @@ def test_knp_solve(case):
     assert all(n >= 5 for n in niter)          # ksp_min_it 5 (solver.py:686)
 
 
+@pytest.mark.parametrize("restart", [30, 8])
+def test_knp_solve_gmres(case, restart):
+    """The reference's KNP Krylov method, restarted GMRES (ksp_type gmres, restart 30: solver.py:684-701), on the device: same
+    preconditioner and stopping test as the default BiCGStab, same converged concentrations as the oracle's direct solve; restart 8
+    forces several restart cycles (solution update, true residual, new cycle)."""
+    pb, dev, A = case
+    ko.solve_emi(pb, direct=True)
+    dev.upload(A.F_PHI, pb.phi)
+    dev.upload(A.F_C, pb.c)
+    dev.update_dnphi()
+    dev.knp_rhs()
+    dev.set_knp_krylov("gmres", restart)
+    try:
+        niter, res = dev.knp_solve(1e-13, maxit=5000)
+    finally:
+        dev.set_knp_krylov("bicgstab")
+    c = dev.download(A.F_C).reshape(pb.c.shape)
+    c0 = pb.c.copy()
+    ref = ko.solve_knp(pb, direct=True)
+    pb.c = c0
+    assert relerr(c, ref) < 1e-9, (niter, res)
+    assert all(n >= 5 for n in niter)
+    with pytest.raises(Exception):
+        dev.set_knp_krylov("gmres", 31)
+
+
 @pytest.mark.parametrize("names,shared", [(("K", "Cl", "X", "Na"), True), (("K", "Cl", "X", "Na"), False), (("K", "Cl"), True)])
 def test_knp_solve_with_other_species_counts(hip_lib, monkeypatch, names, shared):
     """KNP solves with ONE and with THREE solved species through the auxiliary-space preconditioner: three species sharing one

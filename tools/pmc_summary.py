@@ -5,7 +5,7 @@ for row in csv.DictReader(open(sys.argv[1])):
     name = row["Kernel_Name"]
     if "apply" not in name:
         continue
-    acc[name.split("(")[0][:60]][row["Counter_Name"]].append(float(row["Counter_Value"]))
+    acc[name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:60]][row["Counter_Name"]].append(float(row["Counter_Value"]))
 for k, d in acc.items():
     print(k)
     for cn, v in d.items():
