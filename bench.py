@@ -268,7 +268,7 @@ def main():
     # FP64 vector instructions per cell of the two apply kernels (static counts from the gfx950 ISA, loops fully unrolled: DESIGN.md
     # sections 4.0 / 4b) against the chip's FP64 issue peak, 256 CUs x 4 SIMDs x 16 lanes per cycle at 2.4 GHz: the second roofline
     # of these kernels (the P2 applies are bound by it, the P1 ring-staged applies sit between it and the HBM one)
-    fp64_per_cell = {"k_emi_apply_ring": 542, "k_knp_apply_ring<2>": 476, "k_emi_apply_p2<3,256,true>": 2755,
+    fp64_per_cell = {"k_emi_apply_ring": 542, "k_knp_apply_ring<2>": 435, "k_emi_apply_p2<3,256,true>": 2755,
                      "k_knp_apply_p2<3,256,true>": 2 * 2304}
     FP64_PEAK_TINST = 256 * 4 * 16 * 2.4e9 / 1e12
 

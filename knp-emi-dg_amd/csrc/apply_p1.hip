@@ -1071,7 +1071,7 @@ static int emi_apply_impl(knp_ctx* c, const double* x, const double* kappa, doub
     MeshDev m = c->m;                          // the cell range of this launch (the ring-staged kernel may take only its front part)
     if (ring_usable(c, 0) && m.c_begin < c->m.hb_long0 * KNP_HALO_BLK) {
         m.c_end = std::min<int64_t>(c->m.c_end, c->m.hb_long0 * KNP_HALO_BLK);
-        const int rc = ring_emi_apply(c, m, x, kappa, y);
+        const int rc = ring_emi_apply(c, m, x, kappa, y, (c->dist && c->halo_stream) ? env_int("KNP_HALO_RESERVE_CU", 8) : 0);
         if (rc || m.c_end >= c->m.c_end) return rc;
         m.c_begin = m.c_end;                   // blocks with long neighbour lists (a partition's cut cells): LDS-staged kernel below
         m.c_end = c->m.c_end;

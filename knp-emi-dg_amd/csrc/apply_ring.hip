@@ -142,7 +142,8 @@ template <int NS> struct KnpRing {
 
 template <int NS, int I>
 __device__ __forceinline__ void knp_facet_ring(const CellGeom<3>& K, uint32_t flags, unsigned loc, unsigned dsel, const double (*xv)[4],
-                                               const double (*gx)[4], const double* gp, const double* Dk, const double* zpsi, double tau,
+                                               const double (*gx)[4], const double* gp, const double* Dk, const double* hvD,
+                                               const double* zpsi, double tau,
                                                const lds_double* X, const lds_double* G, const lds_double* sD, const lds_double* ft,
                                                double (*y)[4]) {
     constexpr int D = 3, NV = 4;
@@ -166,6 +167,7 @@ __device__ __forceinline__ void knp_facet_ring(const CellGeom<3>& K, uint32_t fl
     const double up_own = fmax(-gp[I], 0.0) * DV;
     const double up_nb = fmax(-gp_nb, 0.0) * nLI_DV;
     const double penA = tau * pen_geo;
+    const double hv = 0.5 * K.vol;
 #pragma unroll
     for (int k = 0; k < NS; ++k) {
         double xr[NV], xf[D];
@@ -178,9 +180,10 @@ __device__ __forceinline__ void knp_facet_ring(const CellGeom<3>& K, uint32_t fl
         double s_nb = xap * gr;
 #pragma unroll
         for (int mm = 0; mm < D; ++mm) s_nb = fma(xf[mm], cf[mm], s_nb);
+        // penalty and upwind weights of the two traces:  D (pen - z psi un),  written so that each costs one FMA and one product
         const double zp = zpsi[k];
-        const double c_own = penA * Dk[k] - zp * Dk[k] * up_own;
-        const double c_nb = penA * Dn - zp * Dn * up_nb;
+        const double c_own = Dk[k] * fma(-zp, up_own, penA);
+        const double c_nb = Dn * fma(-zp, up_nb, penA);
         double sdu = 0.0, w[D], sw = 0.0;
 #pragma unroll
         for (int mm = 0; mm < D; ++mm) {
@@ -189,12 +192,12 @@ __device__ __forceinline__ void knp_facet_ring(const CellGeom<3>& K, uint32_t fl
             w[mm] = fma(c_own, xo, -c_nb * xf[mm]);
             sw += w[mm];
         }
-        const double t1 = 0.5 * K.vol * fma(Dk[k], s_own, Dn * s_nb);
-        const double t2 = 0.5 * Dk[k] * K.vol * sdu;
+        const double t1m = fma(FacetConst<D>::mass, sw, hv * fma(Dk[k], s_own, Dn * s_nb));
+        const double t2 = hvD[k] * sdu;
 #pragma unroll
         for (int a = 0; a < NV; ++a) y[k][a] = fma(K.G[a][I], t2, y[k][a]);
 #pragma unroll
-        for (int mm = 0; mm < D; ++mm) y[k][mm + (mm >= I)] += t1 + FacetConst<D>::mass * (sw + w[mm]);
+        for (int mm = 0; mm < D; ++mm) y[k][mm + (mm >= I)] += fma(FacetConst<D>::mass, w[mm], t1m);
     }
 }
 
@@ -339,7 +342,9 @@ __global__ __launch_bounds__(RB * NG + 64 * RLOADERS) void k_knp_apply_ring(Mesh
                 Dk[k] = sD[k * KNP_MAX_MAT + cur.mymat];
             }
             const double mw = ka.inv_dt * K.vol / 20.0;
-            double gx[KS][NV];
+            double gx[KS][NV], hvD[KS];
+#pragma unroll
+            for (int k = 0; k < KS; ++k) hvD[k] = 0.5 * K.vol * Dk[k];
 #pragma unroll
             for (int k = 0; k < KS; ++k) {
                 double sx = 0.0;
@@ -358,10 +363,10 @@ __global__ __launch_bounds__(RB * NG + 64 * RLOADERS) void k_knp_apply_ring(Mesh
             }
             const lds_double* ft = rec + 11;
             if (!(dbg & 2)) {
-            knp_facet_ring<KS, 0>(K, cur.flags, cur.lw.x & 0xffffu, cur.nm & 0xffu, xv, gx, gp, Dk, zpsi, ka.tau, X, G, sD, ft, y);
-            knp_facet_ring<KS, 1>(K, cur.flags, cur.lw.x >> 16, (cur.nm >> 8) & 0xffu, xv, gx, gp, Dk, zpsi, ka.tau, X, G, sD, ft, y);
-            knp_facet_ring<KS, 2>(K, cur.flags, cur.lw.y & 0xffffu, (cur.nm >> 16) & 0xffu, xv, gx, gp, Dk, zpsi, ka.tau, X, G, sD, ft, y);
-            knp_facet_ring<KS, 3>(K, cur.flags, cur.lw.y >> 16, cur.nm >> 24, xv, gx, gp, Dk, zpsi, ka.tau, X, G, sD, ft, y);
+            knp_facet_ring<KS, 0>(K, cur.flags, cur.lw.x & 0xffffu, cur.nm & 0xffu, xv, gx, gp, Dk, hvD, zpsi, ka.tau, X, G, sD, ft, y);
+            knp_facet_ring<KS, 1>(K, cur.flags, cur.lw.x >> 16, (cur.nm >> 8) & 0xffu, xv, gx, gp, Dk, hvD, zpsi, ka.tau, X, G, sD, ft, y);
+            knp_facet_ring<KS, 2>(K, cur.flags, cur.lw.y & 0xffffu, (cur.nm >> 16) & 0xffu, xv, gx, gp, Dk, hvD, zpsi, ka.tau, X, G, sD, ft, y);
+            knp_facet_ring<KS, 3>(K, cur.flags, cur.lw.y >> 16, cur.nm >> 24, xv, gx, gp, Dk, hvD, zpsi, ka.tau, X, G, sD, ft, y);
             }
 #pragma unroll
             for (int k = 0; k < KS; ++k) store_nodal<3>(yout + (int64_t)(k0 + k) * m.nc * NV, c, y[k]);
@@ -615,10 +620,10 @@ bool ring_usable(const knp_ctx* c, int which) {
     return c->nmat > 0 && c->p.n_sys <= 2 && env_int_ring("KNP_APPLY_MAT", 1) != 0 && env_int_ring("KNP_APPLY_HALO", 1) != 0;
 }
 
-int ring_emi_apply(knp_ctx* c, const MeshDev& m, const double* x, const double* kappa, double* y) {
+int ring_emi_apply(knp_ctx* c, const MeshDev& m, const double* x, const double* kappa, double* y, int reserve_cus) {
     const size_t lds = ring_lds_bytes(c, 0);
     if (!ring_grant_lds(k_emi_apply_ring, lds)) { c->err = "hipFuncSetAttribute(k_emi_apply_ring) failed"; return -2; }
-    hipLaunchKernelGGL(k_emi_apply_ring, ring_grid(m, c->device, 0), dim3(2 * RB + 64 * RLOADERS), lds, c->stream, m, x, kappa, y, c->p.C_phi, c->p.tau_emi);
+    hipLaunchKernelGGL(k_emi_apply_ring, ring_grid(m, c->device, reserve_cus), dim3(2 * RB + 64 * RLOADERS), lds, c->stream, m, x, kappa, y, c->p.C_phi, c->p.tau_emi);
     HIPCHK(c, hipGetLastError());
     return 0;
 }

@@ -203,7 +203,7 @@ bool p2_assembled();                 // KNP_P2_ASSEMBLED=1: round-1 path (quadra
 
 // ring-staged P1 applies on structured 3D meshes (apply_ring.hip): loader wave + LDS-DMA ring + consumer waves
 bool ring_usable(const knp_ctx* c, int which);       // which: 0 EMI, 1 KNP
-int ring_emi_apply(knp_ctx* c, const MeshDev& m, const double* x, const double* kappa, double* y);
+int ring_emi_apply(knp_ctx* c, const MeshDev& m, const double* x, const double* kappa, double* y, int reserve_cus);
 int ring_knp_apply(knp_ctx* c, const MeshDev& m, const double* x, const double* gphi, double* y, const KnpArgs& ka, int reserve_cus);
 
 // matrix-free DG-P2 applies (apply_p2.hip)
