@@ -838,10 +838,10 @@ int knp_knp_solve(knp_ctx* c, double rtol, double atol, int maxit, int min_it, i
     }
     if (c->knp_krylov == 1) {
         const int m = std::min(std::max(c->gm_restart, 2), KNP_GM_MAX);
-        if (c->gm_alloc < m + 1) {
+        if (c->gm_alloc < 2 * m + 1) {                    // basis V_0..V_m and its preconditioned image Z_0..Z_{m-1}
             hipFree(c->gm_V); c->gm_V = nullptr; c->gm_alloc = 0;
-            HIPCHK(c, hipMalloc((void**)&c->gm_V, sizeof(double) * (size_t)(m + 1) * f->n[KNP_F_C]));
-            c->gm_alloc = m + 1;
+            HIPCHK(c, hipMalloc((void**)&c->gm_V, sizeof(double) * (size_t)(2 * m + 1) * f->n[KNP_F_C]));
+            c->gm_alloc = 2 * m + 1;
         }
         kv.gm_V = c->gm_V; kv.gm_m = m;
         rc = gmres_solve(c, kv, rtol, atol, maxit, min_it, check_every, niter, res);

@@ -252,10 +252,11 @@ __device__ void gm_scalar_op(int op, double* S, const double* R, int* flag, int*
         } break;
         case OP_GM_NORM: {               // R[0] = ||w - sum_i h_ij V_i||^2;  aux = j | cycle length m << 8
             if (*flag) return;
-            const int j = aux & 0xff, m = (aux >> 8) & 0xff;
+            const int j = aux & 0xff, m = (aux >> 8) & 0xff, jlo = (aux >> 16) & 0xff;
             double* h = H + (M + 1) * j;
             const double hn = sqrt(R[0]);
             h[j + 1] = hn;
+            for (int i = 0; i < jlo; ++i) h[i] = 0.0;            // truncated orthogonalisation: nothing was projected out there
             for (int i = 0; i < j; ++i) {                        // previous rotations on the new column
                 const double t = cs[i] * h[i] + sn[i] * h[i + 1];
                 h[i + 1] = -sn[i] * h[i] + cs[i] * h[i + 1];
@@ -1095,7 +1096,8 @@ static int bicgstab_impl(knp_ctx* c, KrylovVecs& kv, double rtol, double atol, i
 
 // ---- restarted GMRES (right preconditioning) ------------------------------------------------------------------------------------
 // The reference solves the KNP system with PETSc GMRES(30) + BoomerAMG (solver.py:684-701, 767-771).  Same preconditioner and same
-// stopping test on the true residual as bicgstab_solve; classical Gram-Schmidt with up to eight inner products per pass over w.
+// stopping test on the true residual as bicgstab_solve; classical Gram-Schmidt with up to eight inner products per pass over w; the
+// preconditioned basis Z = M^-1 V is kept (flexible-GMRES storage), so a cycle ends with x += Z y and no extra preconditioner call.
 // Systems (species) run in lockstep; a system whose cycle is complete (status 4) idles until the others are, then all of them
 // update x, look at their true residual and either stop or start the next cycle from it.
 
@@ -1129,6 +1131,24 @@ __global__ __launch_bounds__(KNP_BLOCK) void k_gm_binv(VecDims d, const int* __r
     stv<NV>(SYS_PTR(y, s), c, yv);
 }
 
+// v *= scal[slot] (the normalisation of the newest basis vector) ; y = Binv v : one pass instead of two
+template <int NV>
+__global__ __launch_bounds__(KNP_BLOCK) void k_gm_scale_binv(VecDims d, const int* __restrict__ status, const double* __restrict__ scal, int slot,
+                                                             const bjreal* __restrict__ binv, double* __restrict__ v, double* __restrict__ y) {
+    const int s = blockIdx.y;
+    if (status[2 * s]) return;
+    const double a = scal[s * KS_N + slot];
+    const int64_t c = (int64_t)blockIdx.x * KNP_BLOCK + threadIdx.x;
+    if (c >= d.nc_owned) return;
+    double vv[NV], yv[NV];
+    ldv<NV>(SYS_PTR(v, s), c, vv);
+#pragma unroll
+    for (int a_ = 0; a_ < NV; ++a_) vv[a_] *= a;
+    block_matvec<NV>(bj_block<NV>(d, binv, s, c), 0, vv, yv);
+    stv<NV>(SYS_PTR(v, s), c, vv);
+    stv<NV>(SYS_PTR(y, s), c, yv);
+}
+
 // partial[r] = w . V_{j0 + r}, r < cnt <= 8 (the rest zero)
 template <int NV>
 __global__ __launch_bounds__(KNP_BLOCK) void k_gm_dots(VecDims d, const int* __restrict__ status, const double* __restrict__ w,
@@ -1156,7 +1176,7 @@ __global__ __launch_bounds__(KNP_BLOCK) void k_gm_dots(VecDims d, const int* __r
 // w -= sum_{i <= j} H[i, j] V_i ;  partial[0] = ||w||^2
 template <int NV>
 __global__ __launch_bounds__(KNP_BLOCK) void k_gm_update(VecDims d, const int* __restrict__ status, const double* __restrict__ scal,
-                                                         double* __restrict__ w, const double* __restrict__ V, int64_t vstride, int j,
+                                                         double* __restrict__ w, const double* __restrict__ V, int64_t vstride, int j, int jlo,
                                                          double* __restrict__ partial) {
     const int s = blockIdx.y;
     const int64_t c = (int64_t)blockIdx.x * KNP_BLOCK + threadIdx.x;
@@ -1165,7 +1185,7 @@ __global__ __launch_bounds__(KNP_BLOCK) void k_gm_update(VecDims d, const int* _
         const double* h = scal + KNP_GM_OFFSET + (int64_t)s * KNP_GM_STRIDE + (int64_t)(KNP_GM_MAX + 1) * j;
         double wv[NV], vv[NV];
         ldv<NV>(SYS_PTR(w, s), c, wv);
-        for (int i = 0; i <= j; ++i) {
+        for (int i = jlo; i <= j; ++i) {
             const double hi = h[i];
             ldv<NV>(SYS_PTR(V + (int64_t)i * vstride, s), c, vv);
 #pragma unroll
@@ -1178,7 +1198,7 @@ __global__ __launch_bounds__(KNP_BLOCK) void k_gm_update(VecDims d, const int* _
     write_partials<1>(partial, d.nsys, acc);
 }
 
-// u = sum_{i < k} y_i V_i  (k = the system's column count)
+// u += sum_{i < k} y_i Z_i  (k = the system's column count; u = x, Z_i = M^-1 V_i)
 template <int NV>
 __global__ __launch_bounds__(KNP_BLOCK) void k_gm_lincomb(VecDims d, const int* __restrict__ status, const double* __restrict__ scal,
                                                           const double* __restrict__ V, int64_t vstride, double* __restrict__ u) {
@@ -1189,8 +1209,7 @@ __global__ __launch_bounds__(KNP_BLOCK) void k_gm_lincomb(VecDims d, const int* 
     const int k = (int)scal[s * KS_N + KS_GM_K];
     const double* y = scal + KNP_GM_OFFSET + (int64_t)s * KNP_GM_STRIDE + (KNP_GM_MAX + 1) * KNP_GM_MAX + 3 * KNP_GM_MAX + 1;
     double uv[NV], vv[NV];
-#pragma unroll
-    for (int a = 0; a < NV; ++a) uv[a] = 0.0;
+    ldv<NV>(SYS_PTR(u, s), c, uv);
     for (int i = 0; i < k; ++i) {
         const double yi = y[i];
         ldv<NV>(SYS_PTR(V + (int64_t)i * vstride, s), c, vv);
@@ -1223,12 +1242,16 @@ static int gmres_impl(knp_ctx* c, KrylovVecs& kv, double rtol, double atol, int 
     const dim3 g((unsigned)grid_for(c->m.nc_owned), (unsigned)ns), b(KNP_BLOCK);
     const int64_t vstride = (int64_t)ns * c->m.nc * NV;
     double* V = kv.gm_V;
+    double* Z = kv.gm_V + (int64_t)(m + 1) * vstride;      // Z_j = M^-1 V_j, kept (flexible-GMRES storage): the update x += Z y needs no further preconditioner application
     int rc;
     const bool hyb = kv.bj_lmax > 0.0 && knp_hybrid();
     const double ct = hyb ? 1.0 / bj_theta<false>(kv) : 0.0;
+    static const int trunc = getenv("KNP_GMRES_TRUNC") ? atoi(getenv("KNP_GMRES_TRUNC")) : 0;
     // out = M^-1 in : cell-block-Jacobi (two-step Chebyshev) + auxiliary-space coarse correction, as in bicgstab_impl
-    auto precond = [&](const double* in, double* out) -> int {
-        hipLaunchKernelGGL(k_gm_binv<NV>, g, b, 0, c->stream, d, (const int*)c->status, kv.binv, in, out);
+    // slot >= 0: `in` is the newest, still unnormalised basis vector; it is scaled by scal[slot] in the same pass
+    auto precond = [&](double* in, double* out, int slot) -> int {
+        if (slot >= 0) hipLaunchKernelGGL(k_gm_scale_binv<NV>, g, b, 0, c->stream, d, (const int*)c->status, (const double*)c->scal, slot, kv.binv, in, out);
+        else hipLaunchKernelGGL(k_gm_binv<NV>, g, b, 0, c->stream, d, (const int*)c->status, kv.binv, (const double*)in, out);
         int r;
         if (kv.bj_lmax > 0.0 && (r = bj_cheb2<NV, false>(c, d, kv, in, out))) return r;
         return knp_coarse_correction<NV>(c, d, in, out, hyb ? kv.tmp : nullptr, ct);
@@ -1248,25 +1271,27 @@ static int gmres_impl(knp_ctx* c, KrylovVecs& kv, double rtol, double atol, int 
     int it = 0;
     while (!all_done() && it < maxit) {
         // one restart cycle
-        hipLaunchKernelGGL(k_gm_scale<NV>, g, b, 0, c->stream, d, (const int*)c->status, (const double*)c->scal, (int)KS_ALPHA, V);
         int j = 0;
         while (j < m && any_running() && it < maxit) {
             int chunk = next_chunk(it, maxit, check_every, c->last_it_knp);
             if (chunk > m - j) chunk = m - j;
             for (int k = 0; k < chunk; ++k, ++j) {
                 double* w = V + (int64_t)(j + 1) * vstride;
-                if ((rc = precond(V + (int64_t)j * vstride, kv.y))) return rc;
-                if ((rc = dist_apply(c, 1, kv.y, kv.coef, w))) return rc;
-                for (int j0 = 0; j0 <= j; j0 += 8) {
+                double* zj = Z + (int64_t)j * vstride;
+                if ((rc = precond(V + (int64_t)j * vstride, zj, j == 0 ? (int)KS_ALPHA : (int)KS_OMEGA))) return rc;
+                if ((rc = dist_apply(c, 1, zj, kv.coef, w))) return rc;
+                // KNP_GMRES_TRUNC = t > 0: incomplete orthogonalisation against the last t basis vectors only (IOM / quasi-minimal
+                // residual: the cycle's estimate is then a quasi-residual, the true residual at the cycle's end still decides)
+                const int jlo = trunc > 0 ? std::max(0, j + 1 - trunc) : 0;
+                for (int j0 = jlo; j0 <= j; j0 += 8) {
                     const int cnt = std::min(8, j + 1 - j0);
                     hipLaunchKernelGGL(k_gm_dots<NV>, g, b, 0, c->stream, d, (const int*)c->status, (const double*)w, (const double*)V, vstride, j0,
                                        cnt, c->partial);
                     if ((rc = finalize(c, OP_GM_H, ns, 8, rtol, atol, min_it, 0.0, 0, j0 | (j << 8) | (cnt << 16)))) return rc;
                 }
                 hipLaunchKernelGGL(k_gm_update<NV>, g, b, 0, c->stream, d, (const int*)c->status, (const double*)c->scal, w, (const double*)V,
-                                   vstride, j, c->partial);
-                if ((rc = finalize(c, OP_GM_NORM, ns, 1, rtol, atol, min_it, 0.0, 0, j | (m << 8)))) return rc;
-                hipLaunchKernelGGL(k_gm_scale<NV>, g, b, 0, c->stream, d, (const int*)c->status, (const double*)c->scal, (int)KS_OMEGA, w);
+                                   vstride, j, jlo, c->partial);
+                if ((rc = finalize(c, OP_GM_NORM, ns, 1, rtol, atol, min_it, 0.0, 0, j | (m << 8) | (jlo << 16)))) return rc;
             }
             it += chunk;
             if ((rc = poll_status(c, ns, hs))) return rc;
@@ -1274,9 +1299,7 @@ static int gmres_impl(knp_ctx* c, KrylovVecs& kv, double rtol, double atol, int 
         // x += M^-1 (V y) for every system that iterated in this cycle; then its true residual decides
         hipLaunchKernelGGL(k_scalar_op, dim3(1), dim3(64), 0, c->stream, (int)OP_GM_SOLVE, ns, (const double*)(c->scal + KNP_MAX_SYS * KS_N),
                            c->scal, c->status, rtol, atol, min_it, 0.0, 0, 0);
-        hipLaunchKernelGGL(k_gm_lincomb<NV>, g, b, 0, c->stream, d, (const int*)c->status, (const double*)c->scal, (const double*)V, vstride, kv.z);
-        if ((rc = precond(kv.z, kv.y))) return rc;
-        hipLaunchKernelGGL(k_gm_xpy<NV>, g, b, 0, c->stream, d, (const int*)c->status, (const double*)kv.y, kv.x);
+        hipLaunchKernelGGL(k_gm_lincomb<NV>, g, b, 0, c->stream, d, (const int*)c->status, (const double*)c->scal, (const double*)Z, vstride, kv.x);
         if ((rc = residual(OP_GM_RESTART))) return rc;
         if ((rc = poll_status(c, ns, hs))) return rc;
     }
