@@ -385,7 +385,8 @@ __global__ __launch_bounds__(64) void k_tab_block_inverse(MeshDev m, const doubl
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// L_emi: one thread per (cell, row a)
+// L_emi: one thread per CELL, all ND rows (round 3; rounds 1-2 ran one thread per (cell, row): every row recomputed the cell's
+// geometry, the nodal combination S, the neighbour's data and every quadrature-point flux -- 419 us per step for 124 416 P2 cells)
 // ------------------------------------------------------------------------------------------------------------
 template <int D, int ND>
 __global__ __launch_bounds__(128) void k_tab_emi_rhs(MeshDev m, TabRule rc, TabRule rf, TabRule rm, const double* __restrict__ cc,
@@ -394,37 +395,40 @@ __global__ __launch_bounds__(128) void k_tab_emi_rhs(MeshDev m, TabRule rc, TabR
                                                      double F, double C_phi, int splitting, const double* __restrict__ extra,
                                                      double* __restrict__ out) {
     constexpr int NV = D + 1;
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= m.nc_owned * ND) return;
-    const int64_t c = t / ND;
-    const int a = (int)(t % ND);
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= m.nc_owned) return;
     CellGeom<D> K;
     cell_geo<D>(m, c, K);
     // S = sum_k F z_k D_k c_k is a DG-p function (D_k is cell-wise constant): nodal combination
-    double S[ND];
+    double S[ND], acc[ND];
 #pragma unroll
-    for (int b = 0; b < ND; ++b) S[b] = 0.0;
+    for (int b = 0; b < ND; ++b) { S[b] = 0.0; acc[b] = 0.0; }
     for (int i = 0; i < ia.n; ++i) {
         const double* src = (i < ia.n - 1) ? cc + (int64_t)i * m.nc * ND : celim;
         const double f = F * ia.z[i] * Dk[(int64_t)i * m.nc + c];
 #pragma unroll
         for (int b = 0; b < ND; ++b) S[b] = fma(f, src[c * ND + b], S[b]);
     }
-    double acc = 0.0;
     for (int q = 0; q < rc.nq; ++q) {
         const double* dB = rc.dB + (int64_t)q * ND * NV;
-        double gS[D], ga[D];
+        double gS[D];
 #pragma unroll
-        for (int k = 0; k < D; ++k) { gS[k] = 0.0; ga[k] = 0.0; }
+        for (int k = 0; k < D; ++k) gS[k] = 0.0;
 #pragma unroll
         for (int l = 0; l < NV; ++l) {
             double sl = 0.0;
 #pragma unroll
             for (int b = 0; b < ND; ++b) sl = fma(S[b], dB[b * NV + l], sl);
 #pragma unroll
-            for (int k = 0; k < D; ++k) { gS[k] = fma(sl, K.g[l][k], gS[k]); ga[k] = fma(dB[a * NV + l], K.g[l][k], ga[k]); }
+            for (int k = 0; k < D; ++k) gS[k] = fma(sl, K.g[l][k], gS[k]);
         }
-        acc -= rc.w[q] * K.vol * dotD<D>(gS, ga);
+        // grad(S) . grad(lambda_l), then each row's gradient is a combination of those
+        double gl[NV];
+#pragma unroll
+        for (int l = 0; l < NV; ++l) gl[l] = dotD<D>(gS, K.g[l]);
+        const double wv = rc.w[q] * K.vol;
+#pragma unroll
+        for (int a = 0; a < ND; ++a) acc[a] -= wv * dotNV<NV>(dB + a * NV, gl);
     }
     const uint32_t flags = m.fflag[c];
     for (int i = 0; i < NV; ++i) {
@@ -459,7 +463,9 @@ __global__ __launch_bounds__(128) void k_tab_emi_rhs(MeshDev m, TabRule rc, TabR
                     flux = fma(S[b], dotNV<NV>(dBi + b * NV, gn), flux);
                     flux = fma(S2[b], dotNV<NV>(dBj + b * NV, gn2), flux);
                 }
-                acc += rf.w[q] * area * 0.5 * flux * Bi[a];
+                const double wf = rf.w[q] * area * 0.5 * flux;
+#pragma unroll
+                for (int a = 0; a < ND; ++a) acc[a] = fma(wf, Bi[a], acc[a]);
             }
         } else if (kind == FK_MEMBRANE && splitting != 2) {    // MMS: Robin data arrives as host-integrated extra RHS
             const int64_t f = m.cfacet[c * NV + i];
@@ -471,17 +477,21 @@ __global__ __launch_bounds__(128) void k_tab_emi_rhs(MeshDev m, TabRule rc, TabR
             }
             const double sgn = ((fb >> 4) & 1u) ? -1.0 : 1.0;      // e (plus) side carries -v_e
             const double area = (double)D * K.vol * sqrt(dotD<D>(K.g[i], K.g[i]));
-            double sB = 0.0;
-            for (int q = 0; q < rm.nq; ++q) sB = fma(rm.w[q], rm.B[((int64_t)i * rm.nq + q) * ND + a], sB);
-            acc += sgn * C_phi * g * area * sB;
+            const double wm = sgn * C_phi * g * area;
+            for (int q = 0; q < rm.nq; ++q) {
+                const double* Bi = rm.B + ((int64_t)i * rm.nq + q) * ND;
+                const double wq = wm * rm.w[q];
+#pragma unroll
+                for (int a = 0; a < ND; ++a) acc[a] = fma(wq, Bi[a], acc[a]);
+            }
         }
     }
-    if (extra) acc += extra[t];
-    out[t] = acc;
+#pragma unroll
+    for (int a = 0; a < ND; ++a) out[c * ND + a] = acc[a] + (extra ? extra[c * ND + a] : 0.0);
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// L_knp of species s = blockIdx.y
+// L_knp of species s = blockIdx.y: one thread per CELL, all ND rows (round 3, as above)
 // ------------------------------------------------------------------------------------------------------------
 struct KnpRhsTab { double F, C_M, dt; int splitting; const double* mms_C; const double* extra; };
 
@@ -493,25 +503,26 @@ __global__ __launch_bounds__(128) void k_tab_knp_rhs(MeshDev m, TabRule rc, TabR
                                                      const double* __restrict__ fsrc, IonZ ia, KnpRhsTab ra,
                                                      double* __restrict__ out_all) {
     constexpr int NV = D + 1;
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= m.nc_owned * ND) return;
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= m.nc_owned) return;
     const int s = blockIdx.y;
-    const int64_t c = t / ND;
-    const int a = (int)(t % ND);
     CellGeom<D> K;
     cell_geo<D>(m, c, K);
     const double z = ia.z[s];
     const double Dc = Dk[(int64_t)s * m.nc + c];
-    double cp[ND];
+    double cp[ND], acc[ND];
     ld<ND>(cprev + (int64_t)s * m.nc * ND, c, cp);
+#pragma unroll
+    for (int a = 0; a < ND; ++a) acc[a] = 0.0;
     const double fs = fsrc ? fsrc[(int64_t)s * m.nc + c] : 0.0;
-    double acc = 0.0;
     for (int q = 0; q < rc.nq; ++q) {
         const double* B = rc.B + (int64_t)q * ND;
         double cq = 0.0;
 #pragma unroll
         for (int b = 0; b < ND; ++b) cq = fma(B[b], cp[b], cq);
-        acc += rc.w[q] * K.vol * (cq / ra.dt + fs) * B[a];
+        const double wq = rc.w[q] * K.vol * (cq / ra.dt + fs);
+#pragma unroll
+        for (int a = 0; a < ND; ++a) acc[a] = fma(wq, B[a], acc[a]);
     }
     const uint32_t flags = m.fflag[c];
     for (int i = 0; i < NV; ++i) {
@@ -535,11 +546,11 @@ __global__ __launch_bounds__(128) void k_tab_knp_rhs(MeshDev m, TabRule rc, TabR
 #pragma unroll
             for (int b = 0; b < ND; ++b) as[b] = fma(fz, src[c * ND + b], as[b]);
         }
+        const double area = (double)D * K.vol * sqrt(dotD<D>(K.g[i], K.g[i]));
+        const double sgn = is_e ? -1.0 : 1.0;
         if (ra.splitting == 2) {
             // MMS (solver.py:649-650): -(phi_i - phi_e)(C_i v_i - C_e v_e) with the DG0 coupling coefficient C
             const double Cown = ra.mms_C[(int64_t)s * m.nc + c];
-            const double area = (double)D * K.vol * sqrt(dotD<D>(K.g[i], K.g[i]));
-            const double sgn = is_e ? -1.0 : 1.0;
             for (int q = 0; q < rm.nq; ++q) {
                 const double* Bi = rm.B + ((int64_t)i * rm.nq + q) * ND;
                 const double* Bj = rm.B + ((int64_t)j * rm.nq + q) * ND;
@@ -547,7 +558,9 @@ __global__ __launch_bounds__(128) void k_tab_knp_rhs(MeshDev m, TabRule rc, TabR
 #pragma unroll
                 for (int b = 0; b < ND; ++b) { pq = fma(Bi[b], po[b], pq); pq2 = fma(Bj[b], pn[b], pq2); }
                 const double jump = is_e ? (pq2 - pq) : (pq - pq2);
-                acc -= rm.w[q] * area * sgn * Cown * jump * Bi[a];
+                const double wq = rm.w[q] * area * sgn * Cown * jump;
+#pragma unroll
+                for (int a = 0; a < ND; ++a) acc[a] -= wq * Bi[a];
             }
             continue;
         }
@@ -555,8 +568,6 @@ __global__ __launch_bounds__(128) void k_tab_knp_rhs(MeshDev m, TabRule rc, TabR
         double I_tot = 0.0;
         for (int k = 0; k < ia.n; ++k) I_tot += Ich[(int64_t)k * m.nf + f];
         const double pM = phiM[f];
-        const double area = (double)D * K.vol * sqrt(dotD<D>(K.g[i], K.g[i]));
-        const double sgn = is_e ? -1.0 : 1.0;
         for (int q = 0; q < rm.nq; ++q) {
             const double* Bi = rm.B + ((int64_t)i * rm.nq + q) * ND;
             const double* Bj = rm.B + ((int64_t)j * rm.nq + q) * ND;
@@ -573,11 +584,15 @@ __global__ __launch_bounds__(128) void k_tab_knp_rhs(MeshDev m, TabRule rc, TabR
             double g = pM - ra.dt / (ra.C_M * alpha) * I_k;
             if (ra.splitting) g += (ra.dt / ra.C_M) * I_tot;
             const double jump = is_e ? (pq2 - pq) : (pq - pq2);       // phi_i - phi_e
-            acc += rm.w[q] * area * sgn * C * (g - jump) * Bi[a];
+            const double wq = rm.w[q] * area * sgn * C * (g - jump);
+#pragma unroll
+            for (int a = 0; a < ND; ++a) acc[a] = fma(wq, Bi[a], acc[a]);
         }
     }
-    if (ra.extra) acc += ra.extra[(int64_t)s * m.nc * ND + t];
-    out_all[(int64_t)s * m.nc * ND + t] = acc;
+    double* out = out_all + (int64_t)s * m.nc * ND;
+    const double* ex = ra.extra ? ra.extra + (int64_t)s * m.nc * ND : nullptr;
+#pragma unroll
+    for (int a = 0; a < ND; ++a) out[c * ND + a] = acc[a] + (ex ? ex[c * ND + a] : 0.0);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -676,6 +691,9 @@ static int ensure_blocks(knp_ctx* c) {
     return 0;
 }
 
+static dim3 cells_grid(knp_ctx* c, int block, int ny = 1) {
+    return dim3((unsigned)((c->m.nc_owned + block - 1) / block), (unsigned)ny);
+}
 static dim3 rows_grid(knp_ctx* c, int block, int ny = 1) {
     return dim3((unsigned)((c->m.nc_owned * c->nd + block - 1) / block), (unsigned)ny);
 }
@@ -719,7 +737,7 @@ int tab_block_inverse(knp_ctx* c, int which, bjreal* binv) {
 
 int tab_emi_rhs(knp_ctx* c, const double* cc, const double* celim, const double* phiM, const double* Ich, double* b) {
     if (need_tabs(c, {KNP_TAB_CELL_RHS_EMI, KNP_TAB_FACET_RHS_EMI, KNP_TAB_FACET_MEM_LIN})) return -1;
-    TAB_DISPATCH(c, k_tab_emi_rhs, rows_grid(c, 128), dim3(128), c->m, c->tab[KNP_TAB_CELL_RHS_EMI], c->tab[KNP_TAB_FACET_RHS_EMI],
+    TAB_DISPATCH(c, k_tab_emi_rhs, cells_grid(c, 128), dim3(128), c->m, c->tab[KNP_TAB_CELL_RHS_EMI], c->tab[KNP_TAB_FACET_RHS_EMI],
                  c->tab[KNP_TAB_FACET_MEM_LIN], cc, celim, (const double*)c->D, phiM, Ich, ion_z(c), c->p.F, c->p.C_phi,
                  c->p.splitting, (const double*)c->extra_emi, b);
     return 0;
@@ -729,7 +747,7 @@ int tab_knp_rhs(knp_ctx* c, const double* cc, const double* cprev, const double*
                 const double* Ich, double* b) {
     if (need_tabs(c, {KNP_TAB_CELL_MASS, KNP_TAB_FACET_MEM_KNP})) return -1;
     KnpRhsTab ra{c->p.F, c->p.C_M, c->p.dt, c->p.splitting, (const double*)c->mms_C, (const double*)c->extra_knp};
-    TAB_DISPATCH(c, k_tab_knp_rhs, rows_grid(c, 128, c->p.n_sys), dim3(128), c->m, c->tab[KNP_TAB_CELL_MASS],
+    TAB_DISPATCH(c, k_tab_knp_rhs, cells_grid(c, 128, c->p.n_sys), dim3(128), c->m, c->tab[KNP_TAB_CELL_MASS],
                  c->tab[KNP_TAB_FACET_MEM_KNP], cc, cprev, celim, phi, (const double*)c->D, phiM, Ich, (const double*)c->fsrc,
                  ion_z(c), ra, b);
     return 0;

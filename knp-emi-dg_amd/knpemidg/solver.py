@@ -560,6 +560,9 @@ class Solver:
                 ("residual target %.2e x F min|z| ||b_knp||" % self._emi_target) if self._emi_target else "rtol %.2e" % self._rtol_emi,
                 self._rtol_knp))
         self._atol_knp = 1e-40 if self.direct_knp else float(self.atol_knp)
+        # ksp_min_it 5 of the reference's GMRES (solver.py:686) = five preconditioner applications; kept as five iterations of either method
+        # here (BiCGStab: ten applications) -- KNP_KNP_MIN_IT / solver_params.knp_min_it change it
+        self._knp_min_it = int(getattr(sp, "knp_min_it", None) or os.environ.get("KNP_KNP_MIN_IT", 5))
         # KNP Krylov method: the device default is BiCGStab; `knp_krylov = "gmres"` (+ `gmres_restart`, default 30) in solver_params,
         # or KNP_KNP_KRYLOV=gmres, selects the reference's restarted GMRES (ksp_type gmres / ksp_gmres_restart 30, solver.py:684-701)
         meth = getattr(sp, "knp_krylov", None) or os.environ.get("KNP_KNP_KRYLOV", "bicgstab")
@@ -652,7 +655,7 @@ class Solver:
         if self.save_solver_stats:
             self.file_knp_assem.write("ass_time: %.4f \n" % (res))
         ts = time.perf_counter()
-        niters, r = dev.knp_solve(self._rtol_knp, self._atol_knp, maxit=self.max_it_knp, min_it=5)
+        niters, r = dev.knp_solve(self._rtol_knp, self._atol_knp, maxit=self.max_it_knp, min_it=self._knp_min_it)
         self._knp_bnorm = np.asarray(r)[:, 2].copy()
         te = time.perf_counter()
         res = te - ts
