@@ -6,7 +6,7 @@
 //   * the loaders stream a block's records -- its own x / coefficient rows, the rows of the facet neighbours outside the block
 //     (the per-block lists hb_src of knp_ctx_create, a gather through the per-lane SOURCE address) -- straight into LDS with
 //     global_load_lds_dwordx4 (no VGPR destination, 1 KiB per wave instruction), TWO blocks ahead of the consumers, into a
-//     three-slot ring; a counted s_waitcnt vmcnt(N) retires exactly the block the consumers need next and leaves the following
+//     three-slot (KNP) / four-slot (EMI) ring; a counted s_waitcnt vmcnt(N) retires exactly the block the consumers need next and leaves the following
 //     one in flight across the workgroup barrier;
 //   * the consumers read LDS only (own rows, neighbour rows, per-cell topology bytes, class records, material table) -- they issue
 //     no global load at all, so nothing ever makes them wait for their y stores (loads and stores share the in-order vmcnt
@@ -33,7 +33,7 @@ constexpr int RLISTB = 1024;      // bytes of one list buffer = one DMA instruct
 constexpr int RNLIST = 4;
 constexpr int RLOADERS = 4;       // loader waves per workgroup, one per SIMD
 constexpr int META_F = 0, META_L = 1024, META_N = 3072, META_C = 4096, META_M = 5120, META_KNP = 6144, META_EMI = 5120;   // topology bytes in a slot (dma_meta)
-constexpr int RCLS = 43;          // LDS stride of a geometry-class record (odd: lanes of different classes on different banks): 36 for EMI, 11 + 32 for KNP
+constexpr int RCLS = 43;          // LDS stride of a geometry-class record (odd: lanes of different classes on different banks): vol + Gram (11) + cls_ext (32)
 static_assert(RB == KNP_HALO_BLK, "the halo tables are built for 256-cell blocks");
 
 // one LDS-DMA instruction: lane l copies 16 bytes from its own source address to (lds_dst + 16 l); lds_dst is wave-uniform.  M0 is

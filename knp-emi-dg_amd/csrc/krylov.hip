@@ -1101,22 +1101,6 @@ static int bicgstab_impl(knp_ctx* c, KrylovVecs& kv, double rtol, double atol, i
 // Systems (species) run in lockstep; a system whose cycle is complete (status 4) idles until the others are, then all of them
 // update x, look at their true residual and either stop or start the next cycle from it.
 
-// v *= scal[slot] (the normalisation of the next basis vector)
-template <int NV>
-__global__ __launch_bounds__(KNP_BLOCK) void k_gm_scale(VecDims d, const int* __restrict__ status, const double* __restrict__ scal, int slot,
-                                                        double* __restrict__ v) {
-    const int s = blockIdx.y;
-    if (status[2 * s]) return;
-    const double a = scal[s * KS_N + slot];
-    const int64_t c = (int64_t)blockIdx.x * KNP_BLOCK + threadIdx.x;
-    if (c >= d.nc_owned) return;
-    double vv[NV];
-    ldv<NV>(SYS_PTR(v, s), c, vv);
-#pragma unroll
-    for (int a_ = 0; a_ < NV; ++a_) vv[a_] *= a;
-    stv<NV>(SYS_PTR(v, s), c, vv);
-}
-
 // y = Binv v
 template <int NV>
 __global__ __launch_bounds__(KNP_BLOCK) void k_gm_binv(VecDims d, const int* __restrict__ status, const bjreal* __restrict__ binv,
