@@ -487,6 +487,8 @@ int amg_vcycle(knp_ctx* c, AmgHierarchy& H, hipStream_t on_stream) {
     return amg_vcycle_eager(c, H);      // eager fallback always runs on the context's stream
 }
 
+int amg_restrict_tail(knp_ctx* c, AmgHierarchy& H, hipStream_t st);
+
 int amg_restrict_from_dg(knp_ctx* c, AmgHierarchy& H, const double* r_dg, hipStream_t on_stream, int64_t r_stride, const double* t_dg,
                          double ct) {
     if (on_stream && c->dist) { c->err = "amg: the all-reduced restriction runs on the context's stream"; return -1; }
@@ -495,19 +497,41 @@ int amg_restrict_from_dg(knp_ctx* c, AmgHierarchy& H, const double* r_dg, hipStr
     hipStream_t st = on_stream ? on_stream : c->stream;
     if (H.ntiles > 0) {
         const int tile_dofs = H.tile_cells * c->nd;
-        if (!H.part || H.part_cols != H.ncol) {                       // [ncol][nslots], sized at the first use
-            hipFree(H.part);
-            H.part = nullptr;
-            HIPCHK(c, hipMalloc((void**)&H.part, sizeof(double) * (size_t)H.ncol * (size_t)(H.nslots ? H.nslots : 1)));
-            H.part_cols = H.ncol;
-        }
+        int rc = amg_restrict_tiles_prepare(c, H);
+        if (rc) return rc;
         hipLaunchKernelGGL(k_restrict_tiles, dim3((unsigned)H.ntiles, (unsigned)H.ncol), dim3(256), sizeof(double) * tile_dofs, st,
                            c->m.nc_owned * c->nd, tile_dofs, H.tile_off, H.slot_ptr, H.slot_idx, r_dg, r_stride, H.part, H.nslots, t_dg, ct);
-        hipLaunchKernelGGL(k_restrict_sum, GRIDX((H.ncg + 255) / 256), dim3(256), 0, st, H.ncg, H.part_ptr, H.part_idx,
-                           (const double*)H.part, H.nslots, H.levels[0].b, (H.ncol % 2 == 0) ? 2 : 1);
-    } else {
-        hipLaunchKernelGGL(k_dg_restrict<8>, GRIDX((H.ncg * 8 + 255) / 256), dim3(256), 0, st, H.ncg, H.cg_ptr, H.cg_idx, r_dg, H.levels[0].b, r_stride, (H.ncol % 2 == 0) ? 2 : 1, t_dg, ct);
+        return amg_restrict_finish(c, H, on_stream);
     }
+    hipLaunchKernelGGL(k_dg_restrict<8>, GRIDX((H.ncg * 8 + 255) / 256), dim3(256), 0, st, H.ncg, H.cg_ptr, H.cg_idx, r_dg, H.levels[0].b, r_stride, (H.ncol % 2 == 0) ? 2 : 1, t_dg, ct);
+    return amg_restrict_tail(c, H, st);
+}
+
+// the per-tile partial sums buffer [ncol][nslots] of the tile-wise restriction, sized at the first use
+int amg_restrict_tiles_prepare(knp_ctx* c, AmgHierarchy& H) {
+    if (H.ntiles <= 0) return -1;
+    if (!H.part || H.part_cols != H.ncol) {
+        hipFree(H.part);
+        H.part = nullptr;
+        HIPCHK(c, hipMalloc((void**)&H.part, sizeof(double) * (size_t)H.ncol * (size_t)(H.nslots ? H.nslots : 1)));
+        H.part_cols = H.ncol;
+    }
+    return 0;
+}
+
+// everything behind stage 1 of the tile-wise restriction (H.part filled by k_restrict_tiles or by the fused Chebyshev / restriction
+// kernel of krylov.hip): stage 2, the transfer-only finest level, the all-reduce of a partitioned run
+int amg_restrict_finish(knp_ctx* c, AmgHierarchy& H, hipStream_t on_stream) {
+    if (on_stream && c->dist) { c->err = "amg: the all-reduced restriction runs on the context's stream"; return -1; }
+    s_ncol = H.ncol;
+    struct Reset { ~Reset() { s_ncol = 1; } } reset_on_exit;
+    hipStream_t st = on_stream ? on_stream : c->stream;
+    hipLaunchKernelGGL(k_restrict_sum, GRIDX((H.ncg + 255) / 256), dim3(256), 0, st, H.ncg, H.part_ptr, H.part_idx,
+                       (const double*)H.part, H.nslots, H.levels[0].b, (H.ncol % 2 == 0) ? 2 : 1);
+    return amg_restrict_tail(c, H, st);
+}
+
+static int amg_restrict_tail_impl(knp_ctx* c, AmgHierarchy& H, hipStream_t st) {
     // multi-GPU: the conforming hierarchy is replicated on every rank; the restricted residual is the sum of the
     // ranks' owned-cell contributions (one all-reduce), after which every rank runs the same V-cycle.  When the finest
     // level is transfer-only (EMI) the restriction to level 1 is linear in b, so it is applied to the LOCAL vector first
@@ -520,6 +544,13 @@ int amg_restrict_from_dg(knp_ctx* c, AmgHierarchy& H, const double* r_dg, hipStr
     }
     if (c->dist) return allreduce_red(c, H.levels[0].b, (int)(H.ncg * H.ncol));
     return 0;
+}
+int amg_restrict_tail(knp_ctx* c, AmgHierarchy& H, hipStream_t st) {
+    const int keep = s_ncol;
+    s_ncol = H.ncol;
+    const int rc = amg_restrict_tail_impl(c, H, st);
+    s_ncol = keep;
+    return rc;
 }
 
 void amg_free(AmgHierarchy& H) {

@@ -44,6 +44,9 @@ struct AmgHierarchy {
 
 struct knp_ctx;
 int amg_vcycle(knp_ctx* c, AmgHierarchy& H, hipStream_t on_stream = nullptr);
+// stage 1 of the tile-wise restriction may be done by a fused kernel of krylov.hip: buffer first, the remaining stages afterwards
+int amg_restrict_tiles_prepare(knp_ctx* c, AmgHierarchy& H);
+int amg_restrict_finish(knp_ctx* c, AmgHierarchy& H, hipStream_t on_stream = nullptr);
 // restricts r_dg, or r_dg - ct * t_dg when t_dg is given
 int amg_restrict_from_dg(knp_ctx* c, AmgHierarchy& H, const double* r_dg, hipStream_t on_stream = nullptr, int64_t r_stride = 0,
                          const double* t_dg = nullptr, double ct = 0.0);

@@ -671,6 +671,44 @@ __global__ __launch_bounds__(KNP_BLOCK) void k_bj_cheb2(VecDims d, const int* __
     stv<NV>(SYS_PTR(y, s), c, yv);
 }
 
+// The same step fused with stage 1 of the tile-wise restriction of the coarse correction (amg.hip: k_restrict_tiles): both read r and
+// t = A Binv r, and the restricted vector r - ct t (hybrid form; ct = 0: r itself) is formed from the values already in registers.
+// One pass over r and t instead of two (128 MB per preconditioner application at r=2).  grid = (tiles, systems).
+template <int NV>
+__global__ __launch_bounds__(256) void k_bj_cheb2_restrict(VecDims d, const int* __restrict__ status, const bjreal* __restrict__ binv,
+                                                           const double* __restrict__ r, const double* __restrict__ t, double* __restrict__ y,
+                                                           double cr, double ctt, int tile_cells, const int32_t* __restrict__ tile_off,
+                                                           const int32_t* __restrict__ slot_ptr, const uint16_t* __restrict__ slot_idx,
+                                                           double* __restrict__ part, int64_t nslots, double ct) {
+    extern __shared__ double s_r[];
+    const int s = blockIdx.y;
+    if (status && status[2 * s]) return;                       // converged system: its V-cycle output is not used either
+    const int64_t c0 = (int64_t)blockIdx.x * tile_cells;
+    const int ncell = (int)((d.nc_owned - c0 < tile_cells) ? (d.nc_owned - c0) : tile_cells);
+    for (int i = threadIdx.x; i < ncell; i += 256) {
+        const int64_t c = c0 + i;
+        double rv[NV], tv[NV], yv[NV];
+        ldv<NV>(SYS_PTR(r, s), c, rv);
+        ldv<NV>(SYS_PTR(t, s), c, tv);
+#pragma unroll
+        for (int a = 0; a < NV; ++a) {
+            s_r[i * NV + a] = fma(-ct, tv[a], rv[a]);
+            rv[a] = cr * rv[a] - ctt * tv[a];
+        }
+        block_matvec<NV>(bj_block<NV>(d, binv, s, c), 0, rv, yv);
+        stv<NV>(SYS_PTR(y, s), c, yv);
+    }
+    __syncthreads();
+    part += (int64_t)s * nslots;
+    const int p1 = tile_off[blockIdx.x + 1];
+    for (int p = tile_off[blockIdx.x] + threadIdx.x; p < p1; p += 256) {
+        double acc = 0.0;
+        const int e = slot_ptr[p + 1];
+        for (int k = slot_ptr[p]; k < e; ++k) acc += s_r[slot_idx[k]];
+        part[p] = acc;
+    }
+}
+
 // out = alpha[s] * in  (per system)
 __global__ void k_scale_sys(int64_t n_owned, int64_t stride, const double* __restrict__ in, double a0, double a1, double a2, double a3,
                             double* __restrict__ out) {
@@ -835,19 +873,35 @@ template <bool EMI> static double bj_lmin_frac() {
 template <bool EMI> static double bj_theta(const KrylovVecs& kv) { return 0.5 * (1.0 + bj_lmin_frac<EMI>()) * kv.bj_lmax; }
 
 // y (= Binv r on entry) <- two-step Chebyshev block-Jacobi of r:  costs one operator apply and one fused vector kernel
+// Hfuse != null: the coarse correction's restriction of (r - ct_restrict t) into Hfuse is done in the same pass (k_bj_cheb2_restrict +
+// the remaining restriction stages); the caller then skips amg_restrict_from_dg
 template <int NV, bool EMI>
-static int bj_cheb2(knp_ctx* c, const VecDims& d, const KrylovVecs& kv, const double* r, double* y, bool use_status = true) {
+static int bj_cheb2(knp_ctx* c, const VecDims& d, const KrylovVecs& kv, const double* r, double* y, bool use_status = true,
+                    AmgHierarchy* Hfuse = nullptr, double ct_restrict = 0.0) {
     int rc;
     if ((rc = dist_apply(c, EMI ? 0 : 1, y, kv.coef, kv.tmp))) return rc;
     const double lmin_frac = bj_lmin_frac<EMI>();
     const double lmax = kv.bj_lmax, lmin = lmin_frac * lmax;
     const double theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin), sigma = theta / delta, rho0 = 1.0 / sigma;
     const double rho1 = 1.0 / (2.0 * sigma - rho0);
+    const double cr = (1.0 + rho1 * rho0) / theta + 2.0 * rho1 / delta, ctt = (2.0 * rho1 / delta) / theta;
+    const int* st = use_status ? (const int*)c->status : (const int*)nullptr;
+    if (Hfuse) {
+        AmgHierarchy& H = *Hfuse;
+        if ((rc = amg_restrict_tiles_prepare(c, H))) return rc;
+        hipLaunchKernelGGL(k_bj_cheb2_restrict<NV>, dim3((unsigned)H.ntiles, (unsigned)d.nsys), dim3(256), sizeof(double) * H.tile_cells * NV,
+                           c->stream, d, st, kv.binv, r, (const double*)kv.tmp, y, cr, ctt, H.tile_cells, (const int32_t*)H.tile_off,
+                           (const int32_t*)H.slot_ptr, (const uint16_t*)H.slot_idx, H.part, H.nslots, ct_restrict);
+        return amg_restrict_finish(c, H);
+    }
     const dim3 g((unsigned)grid_for(c->m.nc_owned), (unsigned)d.nsys), b(KNP_BLOCK);
-    hipLaunchKernelGGL(k_bj_cheb2<NV>, g, b, 0, c->stream, d, use_status ? (const int*)c->status : (const int*)nullptr, kv.binv, r,
-                       (const double*)kv.tmp, y,
-                       (1.0 + rho1 * rho0) / theta + 2.0 * rho1 / delta, (2.0 * rho1 / delta) / theta);
+    hipLaunchKernelGGL(k_bj_cheb2<NV>, g, b, 0, c->stream, d, st, kv.binv, r, (const double*)kv.tmp, y, cr, ctt);
     return 0;
+}
+// whether the second Chebyshev step and the restriction into H can share one pass (KNP_FUSE_RESTRICT=0: two passes, A/B runs)
+static bool fuse_restrict(const knp_ctx* c, const KrylovVecs& kv, const AmgHierarchy& H, int nsys) {
+    static const bool on = !(getenv("KNP_FUSE_RESTRICT") && atoi(getenv("KNP_FUSE_RESTRICT")) == 0);
+    return on && kv.bj_lmax > 0.0 && H.ready && H.ntiles > 0 && H.ncol == nsys && H.tile_cells * c->nd * sizeof(double) <= 65536;
 }
 
 // power iteration for lambda_max(Binv A) of the batched KNP operator (inf-norm normalisation; max over the species)
@@ -930,8 +984,12 @@ static int pcg_impl(knp_ctx* c, KrylovVecs& kv, double rtol, double atol, int ma
             hipLaunchKernelGGL(k_cg_update<NV>, g, b, 0, c->stream, d, c->scal, c->status, kv.p, kv.w, kv.binv, kv.x, kv.r, kv.z,
                                c->partial);
             if (H) {
-                if (kv.bj_lmax > 0.0 && (rc = bj_cheb2<NV, true>(c, d, kv, kv.r, kv.z))) return rc;
-                if ((rc = amg_restrict_from_dg(c, *H, kv.r))) return rc;
+                if (fuse_restrict(c, kv, *H, 1)) {
+                    if ((rc = bj_cheb2<NV, true>(c, d, kv, kv.r, kv.z, true, H, 0.0))) return rc;
+                } else {
+                    if (kv.bj_lmax > 0.0 && (rc = bj_cheb2<NV, true>(c, d, kv, kv.r, kv.z))) return rc;
+                    if ((rc = amg_restrict_from_dg(c, *H, kv.r))) return rc;
+                }
                 if ((rc = amg_vcycle(c, *H))) return rc;
                 hipLaunchKernelGGL((k_prolong_dot<NV, 3>), g, b, 0, c->stream, d, c->status, 1, H->dg2cg, H->levels[0].x, kv.r,
                                    kv.z, (const double*)nullptr, (double*)nullptr, c->partial);
@@ -970,7 +1028,8 @@ int pcg_solve(knp_ctx* c, KrylovVecs& kv, double rtol, double atol, int maxit, i
 // independent chains of tiny latency-bound kernels: species 0 runs on the context's stream, every further species
 // on its own auxiliary stream (fork / join with events), so the chains overlap.
 template <int NV>
-static int knp_coarse_correction(knp_ctx* c, const VecDims& d, const double* in, double* out, const double* t = nullptr, double ct = 0.0) {
+static int knp_coarse_correction(knp_ctx* c, const VecDims& d, const double* in, double* out, const double* t = nullptr, double ct = 0.0,
+                                 bool restricted = false) {
     const dim3 g1((unsigned)grid_for(c->m.nc_owned)), b(KNP_BLOCK);
     int active[KNP_MAX_SYS], na = 0;
     for (int s = 0; s < d.nsys; ++s)
@@ -980,7 +1039,7 @@ static int knp_coarse_correction(knp_ctx* c, const VecDims& d, const double* in,
     if (c->amg[1].ready && c->amg[1].ncol == d.nsys) {
         // shared hierarchy: one restriction, one V-cycle and one prolongation carry all species as right-hand-side columns
         AmgHierarchy& H = c->amg[1];
-        if ((rc = amg_restrict_from_dg(c, H, in, nullptr, d.nc * NV, t, ct))) return rc;
+        if (!restricted && (rc = amg_restrict_from_dg(c, H, in, nullptr, d.nc * NV, t, ct))) return rc;     // restricted: done by bj_cheb2's fused pass
         if ((rc = amg_vcycle(c, H))) return rc;
         if (d.nsys % 2 == 0)
             hipLaunchKernelGGL(k_prolong_add_pair<NV>, dim3(g1.x, (unsigned)(d.nsys / 2)), b, 0, c->stream, d, c->status, H.dg2cg,
@@ -1060,15 +1119,16 @@ static int bicgstab_impl(knp_ctx* c, KrylovVecs& kv, double rtol, double atol, i
             hipLaunchKernelGGL(k_bi_p<NV>, g, b, 0, c->stream, d, c->scal, c->status, kv.r, kv.v, kv.binv, kv.p, kv.y);
             const bool hyb = kv.bj_lmax > 0.0 && knp_hybrid();
             const double ct = hyb ? 1.0 / bj_theta<false>(kv) : 0.0;
-            if (kv.bj_lmax > 0.0 && (rc = bj_cheb2<NV, false>(c, d, kv, kv.p, kv.y))) return rc;
-            if ((rc = knp_coarse_correction<NV>(c, d, kv.p, kv.y, hyb ? kv.tmp : nullptr, ct))) return rc;
+            const bool fuse = (int)c->amg.size() > 1 && fuse_restrict(c, kv, c->amg[1], ns);
+            if (kv.bj_lmax > 0.0 && (rc = bj_cheb2<NV, false>(c, d, kv, kv.p, kv.y, true, fuse ? &c->amg[1] : nullptr, ct))) return rc;
+            if ((rc = knp_coarse_correction<NV>(c, d, kv.p, kv.y, hyb ? kv.tmp : nullptr, ct, fuse))) return rc;
             if ((rc = dist_apply(c, 1, kv.y, kv.coef, kv.v))) return rc;
             hipLaunchKernelGGL(k_dot2<NV>, g, b, 0, c->stream, d, kv.rhat, kv.v, (const double*)nullptr, (const double*)nullptr,
                                c->partial, c->status);
             if ((rc = finalize(c, OP_BI_ALPHA, ns, 1, rtol, atol, min_it))) return rc;
             hipLaunchKernelGGL(k_bi_s<NV>, g, b, 0, c->stream, d, c->scal, c->status, kv.v, kv.binv, kv.r, kv.z);
-            if (kv.bj_lmax > 0.0 && (rc = bj_cheb2<NV, false>(c, d, kv, kv.r, kv.z))) return rc;
-            if ((rc = knp_coarse_correction<NV>(c, d, kv.r, kv.z, hyb ? kv.tmp : nullptr, ct))) return rc;
+            if (kv.bj_lmax > 0.0 && (rc = bj_cheb2<NV, false>(c, d, kv, kv.r, kv.z, true, fuse ? &c->amg[1] : nullptr, ct))) return rc;
+            if ((rc = knp_coarse_correction<NV>(c, d, kv.r, kv.z, hyb ? kv.tmp : nullptr, ct, fuse))) return rc;
             if ((rc = dist_apply(c, 1, kv.z, kv.coef, kv.w))) return rc;
             hipLaunchKernelGGL(k_dot2<NV>, g, b, 0, c->stream, d, kv.w, kv.r, kv.w, kv.w, c->partial, c->status);
             if ((rc = finalize(c, OP_BI_OMEGA, ns, 2, rtol, atol, min_it))) return rc;
@@ -1237,8 +1297,9 @@ static int gmres_impl(knp_ctx* c, KrylovVecs& kv, double rtol, double atol, int 
         if (slot >= 0) hipLaunchKernelGGL(k_gm_scale_binv<NV>, g, b, 0, c->stream, d, (const int*)c->status, (const double*)c->scal, slot, kv.binv, in, out);
         else hipLaunchKernelGGL(k_gm_binv<NV>, g, b, 0, c->stream, d, (const int*)c->status, kv.binv, (const double*)in, out);
         int r;
-        if (kv.bj_lmax > 0.0 && (r = bj_cheb2<NV, false>(c, d, kv, in, out))) return r;
-        return knp_coarse_correction<NV>(c, d, in, out, hyb ? kv.tmp : nullptr, ct);
+        const bool fuse = (int)c->amg.size() > 1 && fuse_restrict(c, kv, c->amg[1], ns);
+        if (kv.bj_lmax > 0.0 && (r = bj_cheb2<NV, false>(c, d, kv, in, out, true, fuse ? &c->amg[1] : nullptr, ct))) return r;
+        return knp_coarse_correction<NV>(c, d, in, out, hyb ? kv.tmp : nullptr, ct, fuse);
     };
     // r = b - A x into V_0 (unnormalised), norms of the true residual -> convergence test / next cycle
     auto residual = [&](int op) -> int {
