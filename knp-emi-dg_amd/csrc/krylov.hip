@@ -900,7 +900,8 @@ static int bj_cheb2(knp_ctx* c, const VecDims& d, const KrylovVecs& kv, const do
 }
 // whether the second Chebyshev step and the restriction into H can share one pass (KNP_FUSE_RESTRICT=0: two passes, A/B runs)
 static bool fuse_restrict(const knp_ctx* c, const KrylovVecs& kv, const AmgHierarchy& H, int nsys) {
-    static const bool on = !(getenv("KNP_FUSE_RESTRICT") && atoi(getenv("KNP_FUSE_RESTRICT")) == 0);
+    const char* e = getenv("KNP_FUSE_RESTRICT");            // read per call: tests switch it inside one process
+    const bool on = !(e && atoi(e) == 0);
     return on && kv.bj_lmax > 0.0 && H.ready && H.ntiles > 0 && H.ncol == nsys && H.tile_cells * c->nd * sizeof(double) <= 65536;
 }
 

@@ -174,6 +174,33 @@ def test_active_time_loop(hip_lib, dim, degree):
     assert abs(float(t) - 3e-4) < 1e-12
 
 
+def test_fused_chebyshev_restriction_equals_two_passes(hip_lib, monkeypatch):
+    """The second Chebyshev block-Jacobi step fused with stage 1 of the tile-wise restriction (k_bj_cheb2_restrict, default) against
+    the two separate kernels (KNP_FUSE_RESTRICT=0): same preconditioner, so the same iteration counts and, to rounding, the same
+    fields after three stimulated steps of the 4-axon mesh with its AMG hierarchies (PCG for EMI, BiCGStab and GMRES for KNP)."""
+    from idealized_common import make_solver, solver_parameters, Constant
+    out = {}
+    for krylov in ("bicgstab", "gmres"):
+        for fused in ("1", "0"):
+            monkeypatch.setenv("KNP_FUSE_RESTRICT", fused)
+            S = make_solver(dim=3, resolution=0, n_axons=4)
+            S._unpack_solver_params(solver_parameters(3, 0))
+            S.save_fields = S.save_solver_stats = False
+            S.splitting_scheme = True
+            S.setup_varform_emi(); S.setup_varform_knp(); S.setup_solver_emi(); S.setup_solver_knp()
+            S.dev.set_knp_krylov(krylov)
+            assert S.use_amg
+            t = Constant(0.0)
+            for k in range(3):
+                S.step_membrane_models(k)
+                S.solve_for_time_step(k, t)
+            out[(krylov, fused)] = (S.phi.array().copy(), S.c.array().copy(), list(S.emi_niter), [list(n) for n in S.knp_niter])
+            S.dev.close()
+        a, b = out[(krylov, "1")], out[(krylov, "0")]
+        assert a[2] == b[2] and a[3] == b[3], (a[2:], b[2:])
+        assert relerr(a[0], b[0]) < 1e-10 and relerr(a[1], b[1]) < 1e-12
+
+
 def test_amg_vcycle_matches_reference_and_cuts_iterations(hip_lib):
     """Auxiliary-space AMG: (1) Ac assembled by knpemidg.amg equals P^T A P of the oracle matrix; (2) PCG with the
     device V-cycle converges to the same phi in far fewer iterations than block-Jacobi alone."""
