@@ -270,7 +270,7 @@ def _scale_rows(A, v):
     return sp.csr_matrix((A.data * np.repeat(v, np.diff(A.indptr)), A.indices, A.indptr), shape=A.shape)
 
 
-def build_hierarchy(A, theta=0.08, max_coarse=4000, max_levels=12, cheb_degree=2, cheb_lower=0.3, psmooth=2, trunc=0.04,
+def build_hierarchy(A, theta=0.08, max_coarse=4000, max_levels=12, cheb_degree=None, cheb_lower=0.3, psmooth=2, trunc=0.04,
                     top_interp=None, top_degree=2, top_lower=0.1, level0_degree=None):
     """Smoothed-aggregation hierarchy for an SPD (possibly singular, constants) matrix.
     Each level: A (csr), dinv, rho = spectral radius estimate of D^-1 A, P (csr, to the next level).
@@ -278,6 +278,13 @@ def build_hierarchy(A, theta=0.08, max_coarse=4000, max_levels=12, cheb_degree=2
     ConformingSpaceP2.interp); aggregation starts below it."""
     import os
     theta = float(os.environ.get("KNP_AMG_THETA", theta))
+    # smoother degree of the aggregated levels: 1 since round 3 (with the cheaper applies and the fused restriction the V-cycle is a third
+    # of a step; degree 1 instead of 2 takes two SpMV kernels out of every level visit and costs no iterations: r=2 8.23 -> 7.85 ms/step,
+    # EMI 6.55 -> 6.35 / KNP 5.7 -> 5.75 iterations, degree 3 8.41; profiles/r03_amg_degree_sweep.txt).  The DG-P2 hierarchies (top_interp)
+    # keep degree 2: with degree 1 the P2 configuration steps 4 % faster, but its EMI solve meets the stopping test on the preconditioned
+    # norm after two iterations with 1.35e-6 left in the concentrations (test_production_tolerances_r1_against_tight_solves[2])
+    if cheb_degree is None:
+        cheb_degree = 1 if top_interp is None else 2
     cheb_degree = int(os.environ.get("KNP_AMG_DEGREE", cheb_degree))
     cheb_lower = float(os.environ.get("KNP_AMG_LOWER", cheb_lower))
     max_coarse = int(os.environ.get("KNP_AMG_MAXCOARSE", max_coarse))
