@@ -424,7 +424,11 @@ def build_emi_levels(cspace, cspace2, facet_tags, membrane_tags, kappa, C_phi):
         # tentative prolongator (PCG iterations at r=2: 68 / 17 / 8 for 1 / 2 / 3 steps; on the conforming problem alone two
         # steps lose mesh independence, 12 -> 24 from r=1 to r=2, three do not); no smoother on the finest conforming level
         # (same iteration count with or without it: block-Jacobi on the DG space does that job)
-        return build_hierarchy(Ac, psmooth=psmooth, level0_degree=int(os.environ.get("KNP_AMG_DEGREE0_EMI", 0)))
+        # finest conforming level: ONE damped-Jacobi step before / after (round 3; rounds 1-2: transfer-only).  With the round-3 kernel costs
+        # the extra level-0 kernels are cheap against what they save: r=2 EMI 6.35 -> 4.25 PCG iterations (7.85 -> 7.43 ms/step), r=3 8.6 ->
+        # 6.8, and on the unstructured EMIx reconstruction 32.3 -> 11.7 (8.04 -> 5.94 ms/step); two steps buy nothing more
+        # (profiles/r03_amg_degree_sweep.txt).  A partitioned run then all-reduces the level-0 restricted residual (as KNP does).
+        return build_hierarchy(Ac, psmooth=psmooth, level0_degree=int(os.environ.get("KNP_AMG_DEGREE0_EMI", 1)))
     # DG-P2: auxiliary space = conforming P2 (block-Jacobi over-weights continuous quadratics by the penalty factor); the
     # conforming P1 space is its first coarse level, aggregation starts below
     Ac = cspace2.stiffness(kappa, membrane=(mem, float(C_phi)))
