@@ -193,6 +193,18 @@ int knp_amg_level(knp_ctx* ctx, int which, int64_t n, const int32_t* rowptrA, co
                   const int32_t* rowptrR, const int32_t* colR, const double* valR);
 int knp_amg_finish(knp_ctx* ctx, int which, int64_t n, const double* pinv);
 int knp_amg_clear(knp_ctx* ctx, int which);
+/* Partitioned runs: ROW-DISTRIBUTED finest conforming level (the reference's BoomerAMG is row-distributed on every level under MPI,
+ * src/knpemidg/solver.py:433, 688, with PETSc's VecScatter behind MatMult, :529, :789).  Each rank holds the conforming dofs of its own
+ * cells (+ of the membrane facets assigned to it) in local numbering and the level-0 matrix SUB-ASSEMBLED from those cells / facets, so
+ * that a product is a per-rank partial sum; partial sums at dofs shared by several ranks are exchanged point to point
+ * (2 messages per peer) and added in rank order.  Levels >= 1 stay replicated behind ONE all-reduce of the level-1 residual per V-cycle.
+ *  knp_amg_interface: the shared-dof tables (every rank of the communicator calls it, once per conforming space): peers[p] shares
+ *                     counts[p] dofs; idx = their local numbers grouped by peer, ascending global dof within a peer; uvtx / aptr / asrc:
+ *                     per distinct shared dof the message positions of its other owners in ascending rank order, -1 = own value.
+ *  knp_amg_dist0    : between knp_amg_begin and the first knp_amg_level of a hierarchy uploaded in that local form. */
+int knp_amg_interface(knp_ctx* ctx, int64_t n_local, int npeers, const int32_t* peers, const int64_t* counts, const int32_t* idx,
+                      int64_t nuniq, const int32_t* uvtx, const int32_t* aptr, const int32_t* asrc);
+int knp_amg_dist0(knp_ctx* ctx, int which);
 
 /* ---- step III (solver.py:808-845) -------------------------------------------------------------
  * C_PREV <- C ; PHI_M <- facet-avg(phi_i - phi_e) ; C_ELIM <- -(sum z_k c_k + rho)/z_N ; E <- Nernst. */

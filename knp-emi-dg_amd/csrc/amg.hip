@@ -420,12 +420,12 @@ static void smooth(knp_ctx* c, AmgLevel& L, bool zero_guess, bool first_done = f
 }
 
 // x_0 = V(b_0) ; level vectors b/x of level 0 are filled / read by the caller
-static int amg_vcycle_eager(knp_ctx* c, AmgHierarchy& H) {
+static int amg_vcycle_eager(knp_ctx* c, AmgHierarchy& H, int l0 = 0) {
     const int nl = (int)H.levels.size();
     s_ncol = H.ncol;
     struct Reset { ~Reset() { s_ncol = 1; } } reset_on_exit;
     bool first_done = false;
-    for (int l = 0; l < nl - 1; ++l) {
+    for (int l = l0; l < nl - 1; ++l) {
         AmgLevel& L = H.levels[l];
         if (L.cheb_degree == 0) {                                    // transfer-only level: x = 0, r = b
             // level 0: amg_restrict_from_dg already went down to level 1 (outside the captured graph, see there)
@@ -447,7 +447,7 @@ static int amg_vcycle_eager(knp_ctx* c, AmgHierarchy& H) {
         hipLaunchKernelGGL(k_dense_mv<2>, dim3((unsigned)C.n, (unsigned)(H.ncol / 2)), dim3(256), 0, c->stream, (int)C.n, (const float*)H.pinv, C.b, C.x);
     else
         hipLaunchKernelGGL(k_dense_mv<1>, dim3((unsigned)C.n, (unsigned)H.ncol), dim3(256), 0, c->stream, (int)C.n, (const float*)H.pinv, C.b, C.x);
-    for (int l = nl - 2; l >= 0; --l) {
+    for (int l = nl - 2; l >= l0; --l) {
         AmgLevel& L = H.levels[l];
         if (L.cheb_degree == 0) {
             launch_csr<0>(c, L.P, H.levels[l + 1].x, nullptr, L.x);  // x = P x_{l+1}
@@ -462,14 +462,14 @@ static int amg_vcycle_eager(knp_ctx* c, AmgHierarchy& H) {
 
 // The V-cycle is ~40 tiny launch-bound kernels on fixed buffers: capture it once into a hipGraph and replay it
 // (kernel boundaries ~1.5 us instead of ~5 us of eager launch latency each).
-int amg_vcycle(knp_ctx* c, AmgHierarchy& H, hipStream_t on_stream) {
+static int amg_vcycle_levels(knp_ctx* c, AmgHierarchy& H, int l0, hipStream_t on_stream) {
     static const bool use_graph = !(getenv("KNP_NO_GRAPH") && atoi(getenv("KNP_NO_GRAPH")));
     if (use_graph && !H.graph_tried) {
         H.graph_tried = true;
         hipGraph_t graph = nullptr;
         hipGraphExec_t exec = nullptr;
         if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-            const int rc = amg_vcycle_eager(c, H);
+            const int rc = amg_vcycle_eager(c, H, l0);
             const hipError_t e = hipStreamEndCapture(c->stream, &graph);
             if (rc == 0 && e == hipSuccess && graph && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess)
                 H.graph_exec = exec;
@@ -484,7 +484,97 @@ int amg_vcycle(knp_ctx* c, AmgHierarchy& H, hipStream_t on_stream) {
         HIPCHK(c, hipGraphLaunch((hipGraphExec_t)H.graph_exec, on_stream ? on_stream : c->stream));
         return 0;
     }
-    return amg_vcycle_eager(c, H);      // eager fallback always runs on the context's stream
+    return amg_vcycle_eager(c, H, l0);  // eager fallback always runs on the context's stream
+}
+
+// ---- row-distributed level 0 (partitioned runs) ---------------------------------------------------------------------------------------
+// Vectors on level 0 come in two kinds (the usual bookkeeping of non-overlapping domain decomposition): ACCUMULATED -- every rank that
+// has a shared dof holds its full value (x, the smoother's d, the accumulated residual) -- and DISTRIBUTED -- every rank holds the
+// part its own cells / facets contributed (the restricted DG residual b, and every product with the sub-assembled matrix).  A product
+// needs no communication; turning its result into an accumulated vector is one interface exchange (interface_accumulate); the
+// restriction to the replicated level 1 is a per-rank partial sum behind one all-reduce of n_1 values (29 k at r=2, 6.5x fewer than the
+// level-0 vector the replicated design all-reduced).  Arithmetic per dof is that of smooth() / amg_vcycle_eager on the global level.
+__global__ void k_l0_first_nz(int64_t n, int nil, const double* __restrict__ dinv, const double* __restrict__ r, double inv_theta,
+                              double* __restrict__ d, double* __restrict__ x) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * nil) return;
+    const int64_t o = (int64_t)blockIdx.y * n * nil;
+    const double v = dinv[i / nil] * r[o + i] * inv_theta;
+    d[o + i] = v;
+    x[o + i] += v;
+}
+
+// r -= t (t = accumulated A d) ;  d = c1 d + c2 dinv r ;  x += d
+__global__ void k_l0_step(int64_t n, int nil, const double* __restrict__ dinv, const double* __restrict__ t, double c1, double c2,
+                          double* __restrict__ r, double* __restrict__ d, double* __restrict__ x) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * nil) return;
+    const int64_t o = (int64_t)blockIdx.y * n * nil;
+    const double rn = r[o + i] - t[o + i];
+    const double dn = fma(c1, d[o + i], c2 * dinv[i / nil] * rn);
+    r[o + i] = rn;
+    d[o + i] = dn;
+    x[o + i] += dn;
+}
+
+static int dist0_smooth(knp_ctx* c, AmgHierarchy& H, bool zero_guess) {
+    AmgLevel& L = H.levels[0];
+    const int nil = (s_ncol % 2 == 0) ? 2 : 1;
+    const dim3 g((unsigned)((L.n * nil + 255) / 256), (unsigned)(s_ncol / nil));
+    const double lmax = L.rho, lmin = L.cheb_lower * L.rho;
+    const double theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin), sigma = theta / delta;
+    double rho = 1.0 / sigma;
+    int rc;
+    if (zero_guess) {                                                // r = acc(b) ; d = x = dinv r / theta
+        HIPCHK(c, hipMemcpyAsync(H.t0, L.b, sizeof(double) * (size_t)L.n * s_ncol, hipMemcpyDeviceToDevice, c->stream));
+        if ((rc = interface_accumulate(c, H.t0, L.n, s_ncol))) return rc;
+        hipLaunchKernelGGL(k_cheb_first, g, dim3(256), 0, c->stream, L.n, nil, L.dinv, (const double*)H.t0, 1.0 / theta, L.r, L.d0, L.x);
+    } else {                                                         // r = acc(b - A x) ; d = dinv r / theta ; x += d
+        launch_csr<1>(c, L.A, L.x, L.b, L.r);
+        if ((rc = interface_accumulate(c, L.r, L.n, s_ncol))) return rc;
+        hipLaunchKernelGGL(k_l0_first_nz, g, dim3(256), 0, c->stream, L.n, nil, L.dinv, (const double*)L.r, 1.0 / theta, L.d0, L.x);
+    }
+    for (int k = 1; k < L.cheb_degree; ++k) {
+        const double rho_new = 1.0 / (2.0 * sigma - rho);
+        launch_csr<0>(c, L.A, L.d0, nullptr, H.t0);
+        if ((rc = interface_accumulate(c, H.t0, L.n, s_ncol))) return rc;
+        hipLaunchKernelGGL(k_l0_step, g, dim3(256), 0, c->stream, L.n, nil, L.dinv, (const double*)H.t0, rho_new * rho, 2.0 * rho_new / delta,
+                           L.r, L.d0, L.x);
+        rho = rho_new;
+    }
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
+static int amg_vcycle_dist0(knp_ctx* c, AmgHierarchy& H) {
+    if (H.levels.size() < 2) { c->err = "amg: a distributed level 0 needs a coarser level"; return -1; }
+    s_ncol = H.ncol;
+    struct Reset { ~Reset() { s_ncol = 1; } } reset_on_exit;
+    AmgLevel& L = H.levels[0];
+    AmgLevel& N = H.levels[1];
+    if (!H.t0) HIPCHK(c, hipMalloc((void**)&H.t0, sizeof(double) * (size_t)(L.n ? L.n : 1) * (size_t)H.ncol));
+    int rc;
+    if (L.cheb_degree > 0) {
+        if ((rc = dist0_smooth(c, H, true))) return rc;
+        launch_csr<1>(c, L.A, L.x, L.b, L.r);                        // distributed residual b - A x
+        launch_csr<0>(c, L.R, L.r, nullptr, N.b);                    // this rank's part of the level-1 right-hand side
+        if ((rc = allreduce_red(c, N.b, (int)(N.n * H.ncol)))) return rc;
+    }                                                                // (transfer-only: amg_restrict_tail went down to level 1 already)
+    if ((rc = amg_vcycle_levels(c, H, 1, nullptr))) return rc;
+    s_ncol = H.ncol;
+    if (L.cheb_degree == 0) {
+        launch_csr<0>(c, L.P, N.x, nullptr, L.x);
+        HIPCHK(c, hipGetLastError());
+        return 0;
+    }
+    launch_csr<2>(c, L.P, N.x, nullptr, L.x);
+    return dist0_smooth(c, H, false);
+}
+
+int amg_vcycle(knp_ctx* c, AmgHierarchy& H, hipStream_t on_stream) {
+    if (!H.dist0) return amg_vcycle_levels(c, H, 0, on_stream);
+    if (on_stream && on_stream != c->stream) { c->err = "amg: the distributed level 0 runs on the context's stream"; return -1; }
+    return amg_vcycle_dist0(c, H);
 }
 
 int amg_restrict_tail(knp_ctx* c, AmgHierarchy& H, hipStream_t st);
@@ -542,8 +632,8 @@ static int amg_restrict_tail_impl(knp_ctx* c, AmgHierarchy& H, hipStream_t st) {
         if (c->dist) return allreduce_red(c, H.levels[1].b, (int)(H.levels[1].n * H.ncol));
         return 0;
     }
-    if (c->dist) return allreduce_red(c, H.levels[0].b, (int)(H.ncg * H.ncol));
-    return 0;
+    if (c->dist && !H.dist0) return allreduce_red(c, H.levels[0].b, (int)(H.ncg * H.ncol));
+    return 0;                                                       // dist0: b stays the rank's partial sums (amg_vcycle_dist0)
 }
 int amg_restrict_tail(knp_ctx* c, AmgHierarchy& H, hipStream_t st) {
     const int keep = s_ncol;
@@ -565,6 +655,7 @@ void amg_free(AmgHierarchy& H) {
     H.ncol = 1;
     hipFree(H.pinv); hipFree(H.dg2cg); hipFree(H.cg_ptr); hipFree(H.cg_idx);
     H.pinv = nullptr; H.dg2cg = nullptr; H.cg_ptr = nullptr; H.cg_idx = nullptr;
+    hipFree(H.t0); H.t0 = nullptr; H.dist0 = false;
     hipFree(H.tile_off); hipFree(H.slot_ptr); hipFree(H.slot_idx); hipFree(H.part_ptr); hipFree(H.part_idx); hipFree(H.part);
     H.tile_off = H.slot_ptr = H.part_ptr = H.part_idx = nullptr; H.slot_idx = nullptr; H.part = nullptr;
     H.ntiles = H.nslots = 0; H.part_cols = 0;
@@ -675,6 +766,17 @@ int knp_amg_finish(knp_ctx* c, int which, int64_t n, const double* pinv) {
     int rc = up(c, &H->pinv, p32.data(), p32.size());
     H->ready = (rc == 0);
     return rc;
+}
+
+// Marks hierarchy `which` as carrying a ROW-DISTRIBUTED level 0 (between knp_amg_begin and the first knp_amg_level): ncg, dg2cg and the
+// level-0 matrices are this rank's rows in local numbering, A sub-assembled from its own cells / facets (knp_amg_interface first).
+int knp_amg_dist0(knp_ctx* c, int which) {
+    if (!c) return -1;
+    AmgHierarchy* H = amg_slot(c, which);
+    if (!H || !H->levels.empty()) { c->err = "amg: dist0 must be set after begin and before the first level"; return -1; }
+    if (!c->dist) { c->err = "amg: a distributed level 0 needs a communicator"; return -1; }
+    H->dist0 = true;
+    return 0;
 }
 
 int knp_amg_columns(knp_ctx* c, int which, int ncol) {

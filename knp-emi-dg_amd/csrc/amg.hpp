@@ -38,7 +38,12 @@ struct AmgHierarchy {
     int part_cols = 0;
     std::vector<AmgLevel> levels;
     float* pinv = nullptr;          // dense pseudo-inverse of the coarsest level (fp32 storage)
-    void* graph_exec = nullptr;     // hipGraphExec_t of one V-cycle (fixed kernel sequence on fixed buffers)
+    // Partitioned runs: level 0 holds THIS RANK'S rows only (the conforming dofs of its owned cells + of the membrane facets assigned to it,
+    // local numbering), its matrix sub-assembled from those cells / facets: products are per-rank partial sums, made consistent at the
+    // shared dofs by interface_accumulate (comm.hip); levels >= 1 stay replicated behind one all-reduce of the level-1 residual
+    bool dist0 = false;
+    double* t0 = nullptr;           // [ncol][n_0] work vector of the distributed level
+    void* graph_exec = nullptr;     // hipGraphExec_t of one V-cycle (fixed kernel sequence on fixed buffers; dist0: levels >= 1)
     bool graph_tried = false;
 };
 

@@ -37,6 +37,9 @@ void comm_destroy(knp_ctx* c) {
     if (c->halo_stream) { hipStreamDestroy(c->halo_stream); c->halo_stream = nullptr; }
     if (c->halo_ready) { hipEventDestroy(c->halo_ready); c->halo_ready = nullptr; }
     if (c->halo_done) { hipEventDestroy(c->halo_done); c->halo_done = nullptr; }
+    hipFree(c->if_idx); hipFree(c->if_uvtx); hipFree(c->if_aptr); hipFree(c->if_asrc); hipFree(c->if_send); hipFree(c->if_recv);
+    c->if_idx = c->if_uvtx = c->if_aptr = c->if_asrc = nullptr;
+    c->if_send = c->if_recv = nullptr;
 }
 
 static int shm_allreduce(knp_ctx* c, double* dev, int count, bool is_max);
@@ -86,7 +89,7 @@ static int halo_exchange_on(knp_ctx* c, double* v, int nfields, hipStream_t st, 
 // tables, pack / unpack, all-reduced Krylov scalars and restricted residuals, replicated hierarchies, membrane facets on a cut) with
 // 2..4 ranks on a one-GPU box against the single-rank solution (tests/test_gpu_multirank.py).  Every transfer is staged through the
 // host and every step ends in a barrier, so it is slow by construction and never the measured path.
-// Segment layout: header | per rank { directory[SHM_MAX_PEERS] | reduce slot [red_cap doubles] | outbox [out_cap doubles] }.
+// Segment layout: header | per rank { 2 directories[SHM_MAX_PEERS] | reduce slot [red_cap doubles] | outbox [out_cap doubles] }.
 // ---------------------------------------------------------------------------------------------------------------------------
 #define SHM_MAX_PEERS 64
 struct ShmHeader {
@@ -105,8 +108,9 @@ struct ShmComm {
     std::vector<double> tmp;
     ShmHeader* hdr() const { return reinterpret_cast<ShmHeader*>(base); }
     char* rank_base(int r) const { return base + 4096 + (size_t)r * rank_stride; }
-    ShmDirEntry* dir(int r) const { return reinterpret_cast<ShmDirEntry*>(rank_base(r)); }
-    double* red(int r) const { return reinterpret_cast<double*>(rank_base(r) + sizeof(ShmDirEntry) * SHM_MAX_PEERS); }
+    ShmDirEntry* dir(int r) const { return reinterpret_cast<ShmDirEntry*>(rank_base(r)); }                   // cell halo messages
+    ShmDirEntry* dir_if(int r) const { return dir(r) + SHM_MAX_PEERS; }                                      // interface-dof messages
+    double* red(int r) const { return reinterpret_cast<double*>(rank_base(r) + sizeof(ShmDirEntry) * 2 * SHM_MAX_PEERS); }
     double* out(int r) const { return red(r) + red_cap; }
 };
 
@@ -180,6 +184,88 @@ static int shm_halo_exchange(knp_ctx* c, double* v, int nfields, hipStream_t st)
     }
     HIPCHK(c, hipStreamSynchronize(st));
     return shm_barrier(c, s);                                          // outboxes may be refilled
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Interface exchange of the row-distributed conforming level (amg.hip: dist0).  Message p carries this rank's partial sums at the dofs
+// it shares with peer p ([position][column]); both sides list those dofs in ascending global order, so what arrives from p has the
+// layout of what was sent to p.  k_if_add then forms, per shared dof, the sum over ALL its owners in ascending rank order -- every
+// owner gets the same bits.  Messages: r=2 mesh, 8 slabs: ~3 k dofs x 8 B x columns per peer, i.e. latency only.
+// ---------------------------------------------------------------------------------------------------------------------------
+__global__ void k_if_pack(const double* __restrict__ v, const int32_t* __restrict__ idx, int64_t total, int64_t n, int ncol, int nil,
+                          double* __restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total * ncol) return;
+    const int64_t i = t / ncol;
+    const int j = (int)(t % ncol);
+    out[t] = v[((int64_t)(j / nil) * n + idx[i]) * nil + (j % nil)];
+}
+
+__global__ void k_if_add(double* __restrict__ v, const int32_t* __restrict__ uvtx, const int32_t* __restrict__ aptr,
+                         const int32_t* __restrict__ asrc, const double* __restrict__ recv, int64_t nuniq, int64_t n, int ncol, int nil) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nuniq * ncol) return;
+    const int64_t u = t / ncol;
+    const int j = (int)(t % ncol);
+    const int64_t q = ((int64_t)(j / nil) * n + uvtx[u]) * nil + (j % nil);
+    const double own = v[q];
+    double s = 0.0;
+    for (int k = aptr[u]; k < aptr[u + 1]; ++k) {
+        const int src = asrc[k];
+        s += src < 0 ? own : recv[(int64_t)src * ncol + j];
+    }
+    v[q] = s;
+}
+
+static int shm_interface_exchange(knp_ctx* c, int ncol) {
+    ShmComm* s = (ShmComm*)c->shm;
+    if ((uint64_t)(c->if_total * ncol) > s->out_cap) { c->err = "shm communicator: outbox too small for the interface exchange (KNP_SHM_OUT_DOUBLES)"; return -6; }
+    if (c->if_total)
+        HIPCHK(c, hipMemcpyAsync(s->out(s->rank), c->if_send, sizeof(double) * c->if_total * ncol, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    int rc;
+    if ((rc = shm_barrier(c, s))) return rc;
+    for (size_t p = 0; p < c->if_peer.size(); ++p) {
+        const int peer = c->if_peer[p];
+        const ShmDirEntry* d = s->dir_if(peer);
+        int64_t off = -1;
+        for (int k = 0; k < SHM_MAX_PEERS; ++k)
+            if (d[k].peer == s->rank && d[k].cnt > 0) {
+                if (d[k].cnt != c->if_cnt[p]) { c->err = "shm interface exchange: the peer shares a different number of dofs"; return -6; }
+                off = d[k].off; break;
+            }
+        if (off < 0) { c->err = "shm interface exchange: the peer lists no dofs shared with this rank"; return -6; }
+        HIPCHK(c, hipMemcpyAsync(c->if_recv + c->if_off[p] * ncol, s->out(peer) + off * ncol, sizeof(double) * c->if_cnt[p] * ncol,
+                                 hipMemcpyHostToDevice, c->stream));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return shm_barrier(c, s);                                          // outboxes may be refilled
+}
+
+int interface_accumulate(knp_ctx* c, double* v, int64_t n, int ncol) {
+    if (!c->dist) return 0;
+    if (ncol < 1 || ncol > KNP_MAX_SYS) { c->err = "interface exchange: bad column count"; return -1; }
+    const int nil = (ncol % 2 == 0) ? 2 : 1;
+    if (c->if_total)
+        hipLaunchKernelGGL(k_if_pack, dim3((unsigned)((c->if_total * ncol + 255) / 256)), dim3(256), 0, c->stream, (const double*)v,
+                           (const int32_t*)c->if_idx, c->if_total, n, ncol, nil, c->if_send);
+    if (c->shm) {                                                      // every rank takes part in the barriers, with or without peers
+        int rc = shm_interface_exchange(c, ncol);
+        if (rc) return rc;
+    } else if (!c->if_peer.empty()) {
+        if (!c->comm) { c->err = "interface exchange without communicator"; return -6; }
+        NCCLCHK(c, ncclGroupStart());
+        for (size_t p = 0; p < c->if_peer.size(); ++p) {
+            NCCLCHK(c, ncclSend(c->if_send + c->if_off[p] * ncol, (size_t)(c->if_cnt[p] * ncol), ncclDouble, c->if_peer[p], (ncclComm_t)c->comm, c->stream));
+            NCCLCHK(c, ncclRecv(c->if_recv + c->if_off[p] * ncol, (size_t)(c->if_cnt[p] * ncol), ncclDouble, c->if_peer[p], (ncclComm_t)c->comm, c->stream));
+        }
+        NCCLCHK(c, ncclGroupEnd());
+    }
+    if (c->if_nuniq)
+        hipLaunchKernelGGL(k_if_add, dim3((unsigned)((c->if_nuniq * ncol + 255) / 256)), dim3(256), 0, c->stream, v, (const int32_t*)c->if_uvtx,
+                           (const int32_t*)c->if_aptr, (const int32_t*)c->if_asrc, (const double*)c->if_recv, c->if_nuniq, n, ncol, nil);
+    HIPCHK(c, hipGetLastError());
+    return 0;
 }
 
 static void shm_destroy(knp_ctx* c) {
@@ -343,7 +429,7 @@ int knp_comm_init_shm(knp_ctx* c, int rank, int nranks, const char* name, int64_
     if (c->comm || c->shm) { c->err = "communicator already initialised"; return -1; }
     ShmComm* s = new ShmComm();
     s->rank = rank; s->nranks = nranks; s->red_cap = (uint64_t)red_doubles; s->out_cap = (uint64_t)out_doubles;
-    s->rank_stride = ((sizeof(ShmDirEntry) * SHM_MAX_PEERS + sizeof(double) * (s->red_cap + s->out_cap) + 4095) / 4096) * 4096;
+    s->rank_stride = ((sizeof(ShmDirEntry) * 2 * SHM_MAX_PEERS + sizeof(double) * (s->red_cap + s->out_cap) + 4095) / 4096) * 4096;
     s->bytes = 4096 + s->rank_stride * (size_t)nranks;
     int fd = -1;
     if (rank == 0) {
@@ -374,7 +460,7 @@ int knp_comm_init_shm(knp_ctx* c, int rank, int nranks, const char* name, int64_
             c->err = "shm communicator: ranks disagree about the segment layout"; munmap(s->base, s->bytes); delete s; return -6;
         }
     }
-    for (int k = 0; k < SHM_MAX_PEERS; ++k) s->dir(rank)[k] = ShmDirEntry{-1, 0, 0};
+    for (int k = 0; k < 2 * SHM_MAX_PEERS; ++k) s->dir(rank)[k] = ShmDirEntry{-1, 0, 0};
     c->shm = s;
     c->rank = rank; c->nranks = nranks;
     c->dist = true;
@@ -419,6 +505,66 @@ int knp_halo_tables(knp_ctx* c, int npeers, const int32_t* peers, const int64_t*
         ShmComm* s = (ShmComm*)c->shm;
         if (npeers > SHM_MAX_PEERS) { c->err = "shm communicator: too many peers"; return -1; }
         for (int p = 0; p < npeers; ++p) s->dir(s->rank)[p] = ShmDirEntry{peers[p], c->halo_send_off[p], c->halo_send_cnt[p]};
+        return shm_barrier(c, s);
+    }
+    return 0;
+}
+
+// Interface tables of the row-distributed conforming level (see interface_accumulate): peers[p] shares counts[p] conforming dofs with this
+// rank; idx = their LOCAL numbers (n_local = size of this rank's level 0), grouped by peer, within a peer in ascending GLOBAL order (the
+// peer lists the same dofs in the same order).  uvtx [nuniq]: the distinct shared dofs; aptr / asrc: per distinct dof the positions (into
+// idx) of its other owners' values in ascending rank order, with -1 where this rank's own value belongs.  Every rank of the communicator
+// calls this (also with npeers = 0).
+int knp_amg_interface(knp_ctx* c, int64_t n_local, int npeers, const int32_t* peers, const int64_t* counts, const int32_t* idx,
+                      int64_t nuniq, const int32_t* uvtx, const int32_t* aptr, const int32_t* asrc) {
+    if (!c || npeers < 0 || nuniq < 0 || n_local < 0) return -1;
+    if (!c->dist) { c->err = "amg_interface: no communicator"; return -1; }
+    c->if_peer.clear(); c->if_off.clear(); c->if_cnt.clear();
+    int64_t total = 0;
+    for (int p = 0; p < npeers; ++p) {
+        if (peers[p] < 0 || peers[p] >= c->nranks || peers[p] == c->rank || counts[p] <= 0) { c->err = "amg_interface: bad peer entry"; return -1; }
+        c->if_peer.push_back(peers[p]);
+        c->if_off.push_back(total);
+        c->if_cnt.push_back(counts[p]);
+        total += counts[p];
+    }
+    for (int64_t i = 0; i < total; ++i)
+        if (idx[i] < 0 || idx[i] >= n_local) { c->err = "amg_interface: dof outside the local level"; return -1; }
+    for (int64_t u = 0; u < nuniq; ++u) {
+        if (uvtx[u] < 0 || uvtx[u] >= n_local || aptr[u + 1] < aptr[u]) { c->err = "amg_interface: bad shared-dof table"; return -1; }
+        int own = 0;
+        for (int k = aptr[u]; k < aptr[u + 1]; ++k) {
+            if (asrc[k] < -1 || asrc[k] >= total) { c->err = "amg_interface: source position out of range"; return -1; }
+            own += asrc[k] < 0;
+        }
+        if (own != 1) { c->err = "amg_interface: every shared dof needs this rank's own value exactly once"; return -1; }
+    }
+    if (nuniq && aptr[0] != 0) { c->err = "amg_interface: bad shared-dof table"; return -1; }
+    c->if_total = total;
+    c->if_nuniq = nuniq;
+    hipFree(c->if_idx); hipFree(c->if_uvtx); hipFree(c->if_aptr); hipFree(c->if_asrc); hipFree(c->if_send); hipFree(c->if_recv);
+    c->if_idx = c->if_uvtx = c->if_aptr = c->if_asrc = nullptr;
+    c->if_send = c->if_recv = nullptr;
+    if (total) {
+        HIPCHK(c, hipMalloc((void**)&c->if_idx, sizeof(int32_t) * total));
+        HIPCHK(c, hipMemcpy(c->if_idx, idx, sizeof(int32_t) * total, hipMemcpyHostToDevice));
+        HIPCHK(c, hipMalloc((void**)&c->if_send, sizeof(double) * total * KNP_MAX_SYS));
+        HIPCHK(c, hipMalloc((void**)&c->if_recv, sizeof(double) * total * KNP_MAX_SYS));
+    }
+    if (nuniq) {
+        const int64_t nacc = aptr[nuniq];
+        HIPCHK(c, hipMalloc((void**)&c->if_uvtx, sizeof(int32_t) * nuniq));
+        HIPCHK(c, hipMemcpy(c->if_uvtx, uvtx, sizeof(int32_t) * nuniq, hipMemcpyHostToDevice));
+        HIPCHK(c, hipMalloc((void**)&c->if_aptr, sizeof(int32_t) * (nuniq + 1)));
+        HIPCHK(c, hipMemcpy(c->if_aptr, aptr, sizeof(int32_t) * (nuniq + 1), hipMemcpyHostToDevice));
+        HIPCHK(c, hipMalloc((void**)&c->if_asrc, sizeof(int32_t) * (nacc ? nacc : 1)));
+        HIPCHK(c, hipMemcpy(c->if_asrc, asrc, sizeof(int32_t) * nacc, hipMemcpyHostToDevice));
+    }
+    if (c->shm) {                                                            // where each peer finds its message in this rank's outbox
+        ShmComm* s = (ShmComm*)c->shm;
+        if (npeers > SHM_MAX_PEERS) { c->err = "shm communicator: too many peers"; return -1; }
+        for (int k = 0; k < SHM_MAX_PEERS; ++k) s->dir_if(s->rank)[k] = ShmDirEntry{-1, 0, 0};
+        for (int p = 0; p < npeers; ++p) s->dir_if(s->rank)[p] = ShmDirEntry{peers[p], c->if_off[p], c->if_cnt[p]};
         return shm_barrier(c, s);
     }
     return 0;

@@ -144,6 +144,16 @@ struct knp_ctx {
     int32_t* halo_send_idx = nullptr;   // device: owned cell ids to pack, grouped by peer
     double* halo_sendbuf = nullptr;
     int64_t halo_send_total = 0;
+    // row-distributed finest conforming level (amg.hip: dist0; knp_amg_interface): the conforming dofs this rank shares with peers.
+    // The list of one peer is the same on both sides (ascending global dof), so message p is sent and received with one layout
+    std::vector<int> if_peer;
+    std::vector<int64_t> if_off, if_cnt;
+    int64_t if_total = 0, if_nuniq = 0;
+    int32_t* if_idx = nullptr;      // device [if_total]: local conforming dof of every message position, grouped by peer
+    int32_t* if_uvtx = nullptr;     // device [if_nuniq]: the distinct shared dofs
+    int32_t* if_aptr = nullptr;     // device [if_nuniq + 1]: CSR over if_asrc
+    int32_t* if_asrc = nullptr;     // device: message positions of the dof's other owners in ascending rank order, -1 = this rank's own value
+    double *if_send = nullptr, *if_recv = nullptr;   // device [if_total * KNP_MAX_SYS]
     // optional in-solver timing of the operator applies (knp_apply_timing): event pairs recorded around every launch
     bool time_applies = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> tev[2];   // [0] EMI, [1] KNP
@@ -221,5 +231,8 @@ int launch_nernst_only(knp_ctx* c, const double* cc, const double* celim, double
 void comm_destroy(knp_ctx* c);
 int allreduce_red(knp_ctx* c, double* red, int count);
 int allreduce_max(knp_ctx* c, double* host_value);
+// v [ncol / nil][n][nil] holds per-rank partial sums at the shared conforming dofs: afterwards every owner holds the full sum
+// (same bits on every owner: added in rank order).  On the context's stream; 2 messages per peer (comm.hip)
+int interface_accumulate(knp_ctx* c, double* v, int64_t n, int ncol);
 int max_abs_diff(knp_ctx* c, const double* a, const double* b, int nsys, double* out);
 int ode_check_failed(knp_ctx* c);   // ode.hip: reads and clears the ODE failure flag (stream idle); sets c->err

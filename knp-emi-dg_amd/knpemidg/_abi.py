@@ -89,6 +89,8 @@ SIGNATURES = {
                                 C.c_int64, _i32p, _i32p, _f64p, _i32p, _i32p, _f64p]),
     "knp_amg_finish": (C.c_int, [_ctxp, C.c_int, C.c_int64, _f64p]),
     "knp_amg_clear": (C.c_int, [_ctxp, C.c_int]),
+    "knp_amg_interface": (C.c_int, [_ctxp, C.c_int64, C.c_int, _i32p, _i64p, _i32p, C.c_int64, _i32p, _i32p, _i32p]),
+    "knp_amg_dist0": (C.c_int, [_ctxp, C.c_int]),
 }
 
 _lib = None
@@ -593,8 +595,20 @@ class Device:
         self._chk(self.lib.knp_ode_step(self.ctx, handle, t0, dt, rtol, atol), "knp_ode_step")
 
     # -- auxiliary-space AMG (knpemidg/amg.py builds, csrc/amg.hip applies) ------------------
-    def amg_upload(self, which, dg2cg, levels, ncol=1):
-        """dg2cg [nc, nd]: conforming dof of every DG dof (caller's cell order); levels from amg.build_hierarchy."""
+    def amg_interface(self, n_local, peers, lists, uvtx, aptr, asrc):
+        """Shared-dof tables of the row-distributed conforming level (amg.Dist0Space.interface_tables)."""
+        peers = np.ascontiguousarray(peers, dtype=np.int32)
+        cnt = np.ascontiguousarray([len(l) for l in lists], dtype=np.int64)
+        idx = np.ascontiguousarray(np.concatenate(lists) if len(lists) else np.zeros(0), dtype=np.int32)
+        uvtx = np.ascontiguousarray(uvtx, dtype=np.int32)
+        aptr = np.ascontiguousarray(aptr, dtype=np.int32)
+        asrc = np.ascontiguousarray(asrc if len(asrc) else np.zeros(1), dtype=np.int32)
+        self._chk(self.lib.knp_amg_interface(self.ctx, int(n_local), len(peers), _p(peers, _i32p), _p(cnt, _i64p), _p(idx, _i32p), len(uvtx),
+                                             _p(uvtx, _i32p), _p(aptr, _i32p), _p(asrc, _i32p)), "knp_amg_interface")
+
+    def amg_upload(self, which, dg2cg, levels, ncol=1, dist0=False):
+        """dg2cg [nc, nd]: conforming dof of every DG dof (caller's cell order); levels from amg.build_hierarchy.
+        dist0: level 0 (and dg2cg) are this rank's rows in local numbering (amg.Dist0Space.localize; amg_interface first)."""
         nd = self.nd
         d2c = np.ascontiguousarray(np.asarray(dg2cg)[self.cell_order].ravel(), dtype=np.int32)
         assert d2c.shape == (self.nc * nd,)
@@ -606,6 +620,8 @@ class Device:
         self._chk(self.lib.knp_amg_begin(self.ctx, which, ncg, _p(d2c, _i32p), _p(ptr, _i32p), _p(idx, _i32p)), "knp_amg_begin")
         if ncol != 1:
             self._chk(self.lib.knp_amg_columns(self.ctx, which, int(ncol)), "knp_amg_columns")
+        if dist0:
+            self._chk(self.lib.knp_amg_dist0(self.ctx, which), "knp_amg_dist0")
 
         def csr(M):
             M = M.tocsr()
@@ -649,7 +665,7 @@ def _flushing(fn):
 for _name in ("close", "set_params", "set_mms", "upload", "download", "copy_field", "update_kappa", "update_dnphi", "emi_apply",
               "knp_apply", "emi_rhs", "knp_rhs", "emi_solve", "knp_solve", "step_updates", "picard_updates", "max_abs_diff",
               "nernst", "sync", "timer_begin", "timer_end", "bench_apply", "ode_table", "ode_step", "ode_set_stimulus",
-              "amg_upload", "halo_exchange", "apply_timing_read", "comm_init", "set_interior"):
+              "amg_upload", "amg_interface", "halo_exchange", "apply_timing_read", "comm_init", "set_interior"):
     setattr(Device, _name, _flushing(getattr(Device, _name)))
 
 

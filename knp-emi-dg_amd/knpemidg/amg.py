@@ -85,39 +85,54 @@ class ConformingSpace:
         self.mesh = mesh
         self.ncomp = ncomp
 
-    def stiffness(self, coef_nodal, mass_coef=None, membrane=None):
-        """Ac = sum_cells vol * mean(coef) * G (+ mass_coef * M) (+ C int_F jump jump on membrane facets).
-        coef_nodal [nc, nd] (kappa) or [nc] (D); membrane = (facet ids, cell_e, cell_i, C)."""
-        mesh = self.mesh
-        d = mesh.gdim
+    def cell_blocks(self, coef_nodal, mass_coef=None, cells=None):
+        """Per-cell blocks vol * mean(coef) * G (+ mass_coef * vol * M_ref) [n, nv, nv] of all cells, or of `cells`
+        (coef / mass_coef are indexed by global cell either way)."""
+        d = self.mesh.gdim
         vol, G = _cell_gram(self)
         cbar = coef_nodal.mean(axis=1) if np.ndim(coef_nodal) == 2 else np.asarray(coef_nodal)
+        if cells is not None:
+            vol, G, cbar = vol[cells], G[cells], cbar[cells]
+            mass_coef = None if mass_coef is None else np.asarray(mass_coef)[cells]
         blk = (vol * cbar)[:, None, None] * G
         nv = d + 1
         if mass_coef is not None:
             Mloc = (np.ones((nv, nv)) + np.eye(nv)) / ((d + 1) * (d + 2))
             blk = blk + (mass_coef * vol)[:, None, None] * Mloc[None]
-        A = _assemble_cached(self, blk, nv)
+        return blk
+
+    def membrane_blocks(self, membrane):
+        """(dofs [F, 2d], blocks [F, 2d, 2d]) of the coupling C int_F (u_i - u_e)(v_i - v_e) on the membrane facets `fids`."""
+        mesh = self.mesh
+        d = mesh.gdim
+        fids, C = membrane
+        fcl = mesh.facet_cells[fids]
+        fl = mesh.facet_local[fids].astype(np.int64)
+        fx = mesh.coords[mesh.facets[fids]]
+        if d == 2:
+            area = np.linalg.norm(fx[:, 1] - fx[:, 0], axis=1)
+        else:
+            area = 0.5 * np.linalg.norm(np.cross(fx[:, 1] - fx[:, 0], fx[:, 2] - fx[:, 0]), axis=1)
+        # facet vertex m of side s is the cell's local vertex m + (m >= local facet)
+        mm = np.arange(d)[None, :]
+        d0 = np.take_along_axis(self.dof[fcl[:, 0]], mm + (mm >= fl[:, 0:1]), axis=1)
+        d1 = np.take_along_axis(self.dof[fcl[:, 1]], mm + (mm >= fl[:, 1:2]), axis=1)
+        Mf = (np.ones((d, d)) + np.eye(d)) / (d * (d + 1))
+        blkf = (C * area)[:, None, None] * Mf[None]
+        dofs = np.concatenate([d0, d1], axis=1)                              # [F, 2d]
+        sgn = np.concatenate([np.ones(d), -np.ones(d)])
+        full = np.einsum("a,b,fab->fab", sgn, sgn, np.tile(blkf, (1, 2, 2)))
+        return dofs, full
+
+    def stiffness(self, coef_nodal, mass_coef=None, membrane=None):
+        """Ac = sum_cells vol * mean(coef) * G (+ mass_coef * M) (+ C int_F jump jump on membrane facets).
+        coef_nodal [nc, nd] (kappa) or [nc] (D); membrane = (facet ids, C)."""
+        A = _assemble_cached(self, self.cell_blocks(coef_nodal, mass_coef), self.mesh.gdim + 1)
         if membrane is not None:
-            fids, C = membrane
-            fcl = mesh.facet_cells[fids]
-            fl = mesh.facet_local[fids].astype(np.int64)
-            fx = mesh.coords[mesh.facets[fids]]
-            if d == 2:
-                area = np.linalg.norm(fx[:, 1] - fx[:, 0], axis=1)
-            else:
-                area = 0.5 * np.linalg.norm(np.cross(fx[:, 1] - fx[:, 0], fx[:, 2] - fx[:, 0]), axis=1)
-            # facet vertex m of side s is the cell's local vertex m + (m >= local facet)
-            mm = np.arange(d)[None, :]
-            d0 = np.take_along_axis(self.dof[fcl[:, 0]], mm + (mm >= fl[:, 0:1]), axis=1)
-            d1 = np.take_along_axis(self.dof[fcl[:, 1]], mm + (mm >= fl[:, 1:2]), axis=1)
-            Mf = (np.ones((d, d)) + np.eye(d)) / (d * (d + 1))
-            blkf = (C * area)[:, None, None] * Mf[None]
-            dofs = np.concatenate([d0, d1], axis=1)                              # [F, 2d]
-            sgn = np.concatenate([np.ones(d), -np.ones(d)])
-            full = np.einsum("a,b,fab->fab", sgn, sgn, np.tile(blkf, (1, 2, 2)))
-            rows = np.repeat(dofs[:, :, None], 2 * d, axis=2).ravel()
-            cols = np.repeat(dofs[:, None, :], 2 * d, axis=1).ravel()
+            dofs, full = self.membrane_blocks(membrane)
+            k = dofs.shape[1]
+            rows = np.repeat(dofs[:, :, None], k, axis=2).ravel()
+            cols = np.repeat(dofs[:, None, :], k, axis=1).ravel()
             A = A + sp.coo_matrix((full.ravel(), (rows, cols)), shape=(self.n, self.n))
         A = A.tocsr()
         A.sum_duplicates()
@@ -151,18 +166,20 @@ class ConformingSpaceP2:
         vals = np.concatenate([np.ones(cs.n), np.full(2 * ne, 0.5)])
         self.interp = sp.csr_matrix((vals, (rows, cols)), shape=(self.n, cs.n))
 
-    def stiffness(self, coef, mass_coef=None, membrane=None):
-        """Conforming-P2 Galerkin operator: sum_cells int coef grad u.grad v (+ mass_coef int u v)
-        (+ C int_F jump jump on membrane facets).  coef: [nc, nd] P2 nodal or [nc] cell-wise constant."""
+    def cell_blocks(self, coef, mass_coef=None, cells=None):
+        """Per-cell blocks int coef grad u.grad v (+ mass_coef int u v) [n, nd, nd] of all cells, or of `cells`."""
         from knpemidg import dgtab
         from knpemidg.quadrature import simplex_rule
         mesh = self.cs.mesh
         d = mesh.gdim
         vol, Gl = _cell_gram(self.cs)                                         # grad lambda_l . grad lambda_m
+        coef = np.asarray(coef, dtype=np.float64)
+        if cells is not None:
+            vol, Gl, coef = vol[cells], Gl[cells], coef[cells]
+            mass_coef = None if mass_coef is None else np.asarray(mass_coef)[cells]
         nd = self.dof.shape[1]
         bary, w = simplex_rule(d, 4)
         B, dB = dgtab.tabulate(2, bary)
-        coef = np.asarray(coef, dtype=np.float64)
         kq = coef @ B.T if coef.ndim == 2 else np.repeat(coef[:, None], len(w), axis=1)      # [nc, q]
         # blk[c, a, b] = vol sum_q w kq dB[q,a,l] Gl[c,l,m] dB[q,b,m]: per point two batched small products
         blk = np.zeros((Gl.shape[0], nd, nd))
@@ -172,22 +189,37 @@ class ConformingSpaceP2:
         if mass_coef is not None:
             Mref = np.einsum("q,qa,qb->ab", w, B, B)
             blk = blk + (np.asarray(mass_coef) * vol)[:, None, None] * Mref[None]
-        A = _assemble_cached(self, blk, nd)
+        return blk
+
+    def membrane_blocks(self, membrane):
+        """(dofs [F, 2 nd], blocks [F, 2 nd, 2 nd]) of the coupling C int_F jump jump on the membrane facets."""
+        from knpemidg import dgtab
+        from knpemidg.quadrature import simplex_rule
+        mesh = self.cs.mesh
+        d = mesh.gdim
+        fids, C = membrane
+        fcl = mesh.facet_cells[fids]
+        fl = mesh.facet_local[fids].astype(np.int64)
+        fx = mesh.coords[mesh.facets[fids]]
+        if d == 2:
+            area = np.linalg.norm(fx[:, 1] - fx[:, 0], axis=1)
+        else:
+            area = 0.5 * np.linalg.norm(np.cross(fx[:, 1] - fx[:, 0], fx[:, 2] - fx[:, 0]), axis=1)
+        mu, wf = simplex_rule(d - 1, 4)
+        Bs = np.array([dgtab.tabulate(2, np.insert(mu, i, 0.0, axis=1))[0] for i in range(d + 1)])   # [i, q, nd]
+        B0, B1 = Bs[fl[:, 0]], Bs[fl[:, 1]]                                 # [F, q, nd]
+        Jm = np.concatenate([B0, -B1], axis=2)                              # jump operator on the facet pair
+        full = np.einsum("f,q,fqa,fqb->fab", C * area, wf, Jm, Jm)
+        dofs = np.concatenate([self.dof[fcl[:, 0]], self.dof[fcl[:, 1]]], axis=1)
+        return dofs, full
+
+    def stiffness(self, coef, mass_coef=None, membrane=None):
+        """Conforming-P2 Galerkin operator: sum_cells int coef grad u.grad v (+ mass_coef int u v)
+        (+ C int_F jump jump on membrane facets).  coef: [nc, nd] P2 nodal or [nc] cell-wise constant."""
+        nd = self.dof.shape[1]
+        A = _assemble_cached(self, self.cell_blocks(coef, mass_coef), nd)
         if membrane is not None:
-            fids, C = membrane
-            fcl = mesh.facet_cells[fids]
-            fl = mesh.facet_local[fids].astype(np.int64)
-            fx = mesh.coords[mesh.facets[fids]]
-            if d == 2:
-                area = np.linalg.norm(fx[:, 1] - fx[:, 0], axis=1)
-            else:
-                area = 0.5 * np.linalg.norm(np.cross(fx[:, 1] - fx[:, 0], fx[:, 2] - fx[:, 0]), axis=1)
-            mu, wf = simplex_rule(d - 1, 4)
-            Bs = np.array([dgtab.tabulate(2, np.insert(mu, i, 0.0, axis=1))[0] for i in range(d + 1)])   # [i, q, nd]
-            B0, B1 = Bs[fl[:, 0]], Bs[fl[:, 1]]                                 # [F, q, nd]
-            Jm = np.concatenate([B0, -B1], axis=2)                              # jump operator on the facet pair
-            full = np.einsum("f,q,fqa,fqb->fab", C * area, wf, Jm, Jm)
-            dofs = np.concatenate([self.dof[fcl[:, 0]], self.dof[fcl[:, 1]]], axis=1)
+            dofs, full = self.membrane_blocks(membrane)
             rows = np.repeat(dofs[:, :, None], 2 * nd, axis=2).ravel()
             cols = np.repeat(dofs[:, None, :], 2 * nd, axis=1).ravel()
             A = A + sp.coo_matrix((full.ravel(), (rows, cols)), shape=(self.n, self.n))
@@ -195,6 +227,115 @@ class ConformingSpaceP2:
         A.sum_duplicates()
         A.eliminate_zeros()
         return A
+
+
+# ----------------------------------------------------------------------------------------------
+# row-distributed finest level of a partitioned run
+# ----------------------------------------------------------------------------------------------
+class Dist0Space:
+    """Row distribution of the finest conforming level (space: ConformingSpace or ConformingSpaceP2 on the GLOBAL mesh) over the ranks of
+    a cell partition `owner` [nc].  The reference's BoomerAMG is row-distributed by PETSc (src/knpemidg/solver.py:433, 688); here only the
+    finest level is, in the sub-assembled form of non-overlapping domain decomposition (csrc/amg.hip: dist0):
+
+    * rank r's ELEMENTS are its owned cells and the membrane facets whose first cell it owns; its level-0 rows `verts` are the conforming
+      dofs those elements touch (ascending global number = local number);
+    * its level-0 matrix is assembled from its elements only, so sum_r S_r^T A_r S_r = A (S_r: selection of the rank's rows) and a product
+      with an accumulated vector is a per-rank partial sum;
+    * dofs touched by elements of several ranks are SHARED: `interface_tables` lists them per peer in ascending global order (both sides
+      agree without communication: every rank computes all of this from the global mesh).
+    """
+
+    def __init__(self, space, owner, membrane_facets, rank, world):
+        self.space = space
+        self.rank, self.world = int(rank), int(world)
+        self.owner = np.asarray(owner)
+        self.mesh = (space.cs if hasattr(space, "cs") else space).mesh
+        self.mem = np.asarray(membrane_facets, dtype=np.int64)
+        self.facet_owner = self.owner[self.mesh.facet_cells[self.mem, 0]] if len(self.mem) else np.zeros(0, dtype=self.owner.dtype)
+        mdofs = space.membrane_blocks((self.mem, 1.0))[0] if len(self.mem) else None
+        self.rank_verts = []
+        for q in range(self.world):
+            parts = [space.dof[self.owner == q].ravel()]
+            if mdofs is not None:
+                parts.append(mdofs[self.facet_owner == q].ravel())
+            self.rank_verts.append(np.unique(np.concatenate(parts)).astype(np.int64))
+        self.verts = self.rank_verts[self.rank]
+        self.n = len(self.verts)
+        self.g2l = np.full(space.n, -1, dtype=np.int64)
+        self.g2l[self.verts] = np.arange(self.n)
+        self.cells = np.nonzero(self.owner == self.rank)[0]
+        self.facets = self.mem[self.facet_owner == self.rank] if len(self.mem) else self.mem
+
+    def local_dg2cg(self, cells_global):
+        """[n_local_cells, nd] local conforming dof of every DG dof of the rank's cells (owned first, then ghosts); dofs of ghost cells
+        outside the rank's rows map to 0 (never read: vector updates and the prolongation touch owned cells only)."""
+        d = self.g2l[self.space.dof[cells_global]]
+        return np.where(d >= 0, d, 0).astype(np.int32)
+
+    def local_matrix(self, coef, mass_coef=None, membrane_C=None):
+        """The rank's sub-assembled level-0 matrix [n, n] (same arguments as space.stiffness; membrane_C: the coupling constant)."""
+        sp_ = self.space
+        blk = sp_.cell_blocks(coef, mass_coef, cells=self.cells)
+        dofs = self.g2l[sp_.dof[self.cells]]
+        k = dofs.shape[1]
+        rows = [np.repeat(dofs[:, :, None], k, axis=2).ravel()]
+        cols = [np.repeat(dofs[:, None, :], k, axis=1).ravel()]
+        vals = [blk.ravel()]
+        if membrane_C is not None and len(self.facets):
+            fd, full = sp_.membrane_blocks((self.facets, float(membrane_C)))
+            fd = self.g2l[fd]
+            k = fd.shape[1]
+            rows.append(np.repeat(fd[:, :, None], k, axis=2).ravel())
+            cols.append(np.repeat(fd[:, None, :], k, axis=1).ravel())
+            vals.append(full.ravel())
+        A = sp.coo_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(self.n, self.n)).tocsr()
+        A.sum_duplicates()
+        A.sort_indices()
+        return A
+
+    def localize(self, levels, A_local):
+        """The hierarchy with level 0 replaced by the rank's rows: A sub-assembled, inverse diagonal / prolongator rows of the GLOBAL level
+        (so the smoother and the Galerkin coarse operators are exactly those of the replicated hierarchy).  None if there is no coarser level."""
+        if len(levels) < 2:
+            return None
+        g = levels[0]
+        lv = Level()
+        lv.A = A_local
+        lv.dinv = np.ascontiguousarray(g.dinv[self.verts])
+        lv.rho, lv.cheb_degree, lv.cheb_lower = g.rho, g.cheb_degree, g.cheb_lower
+        lv.P = g.P.tocsr()[self.verts].tocsr()
+        lv.P.sort_indices()
+        lv.R = lv.P.T.tocsr()
+        lv.R.sort_indices()
+        return [lv] + list(levels[1:])
+
+    def interface_tables(self):
+        """(peers, lists, uvtx, aptr, asrc) for Device.amg_interface: lists[p] = local numbers of the dofs shared with peers[p] in ascending
+        global order; uvtx = the distinct shared dofs (local); per distinct dof aptr / asrc give the message positions of the other owners'
+        values in ascending rank order, -1 standing for this rank's own value."""
+        peers, lists, g_all, r_all = [], [], [], []
+        for q in range(self.world):
+            if q == self.rank:
+                continue
+            sh = np.intersect1d(self.verts, self.rank_verts[q], assume_unique=True)
+            if len(sh):
+                peers.append(q)
+                lists.append(self.g2l[sh].astype(np.int32))
+                g_all.append(sh)
+                r_all.append(np.full(len(sh), q, dtype=np.int64))
+        if not peers:
+            return [], [], np.zeros(0, np.int32), np.zeros(1, np.int32), np.zeros(0, np.int32)
+        g = np.concatenate(g_all)
+        rk = np.concatenate(r_all)
+        pos = np.arange(len(g), dtype=np.int64)
+        ug = np.unique(g)
+        g2 = np.concatenate([g, ug])
+        rk2 = np.concatenate([rk, np.full(len(ug), self.rank, dtype=np.int64)])
+        pos2 = np.concatenate([pos, np.full(len(ug), -1, dtype=np.int64)])
+        order = np.lexsort((rk2, g2))
+        cnt = np.bincount(np.searchsorted(ug, g2), minlength=len(ug))
+        aptr = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int32)
+        return peers, lists, self.g2l[ug].astype(np.int32), aptr, pos2[order].astype(np.int32)
 
 
 # ----------------------------------------------------------------------------------------------

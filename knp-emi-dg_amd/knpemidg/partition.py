@@ -91,6 +91,7 @@ class LocalMesh:
     def __init__(self, part, rank):
         mesh = part.mesh
         self.rank = rank
+        self.part = part
         self.owned = np.nonzero(part.owner == rank)[0]
         ghosts = part.ghosts_of(rank)
         self.peers = sorted(ghosts.keys())

@@ -378,10 +378,21 @@ class Solver:
             levels = amg.build_emi_levels(self._cspace, self._cspace2 if self.degree_knp != 1 else None, gsurf.array(),
                                           self.membrane_tags, kappa, _f(self.C_phi))
             dg2cg = self._local_dg2cg()
-        dev.amg_upload(0, dg2cg, levels)
+            d0 = self._dist0()
+            if d0 is not None:                      # partitioned run: this rank's rows of the finest conforming level
+                local = d0.localize(levels, d0.local_matrix(kappa, membrane_C=_f(self.C_phi)))
+                if local is not None:
+                    dev.amg_upload(0, d0.local_dg2cg(self.local_mesh.cells_global), local, dist0=True)
+                    self.amg_dist0 = getattr(self, "amg_dist0", 0) + 1          # hierarchies uploaded in the row-distributed form
+                    levels = None
+        if levels is not None:
+            dev.amg_upload(0, dg2cg, levels)
+            nlev = [lv.A.shape[0] for lv in levels]
+        else:
+            nlev = [lv.A.shape[0] for lv in local]
         self.amg_setup_timer = time.perf_counter() - ts
         if self.verbose:
-            print(" AMG(EMI) levels:", [lv.A.shape[0] for lv in levels], "setup %.2f s" % self.amg_setup_timer)
+            print(" AMG(EMI) levels:", nlev, "setup %.2f s" % self.amg_setup_timer)
 
     def _maybe_refresh_amg_emi(self, niter):
         """Refresh policy of the lagged EMI hierarchy.  The reference rebuilds BoomerAMG from the freshly assembled B_emi at
@@ -438,6 +449,24 @@ class Solver:
             if self.degree_knp != 1:
                 self._cspace2 = amg.ConformingSpaceP2(self._cspace)
         return g
+
+    def _dist0(self):
+        """Row distribution of the finest conforming level over the ranks of a partitioned run (amg.Dist0Space; the reference's BoomerAMG
+        is row-distributed by PETSc, solver.py:433, 688), with the shared-dof tables handed to the device on the first call; None on one
+        rank and with KNP_AMG_DIST0=0 (replicated level 0 behind an all-reduce of the level-0 residual, rounds 1-2)."""
+        loc = getattr(self, "local_mesh", None)
+        if loc is None or getattr(loc, "part", None) is None or loc.part.world < 2 or os.environ.get("KNP_AMG_DIST0", "1") == "0":
+            return None
+        d0 = getattr(self, "_dist0_space", None)
+        if d0 is None:
+            from knpemidg import amg
+            gmesh, gsub, gsurf = self._amg_global()
+            space = self._cspace if self.degree_knp == 1 else self._cspace2
+            mem = np.nonzero((gmesh.facet_cells[:, 1] >= 0) & np.isin(np.asarray(gsurf.array()), list(self.membrane_tags)))[0]
+            d0 = amg.Dist0Space(space, loc.part.owner, mem, loc.rank, loc.part.world)
+            self.dev.amg_interface(d0.n, *d0.interface_tables())
+            self._dist0_space = d0
+        return d0
 
     def _local_dg2cg(self):
         loc = getattr(self, "local_mesh", None)
@@ -496,8 +525,18 @@ class Solver:
                 setup_worker.cancel(handle)
         if groups is None:
             groups = self._build_amg_knp()
+        d0 = self._dist0()
         for members, levels in groups:
-            self.dev.amg_upload(1 + members[0], self._local_dg2cg(), levels, ncol=len(members))
+            local = None
+            if d0 is not None:                      # partitioned run: this rank's rows of the finest conforming level
+                gsub = self._amg_global()[1]
+                D = np.mean([self._by_tag(self.ion_list[k]['D_sub'], gsub) for k in members], axis=0)
+                local = d0.localize(levels, d0.local_matrix(D, mass_coef=np.full(len(D), 1.0 / _f(self.dt))))
+            if local is not None:
+                self.dev.amg_upload(1 + members[0], d0.local_dg2cg(self.local_mesh.cells_global), local, ncol=len(members), dist0=True)
+                self.amg_dist0 = getattr(self, "amg_dist0", 0) + 1
+            else:
+                self.dev.amg_upload(1 + members[0], self._local_dg2cg(), levels, ncol=len(members))
             for k in members[1:]:
                 self.dev.amg_clear(1 + k)
             if self.verbose:

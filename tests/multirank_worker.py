@@ -29,8 +29,9 @@ else:
     # "thin": three slabs, the middle one 2 % of the cells -- every cell of that rank touches a cut (n_interior == 0), its peers have
     # interior cells: all three must take the same (overlapped) exchange channel (comm.hip dist_apply)
     fractions = [0.0, 0.49, 0.51, 1.0] if method == "thin" else None
-    S = distribute_solver(lambda: SolverIdealized(params, ion_list, degree_emi=1, degree_knp=1), mesh_tuple, ode_models, stim_params,
-                          rank, world, 0, None, method="slab" if method == "thin" else method, fractions=fractions)
+    deg = 2 if method == "p2" else 1
+    S = distribute_solver(lambda: SolverIdealized(params, ion_list, degree_emi=deg, degree_knp=deg), mesh_tuple, ode_models, stim_params,
+                          rank, world, 0, None, method="slab" if method in ("thin", "p2") else method, fractions=fractions)
     if method == "thin":
         assert (S.dev.n_interior == 0) == (rank == 1), (rank, S.dev.n_interior)
     S._unpack_solver_params(solver_parameters(3, 0)._replace(rtol_emi=1e-10, rtol_knp=1e-12))
@@ -47,5 +48,5 @@ nc = loc.mesh.num_cells()
 c = S.c.array().reshape(S.N_ions, nc, S.nd)[:, :n_own]
 phi = S.phi.array().reshape(nc, S.nd)[:n_own]
 np.savez(os.path.join(outdir, "rank%d.npz" % rank), cells=loc.cells_global[:n_own], c=c, phi=phi, emi_its=np.asarray(S.emi_niter),
-         knp_its=np.asarray([max(n) for n in S.knp_niter]))
+         knp_its=np.asarray([max(n) for n in S.knp_niter]), dist0=int(getattr(S, "amg_dist0", 0)))
 S.dev.close()

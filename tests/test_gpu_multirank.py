@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def _single_rank(n_axons, steps, method):
+def _single_rank(n_axons, steps, method, degree=1):
     from common_examples import make_solver, solver_parameters, Constant
     if method == "emix":
         ex = os.path.join(os.path.dirname(HERE), "examples", "emix_simulations")
@@ -27,7 +27,7 @@ def _single_rank(n_axons, steps, method):
         S = emix_common.make_solver()
         S._unpack_solver_params(emix_common.solver_parameters()._replace(rtol_emi=1e-10, rtol_knp=1e-12))
     else:
-        S = make_solver(dim=3, resolution=0, n_axons=n_axons)
+        S = make_solver(dim=3, resolution=0, n_axons=n_axons, degree=degree)
         S._unpack_solver_params(solver_parameters(3, 0)._replace(rtol_emi=1e-10, rtol_knp=1e-12))
     S.save_fields = S.save_solver_stats = False
     S.splitting_scheme = True
@@ -39,14 +39,22 @@ def _single_rank(n_axons, steps, method):
     nc = S.mesh.num_cells()
     x = S.mesh.coords[S.mesh.cells]
     vol = np.abs(np.linalg.det(x[:, 1:] - x[:, :1])) / 6.0
-    out = (S.c.array().reshape(S.N_ions, nc, S.nd).copy(), S.phi.array().reshape(nc, S.nd).copy(), vol, list(S.emi_niter))
+    out = (S.c.array().reshape(S.N_ions, nc, S.nd).copy(), S.phi.array().reshape(nc, S.nd).copy(), vol, list(S.emi_niter),
+           [max(n) for n in S.knp_niter])
     S.dev.close()
     return out
 
 
-@pytest.mark.parametrize("world,method,n_axons", [(2, "slab", 4), (3, "slab", 4), (3, "rcb", 1), (3, "emix", 0), (3, "thin", 4)])
-def test_partitioned_solver_with_several_ranks_on_one_gpu(hip_lib, tmp_path, world, method, n_axons):
+@pytest.mark.parametrize("world,method,n_axons,dist0", [(2, "slab", 4, 1), (3, "slab", 4, 1), (3, "rcb", 1, 1), (3, "emix", 0, 1),
+                                                        (3, "thin", 4, 1), (2, "p2", 4, 1), (2, "slab", 4, 0)])
+def test_partitioned_solver_with_several_ranks_on_one_gpu(hip_lib, tmp_path, monkeypatch, world, method, n_axons, dist0):
+    # dist0 = 1: the finest conforming level ROW-DISTRIBUTED (sub-assembled matrices, point-to-point exchange of the shared dofs, one
+    # all-reduce of the level-1 residual; csrc/amg.hip dist0) -- the default of a partitioned run; 0: replicated behind an all-reduce of
+    # the level-0 residual (rounds 1-2).  The small meshes get a coarse-size limit that leaves at least one level below the finest.
     steps = 3
+    monkeypatch.setenv("KNP_AMG_DIST0", str(dist0))
+    if method != "emix":
+        monkeypatch.setenv("KNP_AMG_MAXCOARSE", "300")
     name = "/knp_%s" % uuid.uuid4().hex[:16]
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "multirank_worker.py"), str(r), str(world), name, str(tmp_path), method,
                                str(n_axons), str(steps)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
@@ -60,7 +68,7 @@ def test_partitioned_solver_with_several_ranks_on_one_gpu(hip_lib, tmp_path, wor
             if p.poll() is None:
                 p.kill()
     assert all(p.returncode == 0 for p in procs), "\n".join(l[-2000:] for l in logs)
-    c_ref, phi_ref, vol, emi_ref = _single_rank(n_axons, steps, method)
+    c_ref, phi_ref, vol, emi_ref, knp_ref = _single_rank(n_axons, steps, method, degree=2 if method == "p2" else 1)
     nc = c_ref.shape[1]
     c = np.full_like(c_ref, np.nan)
     phi = np.full_like(phi_ref, np.nan)
@@ -71,6 +79,10 @@ def test_partitioned_solver_with_several_ranks_on_one_gpu(hip_lib, tmp_path, wor
         phi[d["cells"]] = d["phi"]
         seen[d["cells"]] += 1
         assert len(d["emi_its"]) == steps and d["emi_its"].max() < 1000 and d["knp_its"].max() < 1000
+        assert int(d["dist0"]) == (2 if dist0 else 0), d["dist0"]              # EMI + the shared KNP hierarchy, both row-distributed
+        # the partitioned preconditioner is the single-rank one up to rounding: same iteration counts
+        assert np.abs(d["emi_its"] - np.asarray(emi_ref)).max() <= 1 and np.abs(d["knp_its"] - np.asarray(knp_ref)).max() <= 1, (
+            d["emi_its"], emi_ref, d["knp_its"], knp_ref)
     assert (seen == 1).all()                                   # every cell owned by exactly one rank
     mean = lambda p: p - (p.mean(axis=1) * vol).sum() / vol.sum()
     assert relerr(c, c_ref) < 1e-8

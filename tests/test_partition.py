@@ -134,3 +134,143 @@ def test_halo_exchange_gloo(world, method):
     for rank, e in res:
         assert not isinstance(e, str), e
         assert e < 1e-12, (rank, e)
+
+
+@pytest.mark.parametrize("degree,world,method", [(1, 3, "slab"), (1, 4, "rcb"), (2, 2, "slab"), (2, 3, "rcb")])
+def test_row_distributed_level0_algebra(degree, world, method, monkeypatch):
+    """knpemidg/amg.py: Dist0Space (the row-distributed finest conforming level of a partitioned run, csrc/amg.hip dist0), emulated on
+    the host with every rank's tables: the sub-assembled matrices add up to the global operator, the shared-dof tables of two peers list
+    the same dofs in the same order, the rank-ordered accumulation gives every owner the same bits, and one level-0 visit of the V-cycle
+    (smooth, residual, restriction, a replicated coarse map, prolongation, smooth) on the distributed data equals the global one."""
+    from common import small_3d
+    from knpemidg import amg
+    from knpemidg.partition import Partition
+    monkeypatch.setenv("KNP_AMG_MAXCOARSE", "60")         # a coarser level below the small mesh's finest one
+    mesh, sub, surf = small_3d((8, 4, 4))
+    cs = amg.ConformingSpace(mesh, surf.array(), [1])
+    space = cs if degree == 1 else amg.ConformingSpaceP2(cs)
+    nd = space.dof.shape[1]
+    rng = np.random.default_rng(5)
+    kappa = rng.uniform(0.5, 1.5, size=(mesh.num_cells(), nd))
+    mem = np.nonzero((mesh.facet_cells[:, 1] >= 0) & np.isin(surf.array(), [1]))[0]
+    assert len(mem) > 0
+    levels = amg.build_emi_levels(cs, space if degree == 2 else None, surf.array(), [1], kappa, 2.0e2)
+    if degree == 1:
+        levels[0].cheb_degree = 2                     # exercise the extra Chebyshev step of the distributed smoother too
+    assert len(levels) >= 2
+    A = levels[0].A
+    part = Partition(mesh, world, method=method)
+    D = [amg.Dist0Space(space, part.owner, mem, r, world) for r in range(world)]
+    Al = [d.local_matrix(kappa, membrane_C=2.0e2) for d in D]
+    # (1) sub-assembled matrices add up to the global operator; every dof has an owner
+    S = sum((sp_sel(d, space.n).T @ a @ sp_sel(d, space.n)) for d, a in zip(D, Al))
+    assert abs(S - A).max() <= 1e-12 * abs(A).max()
+    assert np.array_equal(np.unique(np.concatenate([d.verts for d in D])), np.arange(space.n))
+    tabs = [d.interface_tables() for d in D]
+    # (2) peers list the same shared dofs in the same order
+    for r, (peers, lists, uvtx, aptr, asrc) in enumerate(tabs):
+        for q, l in zip(peers, lists):
+            pq, lq = tabs[q][0], tabs[q][1]
+            assert r in pq
+            assert np.array_equal(D[r].verts[l], D[q].verts[lq[pq.index(r)]])
+        assert len(uvtx) == len(aptr) - 1 and aptr[-1] == len(asrc) and (asrc == -1).sum() == len(uvtx)
+
+    def accumulate(vs):
+        """what interface_accumulate does: pack per peer, 'receive' the peer's message, add in rank order"""
+        send = [np.concatenate([v[l] for l in t[1]]) if t[0] else np.zeros(0) for v, t in zip(vs, tabs)]
+        out = []
+        for r, (v, (peers, lists, uvtx, aptr, asrc)) in enumerate(zip(vs, tabs)):
+            recv = []
+            for q, l in zip(peers, lists):
+                pq, lq = tabs[q][0], tabs[q][1]
+                k = pq.index(r)
+                off = sum(len(x) for x in lq[:k])
+                recv.append(send[q][off:off + len(lq[k])])
+            recv = np.concatenate(recv) if recv else np.zeros(0)
+            w = v.copy()
+            for u in range(len(uvtx)):
+                s_ = 0.0
+                for k in range(aptr[u], aptr[u + 1]):
+                    s_ += v[uvtx[u]] if asrc[k] < 0 else recv[asrc[k]]
+                w[uvtx[u]] = s_
+            out.append(w)
+        return out
+
+    # (3) accumulation: partial sums of a global vector -> every owner holds the global value, bit-identical between owners
+    bg = rng.standard_normal(space.n)
+    parts = [a @ np.ones(d.n) * 0 + (sp_sel(d, space.n) @ bg) / share_count(D, space.n)[d.verts] for d, a in zip(D, Al)]
+    acc = accumulate(parts)
+    full = np.zeros(space.n)
+    seen = np.zeros(space.n, dtype=bool)
+    for d, v in zip(D, acc):
+        assert np.allclose(v, bg[d.verts], rtol=1e-13, atol=1e-14)
+        assert np.array_equal(v[seen[d.verts]], full[d.verts][seen[d.verts]])
+        full[d.verts] = v
+        seen[d.verts] = True
+
+    # (4) one level-0 visit: global reference
+    g = levels[0]
+    lmax, lmin = g.rho, g.cheb_lower * g.rho
+    theta, delta = 0.5 * (lmax + lmin), 0.5 * (lmax - lmin)
+    sigma = theta / delta
+    Cmap = rng.standard_normal((g.P.shape[1],)) * 1e-3               # a replicated (diagonal) stand-in for the coarser levels
+
+    def smooth_global(x, b, zero):
+        r = b.copy() if zero else b - A @ x
+        d_ = g.dinv * r / theta
+        x = d_.copy() if zero else x + d_
+        rho = 1.0 / sigma
+        for _ in range(1, g.cheb_degree):
+            rho_new = 1.0 / (2.0 * sigma - rho)
+            r = r - A @ d_
+            d_ = rho_new * rho * d_ + 2.0 * rho_new / delta * g.dinv * r
+            x = x + d_
+            rho = rho_new
+        return x
+    b = A @ rng.standard_normal(space.n) + 0.1 * rng.standard_normal(space.n)
+    xg = smooth_global(None, b, True)
+    xg = xg + g.P @ (Cmap * (g.P.T @ (b - A @ xg)))
+    xg = smooth_global(xg, b, False)
+
+    # distributed: b as per-rank partial sums (what the DG restriction of the owned cells produces)
+    loc = [d.localize(levels, a)[0] for d, a in zip(D, Al)]
+    bp = [(sp_sel(d, space.n) @ b) / share_count(D, space.n)[d.verts] for d in D]
+
+    def smooth_dist(xs, zero):
+        if zero:
+            rs = accumulate([p.copy() for p in bp])
+        else:
+            rs = accumulate([p - l.A @ x for p, l, x in zip(bp, loc, xs)])
+        ds = [l.dinv * r / theta for l, r in zip(loc, rs)]
+        xs = [d_.copy() for d_ in ds] if zero else [x + d_ for x, d_ in zip(xs, ds)]
+        rho = 1.0 / sigma
+        for _ in range(1, g.cheb_degree):
+            rho_new = 1.0 / (2.0 * sigma - rho)
+            ts = accumulate([l.A @ d_ for l, d_ in zip(loc, ds)])
+            rs = [r - t for r, t in zip(rs, ts)]
+            ds = [rho_new * rho * d_ + 2.0 * rho_new / delta * l.dinv * r for l, d_, r in zip(loc, ds, rs)]
+            xs = [x + d_ for x, d_ in zip(xs, ds)]
+            rho = rho_new
+        return xs
+    xs = smooth_dist(None, True)
+    r1 = sum(l.R @ (p - l.A @ x) for l, p, x in zip(loc, bp, xs))     # the all-reduce of the level-1 right-hand side
+    xs = [x + l.P @ (Cmap * r1) for l, x in zip(loc, xs)]
+    xs = smooth_dist(xs, False)
+    for d, x in zip(D, xs):
+        assert np.allclose(x, xg[d.verts], rtol=1e-10, atol=1e-12 * np.abs(xg).max())
+    # DG map: every DG dof of an owned cell finds its conforming dof among the rank's rows
+    for r, d in enumerate(D):
+        cells = np.nonzero(part.owner == r)[0]
+        assert np.array_equal(d.verts[d.local_dg2cg(cells)], space.dof[cells])
+
+
+def sp_sel(d, n):
+    import scipy.sparse as sp
+    return sp.csr_matrix((np.ones(d.n), (np.arange(d.n), d.verts)), shape=(d.n, n))
+
+
+def share_count(D, n):
+    cnt = np.zeros(n)
+    for d in D:
+        cnt[d.verts] += 1.0
+    return cnt
