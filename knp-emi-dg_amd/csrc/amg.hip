@@ -267,45 +267,66 @@ void launch_cheb_step(knp_ctx* c, const CsrDev& A, const double* dinv, const dou
 // dense y = M b on the coarsest level (n up to a few thousand): one workgroup per row, 4 independent loads in flight per
 // lane; M is the pseudo-inverse stored in fp32 (preconditioner data: half the bytes, still an exactly symmetric
 // operator because symmetric entries round identically), accumulation in fp64, fixed reduction tree.
+constexpr int DENSE_ROWS = 2;
 template <int NC>
 __global__ __launch_bounds__(256) void k_dense_mv(int n, const float* __restrict__ M, const double* __restrict__ b,
                                                   double* __restrict__ y) {
-    // one workgroup per row, 4 independent row segments in flight per lane; NC right-hand-side columns share the pass over the fp32
-    // row (further columns along grid.y)
-    __shared__ double part[4][NC];
-    const int row = blockIdx.x;
+    // DENSE_ROWS rows per workgroup (they share the loads of b: with one row per workgroup every workgroup pulls the whole of b through
+    // its L1 -- 151 MB for two columns against 38 MB of matrix at n = 3 089), 4 independent row segments in flight per lane and row;
+    // lanes read consecutive entries (a 16-byte-per-lane layout touches four times the cache lines per load of b and is slower);
+    // NC right-hand-side columns share the pass over the fp32 rows (further columns along grid.y)
+    __shared__ double part[4][DENSE_ROWS][NC];
+    const int row0 = blockIdx.x * DENSE_ROWS;
     b += (int64_t)blockIdx.y * NC * n;
     y += (int64_t)blockIdx.y * NC * n;
-    const float* __restrict__ Mr = M + (int64_t)row * n;
-    double s[4][NC];
+    const float* __restrict__ Mr[DENSE_ROWS];
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+    for (int r = 0; r < DENSE_ROWS; ++r) Mr[r] = M + (int64_t)(row0 + r < n ? row0 + r : n - 1) * n;      // (a duplicate row is not stored)
+    double s[DENSE_ROWS][4][NC];
 #pragma unroll
-        for (int j = 0; j < NC; ++j) s[u][j] = 0.0;
-    int k = threadIdx.x;
-    for (; k + 768 < n; k += 1024) {
-        float m[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) m[u] = Mr[k + 256 * u];
+    for (int r = 0; r < DENSE_ROWS; ++r)
 #pragma unroll
         for (int u = 0; u < 4; ++u)
 #pragma unroll
-            for (int j = 0; j < NC; ++j) s[u][j] = fma((double)m[u], b[(int64_t)(k + 256 * u) * NC + j], s[u][j]);
+            for (int j = 0; j < NC; ++j) s[r][u][j] = 0.0;
+    int k = threadIdx.x;
+    for (; k + 768 < n; k += 1024) {
+        float m[DENSE_ROWS][4];
+#pragma unroll
+        for (int r = 0; r < DENSE_ROWS; ++r)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) m[r][u] = Mr[r][k + 256 * u];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int j = 0; j < NC; ++j) {
+                const double bv = b[(int64_t)(k + 256 * u) * NC + j];
+#pragma unroll
+                for (int r = 0; r < DENSE_ROWS; ++r) s[r][u][j] = fma((double)m[r][u], bv, s[r][u][j]);
+            }
     }
     for (; k < n; k += 256) {
-        const double m = (double)Mr[k];
 #pragma unroll
-        for (int j = 0; j < NC; ++j) s[0][j] = fma(m, b[(int64_t)k * NC + j], s[0][j]);
+        for (int j = 0; j < NC; ++j) {
+            const double bv = b[(int64_t)k * NC + j];
+#pragma unroll
+            for (int r = 0; r < DENSE_ROWS; ++r) s[r][0][j] = fma((double)Mr[r][k], bv, s[r][0][j]);
+        }
     }
 #pragma unroll
-    for (int j = 0; j < NC; ++j) {
-        double v = (s[0][j] + s[1][j]) + (s[2][j] + s[3][j]);
+    for (int r = 0; r < DENSE_ROWS; ++r)
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-        if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6][j] = v;
-    }
+        for (int j = 0; j < NC; ++j) {
+            double v = (s[r][0][j] + s[r][1][j]) + (s[r][2][j] + s[r][3][j]);
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+            if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6][r][j] = v;
+        }
     __syncthreads();
-    if ((int)threadIdx.x < NC) y[(int64_t)row * NC + threadIdx.x] = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+    if ((int)threadIdx.x < DENSE_ROWS * NC) {
+        const int r = threadIdx.x / NC, j = threadIdx.x % NC;
+        if (row0 + r < n) y[(int64_t)(row0 + r) * NC + j] = (part[0][r][j] + part[1][r][j]) + (part[2][r][j] + part[3][r][j]);
+    }
 }
 
 // rc[v] = sum over the DG dofs mapped to conforming dof v (CSR list, fixed order -> deterministic)
@@ -444,9 +465,9 @@ static int amg_vcycle_eager(knp_ctx* c, AmgHierarchy& H, int l0 = 0) {
     }
     AmgLevel& C = H.levels[nl - 1];
     if (H.ncol % 2 == 0)
-        hipLaunchKernelGGL(k_dense_mv<2>, dim3((unsigned)C.n, (unsigned)(H.ncol / 2)), dim3(256), 0, c->stream, (int)C.n, (const float*)H.pinv, C.b, C.x);
+        hipLaunchKernelGGL(k_dense_mv<2>, dim3((unsigned)((C.n + DENSE_ROWS - 1) / DENSE_ROWS), (unsigned)(H.ncol / 2)), dim3(256), 0, c->stream, (int)C.n, (const float*)H.pinv, C.b, C.x);
     else
-        hipLaunchKernelGGL(k_dense_mv<1>, dim3((unsigned)C.n, (unsigned)H.ncol), dim3(256), 0, c->stream, (int)C.n, (const float*)H.pinv, C.b, C.x);
+        hipLaunchKernelGGL(k_dense_mv<1>, dim3((unsigned)((C.n + DENSE_ROWS - 1) / DENSE_ROWS), (unsigned)H.ncol), dim3(256), 0, c->stream, (int)C.n, (const float*)H.pinv, C.b, C.x);
     for (int l = nl - 2; l >= l0; --l) {
         AmgLevel& L = H.levels[l];
         if (L.cheb_degree == 0) {
