@@ -397,17 +397,26 @@ __global__ __launch_bounds__(256) void k_restrict_tiles(int64_t ndof_owned, int 
     }
 }
 
-// stage 2: rc[v] = sum of the slots of conforming dof v (fixed order)
+// stage 2: rc[v] = sum of the slots of conforming dof v (fixed order); with dinv also the zero-guess first Chebyshev update of level 0
+// (r = rc ; d = x = dinv rc / theta: one launch less per V-cycle; AmgHierarchy::fuse_first0)
 __global__ __launch_bounds__(256) void k_restrict_sum(int64_t ncg, const int32_t* __restrict__ part_ptr, const int32_t* __restrict__ part_idx,
-                                                      const double* __restrict__ part, int64_t nslots, double* __restrict__ rc, int nil) {
+                                                      const double* __restrict__ part, int64_t nslots, double* __restrict__ rc, int nil,
+                                                      const double* __restrict__ dinv, double inv_theta, double* __restrict__ r0,
+                                                      double* __restrict__ d0, double* __restrict__ x0) {
     part += (int64_t)blockIdx.y * nslots;
-    rc += (int64_t)(blockIdx.y / nil) * nil * ncg + (blockIdx.y % nil);          // column blockIdx.y of the interleaved level vector
+    const int64_t o = (int64_t)(blockIdx.y / nil) * nil * ncg + (blockIdx.y % nil);   // column blockIdx.y of the interleaved level vector
     const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (v >= ncg) return;
     double s = 0.0;
     const int e = part_ptr[v + 1];
     for (int k = part_ptr[v]; k < e; ++k) s += part[part_idx[k]];
-    rc[v * nil] = s;
+    rc[o + v * nil] = s;
+    if (dinv) {
+        const double w = dinv[v] * s * inv_theta;
+        r0[o + v * nil] = s;
+        d0[o + v * nil] = w;
+        x0[o + v * nil] = w;
+    }
 }
 
 }  // namespace
@@ -445,7 +454,7 @@ static int amg_vcycle_eager(knp_ctx* c, AmgHierarchy& H, int l0 = 0) {
     const int nl = (int)H.levels.size();
     s_ncol = H.ncol;
     struct Reset { ~Reset() { s_ncol = 1; } } reset_on_exit;
-    bool first_done = false;
+    bool first_done = l0 == 0 && H.fuse_first0;                     // level 0's first update came with the restriction (k_restrict_sum)
     for (int l = l0; l < nl - 1; ++l) {
         AmgLevel& L = H.levels[l];
         if (L.cheb_degree == 0) {                                    // transfer-only level: x = 0, r = b
@@ -490,10 +499,15 @@ static int amg_vcycle_levels(knp_ctx* c, AmgHierarchy& H, int l0, hipStream_t on
         hipGraph_t graph = nullptr;
         hipGraphExec_t exec = nullptr;
         if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+            H.entry_x = H.levels[0].x; H.entry_r = H.levels[0].r; H.entry_d0 = H.levels[0].d0;
+            std::vector<std::pair<double*, double*>> keep;           // the smoother swaps (x, d1) of a level as it goes
+            for (auto& L : H.levels) keep.emplace_back(L.x, L.d1);
             const int rc = amg_vcycle_eager(c, H, l0);
             const hipError_t e = hipStreamEndCapture(c->stream, &graph);
             if (rc == 0 && e == hipSuccess && graph && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess)
                 H.graph_exec = exec;
+            else                                                     // nothing ran: the eager V-cycle below starts from the buffers the
+                for (size_t l = 0; l < H.levels.size(); ++l) { H.levels[l].x = keep[l].first; H.levels[l].d1 = keep[l].second; }   // restriction wrote
             if (graph) hipGraphDestroy(graph);
             if (getenv("KNP_DEBUG")) fprintf(stderr, "[knp] V-cycle graph capture: rc=%d end=%d exec=%p\n", rc, (int)e, (void*)H.graph_exec);
         } else if (getenv("KNP_DEBUG")) {
@@ -637,8 +651,12 @@ int amg_restrict_finish(knp_ctx* c, AmgHierarchy& H, hipStream_t on_stream) {
     s_ncol = H.ncol;
     struct Reset { ~Reset() { s_ncol = 1; } } reset_on_exit;
     hipStream_t st = on_stream ? on_stream : c->stream;
+    AmgLevel& L0 = H.levels[0];
+    const bool fuse = H.fuse_first0;                                // (amg_vcycle_eager then skips level 0's k_cheb_first)
+    const bool baked = H.graph_exec != nullptr;                     // the captured V-cycle reads the buffers of its capture
     hipLaunchKernelGGL(k_restrict_sum, GRIDX((H.ncg + 255) / 256), dim3(256), 0, st, H.ncg, H.part_ptr, H.part_idx,
-                       (const double*)H.part, H.nslots, H.levels[0].b, (H.ncol % 2 == 0) ? 2 : 1);
+                       (const double*)H.part, H.nslots, L0.b, (H.ncol % 2 == 0) ? 2 : 1, fuse ? (const double*)L0.dinv : (const double*)nullptr,
+                       1.0 / level_theta(L0), baked ? H.entry_r : L0.r, baked ? H.entry_d0 : L0.d0, baked ? H.entry_x : L0.x);
     return amg_restrict_tail(c, H, st);
 }
 
@@ -677,6 +695,7 @@ void amg_free(AmgHierarchy& H) {
     hipFree(H.pinv); hipFree(H.dg2cg); hipFree(H.cg_ptr); hipFree(H.cg_idx);
     H.pinv = nullptr; H.dg2cg = nullptr; H.cg_ptr = nullptr; H.cg_idx = nullptr;
     hipFree(H.t0); H.t0 = nullptr; H.dist0 = false;
+    H.fuse_first0 = false; H.entry_x = H.entry_r = H.entry_d0 = nullptr;
     hipFree(H.tile_off); hipFree(H.slot_ptr); hipFree(H.slot_idx); hipFree(H.part_ptr); hipFree(H.part_idx); hipFree(H.part);
     H.tile_off = H.slot_ptr = H.part_ptr = H.part_idx = nullptr; H.slot_idx = nullptr; H.part = nullptr;
     H.ntiles = H.nslots = 0; H.part_cols = 0;
@@ -785,6 +804,8 @@ int knp_amg_finish(knp_ctx* c, int which, int64_t n, const double* pinv) {
     std::vector<float> p32((size_t)n * n);
     for (size_t i = 0; i < p32.size(); ++i) p32[i] = (float)pinv[i];
     int rc = up(c, &H->pinv, p32.data(), p32.size());
+    static const bool fuse_env = !(getenv("KNP_FUSE_FIRST0") && atoi(getenv("KNP_FUSE_FIRST0")) == 0);
+    H->fuse_first0 = fuse_env && !c->dist && H->ntiles > 0 && H->levels.size() > 1 && H->levels[0].cheb_degree > 0;
     H->ready = (rc == 0);
     return rc;
 }

@@ -45,6 +45,12 @@ struct AmgHierarchy {
     double* t0 = nullptr;           // [ncol][n_0] work vector of the distributed level
     void* graph_exec = nullptr;     // hipGraphExec_t of one V-cycle (fixed kernel sequence on fixed buffers; dist0: levels >= 1)
     bool graph_tried = false;
+    // Level 0's zero-guess first Chebyshev update comes with stage 2 of the tile-wise restriction (k_restrict_sum) instead of a launch
+    // of its own: one process, tile tables, a smoothed level 0 with a coarser level below.  The V-cycle swaps level buffers while it runs
+    // (and a captured graph keeps the pointers of its capture), so the restriction writes where THIS V-cycle will read: entry_* = the
+    // level-0 buffers at the start of the captured V-cycle (eager V-cycles start from the current ones)
+    bool fuse_first0 = false;
+    double *entry_x = nullptr, *entry_r = nullptr, *entry_d0 = nullptr;
 };
 
 struct knp_ctx;
