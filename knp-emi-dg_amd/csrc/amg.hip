@@ -804,7 +804,7 @@ int knp_amg_finish(knp_ctx* c, int which, int64_t n, const double* pinv) {
     std::vector<float> p32((size_t)n * n);
     for (size_t i = 0; i < p32.size(); ++i) p32[i] = (float)pinv[i];
     int rc = up(c, &H->pinv, p32.data(), p32.size());
-    static const bool fuse_env = !(getenv("KNP_FUSE_FIRST0") && atoi(getenv("KNP_FUSE_FIRST0")) == 0);
+    const bool fuse_env = !(getenv("KNP_FUSE_FIRST0") && atoi(getenv("KNP_FUSE_FIRST0")) == 0);   // read per upload: tests switch it
     H->fuse_first0 = fuse_env && !c->dist && H->ntiles > 0 && H->levels.size() > 1 && H->levels[0].cheb_degree > 0;
     H->ready = (rc == 0);
     return rc;

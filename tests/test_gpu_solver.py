@@ -174,15 +174,19 @@ def test_active_time_loop(hip_lib, dim, degree):
     assert abs(float(t) - 3e-4) < 1e-12
 
 
-def test_fused_chebyshev_restriction_equals_two_passes(hip_lib, monkeypatch):
+@pytest.mark.parametrize("switch", ["KNP_FUSE_RESTRICT", "KNP_FUSE_FIRST0"])
+def test_fused_chebyshev_restriction_equals_two_passes(hip_lib, monkeypatch, switch):
     """The second Chebyshev block-Jacobi step fused with stage 1 of the tile-wise restriction (k_bj_cheb2_restrict, default) against
-    the two separate kernels (KNP_FUSE_RESTRICT=0): same preconditioner, so the same iteration counts and, to rounding, the same
-    fields after three stimulated steps of the 4-axon mesh with its AMG hierarchies (PCG for EMI, BiCGStab and GMRES for KNP)."""
+    the two separate kernels (KNP_FUSE_RESTRICT=0), and the finest conforming level's first Chebyshev update written by stage 2 of the
+    restriction -- into the buffers the captured V-cycle reads -- against its own launch (KNP_FUSE_FIRST0=0): same preconditioner, so the
+    same iteration counts and, to rounding, the same fields after three stimulated steps of the 4-axon mesh with its AMG hierarchies
+    (PCG for EMI, BiCGStab and GMRES for KNP).  The coarse-size limit leaves a level below the finest one on this small mesh."""
+    monkeypatch.setenv("KNP_AMG_MAXCOARSE", "300")
     from idealized_common import make_solver, solver_parameters, Constant
     out = {}
     for krylov in ("bicgstab", "gmres"):
         for fused in ("1", "0"):
-            monkeypatch.setenv("KNP_FUSE_RESTRICT", fused)
+            monkeypatch.setenv(switch, fused)
             S = make_solver(dim=3, resolution=0, n_axons=4)
             S._unpack_solver_params(solver_parameters(3, 0))
             S.save_fields = S.save_solver_stats = False
