@@ -173,6 +173,10 @@ int knp_knp_solve(knp_ctx* ctx, double rtol, double atol, int maxit, int min_it,
  * src/knpemidg/solver.py:684-701); same preconditioner and the same stopping test on the true residual either way.  niter of a GMRES
  * solve counts Arnoldi steps (= preconditioner applications). */
 int knp_set_knp_krylov(knp_ctx* ctx, int method, int restart);
+/* DG-level smoother of the EMI preconditioner (stands in for pc_type hypre on BB_emi, solver.py:433, 505): 1 = two-step Chebyshev
+ * block-Jacobi (one more operator apply per PCG iteration, fewer iterations), 0 = plain cell-block-Jacobi, -1 = default (1 for DG-P1).
+ * Every rank of a partitioned run must pass the same value (the preconditioner has to be one symmetric operator). */
+int knp_set_emi_dg_smoother(knp_ctx* ctx, int chebyshev);
 
 /* ---- auxiliary-space AMG preconditioner (stands in for pc_type hypre, solver.py:433, 688) ---------------
  * M^-1 = cell-block-Jacobi + P Ac^+ P^T with Ac the conforming (membrane-broken) P1 operator; the hierarchy is

@@ -693,7 +693,10 @@ int knp_emi_solve(knp_ctx* c, double rtol, double atol, int maxit, int check_eve
     // parity bounds need (rtol 2e-8, knpemidg/solver.py) it cuts the PCG iterations from 5.2 to 4.2 per step and the
     // error of phi by 2x at equal tolerance (r=1, 40 steps through an action potential) for one more apply per iteration
     static const int cheb_env_emi = getenv("KNP_EMI_CHEB") ? atoi(getenv("KNP_EMI_CHEB")) : -1;
-    const int cheb_emi = cheb_env_emi >= 0 ? cheb_env_emi : (c->degree == 1 ? 1 : 0);
+    // Round 3: with the finest conforming level smoothed, the step no longer pays on large uniform meshes (r=2: 4.25 -> 4.7 iterations
+    // for 27 % less work per iteration, 7.35 -> 7.14 ms/step; r=3 48.9 -> 46.0) while small or badly shaped meshes still need it (EMIx:
+    // 9.2 -> 13.5 iterations): the host decides per mesh (knp_set_emi_dg_smoother; knpemidg/solver.py), the environment overrides
+    const int cheb_emi = cheb_env_emi >= 0 ? cheb_env_emi : (c->degree == 1 ? (c->emi_dg_cheb >= 0 ? c->emi_dg_cheb : 1) : 0);
     if (cheb_emi && c->amg.size() && c->amg[0].ready) {
         if (!f->tmp_emi) HIPCHK(c, hipMalloc((void**)&f->tmp_emi, sizeof(double) * f->n[KNP_F_PHI]));
         kv.tmp = f->tmp_emi;
@@ -860,6 +863,14 @@ int knp_set_knp_krylov(knp_ctx* c, int method, int restart) {
     if (method == 1 && (restart < 2 || restart > KNP_GM_MAX)) { c->err = "knp_set_knp_krylov: restart length 2.." + std::to_string(KNP_GM_MAX); return -1; }
     c->knp_krylov = method;
     if (method == 1) c->gm_restart = restart;
+    return 0;
+}
+
+int knp_set_emi_dg_smoother(knp_ctx* c, int chebyshev) {
+    if (!c) return -1;
+    if (chebyshev < -1 || chebyshev > 1) { c->err = "knp_set_emi_dg_smoother: -1 (default), 0 or 1"; return -1; }
+    if (chebyshev != c->emi_dg_cheb) F(c)->bj_lmax_emi = 0.0;       // (the bound is estimated at the next solve that needs it)
+    c->emi_dg_cheb = chebyshev;
     return 0;
 }
 

@@ -120,6 +120,7 @@ struct knp_ctx {
     int* status = nullptr;         // device: per system {converged flag, iterations}, then the ODE failure flag
     void* pinned = nullptr;        // host pinned mirror for status/scalars
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int emi_dg_cheb = -1;          // DG-level Chebyshev step of the EMI preconditioner: -1 default (on for degree 1), 0 / 1 (knp_set_emi_dg_smoother)
     int knp_krylov = 0;            // KNP Krylov method: 0 BiCGStab (default), 1 restarted GMRES (knp_set_knp_krylov)
     int gm_restart = 30;
     double* gm_V = nullptr;        // GMRES basis, allocated at the first GMRES solve

@@ -53,6 +53,7 @@ SIGNATURES = {
     "knp_emi_solve": (C.c_int, [_ctxp, C.c_double, C.c_double, C.c_int, C.c_int, C.POINTER(C.c_int), _f64p]),
     "knp_knp_solve": (C.c_int, [_ctxp, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), _f64p]),
     "knp_set_knp_krylov": (C.c_int, [_ctxp, C.c_int, C.c_int]),
+    "knp_set_emi_dg_smoother": (C.c_int, [_ctxp, C.c_int]),
     "knp_step_updates": (C.c_int, [_ctxp]),
     "knp_nernst": (C.c_int, [_ctxp]),
     "knp_picard_updates": (C.c_int, [_ctxp]),
@@ -447,6 +448,10 @@ class Device:
         """KNP Krylov method: 'bicgstab' (default) or 'gmres' (restarted, the reference's GMRES(30): solver.py:684-701)."""
         code = {"bicgstab": 0, "gmres": 1}[method] if isinstance(method, str) else int(method)
         self._chk(self.lib.knp_set_knp_krylov(self.ctx, code, int(restart)), "knp_set_knp_krylov")
+
+    def set_emi_dg_smoother(self, chebyshev):
+        """DG-level smoother of the EMI preconditioner: True = two-step Chebyshev block-Jacobi, False = plain block-Jacobi, None = default."""
+        self._chk(self.lib.knp_set_emi_dg_smoother(self.ctx, -1 if chebyshev is None else int(bool(chebyshev))), "knp_set_emi_dg_smoother")
 
     def step_updates(self):
         self._chk(self.lib.knp_step_updates(self.ctx), "knp_step_updates")

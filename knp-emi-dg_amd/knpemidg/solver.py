@@ -303,10 +303,34 @@ class Solver:
         # block-Jacobi preconditioner: it stays SPD to rounding for any coefficient contrast (the MMS problem couples
         # the membrane with C_phi = 1e10), which a V-cycle does not
         if self.use_amg and not self.direct_emi:
+            self.dev.set_emi_dg_smoother(self._emi_dg_chebyshev())
             self._setup_amg_emi()
         else:
             self._drop_emi_helper()
         return
+
+    def _emi_dg_chebyshev(self):
+        """Whether the EMI preconditioner smooths the DG level with a two-step Chebyshev block-Jacobi (one more operator apply per PCG
+        iteration) or with plain block-Jacobi.  With the finest conforming level smoothed (round 3) the extra step no longer pays on LARGE
+        UNIFORM meshes -- r=2: 4.25 -> 4.7 iterations for a quarter less work per iteration (7.35 -> 7.14 ms/step), r=3 48.9 -> 46.0 -- while
+        small meshes (launch-latency regime: the apply is a small part of an iteration) and badly shaped ones (EMIx reconstruction, cell
+        volumes over 6 decades: 9.2 -> 13.5 iterations without it) keep it (profiles/r03_emi_dg_smoother.txt).  Decided from GLOBAL mesh
+        quantities only, so that every rank of a partitioned run builds the same (symmetric) preconditioner; `emi_dg_chebyshev` in
+        solver_params decides explicitly."""
+        sp = getattr(self, "solver_params", None)
+        explicit = getattr(sp, "emi_dg_chebyshev", None)
+        if explicit is not None:
+            return bool(explicit)
+        if self.degree_knp != 1:
+            return None
+        g = getattr(self, "global_mesh_tuple", None)
+        mesh = g[0] if g is not None else self.mesh
+        if mesh.gdim != 3 or mesh.num_cells() < 400000:
+            return True
+        x = mesh.coords[mesh.cells]
+        e = x[:, 1:] - x[:, :1]
+        vol = np.abs(np.einsum("ci,ci->c", e[:, 0], np.cross(e[:, 1], e[:, 2])))        # 6 x cell volume
+        return bool(vol.max() > 10.0 * vol.min())
 
     def _host_initial_kappa(self):
         """kappa = F psi sum_k z_k^2 D_k c_k of the initial state, nodal [nc, nd] (what k_kappa computes on the device)."""
