@@ -696,7 +696,7 @@ int knp_emi_solve(knp_ctx* c, double rtol, double atol, int maxit, int check_eve
     // Round 3: with the finest conforming level smoothed, the step no longer pays on large uniform meshes (r=2: 4.25 -> 4.7 iterations
     // for 27 % less work per iteration, 7.35 -> 7.14 ms/step; r=3 48.9 -> 46.0) while small or badly shaped meshes still need it (EMIx:
     // 9.2 -> 13.5 iterations): the host decides per mesh (knp_set_emi_dg_smoother; knpemidg/solver.py), the environment overrides
-    const int cheb_emi = cheb_env_emi >= 0 ? cheb_env_emi : (c->degree == 1 ? (c->emi_dg_cheb >= 0 ? c->emi_dg_cheb : 1) : 0);
+    const int cheb_emi = cheb_env_emi >= 0 ? cheb_env_emi : (c->emi_dg_cheb >= 0 ? c->emi_dg_cheb : (c->degree == 1 ? 1 : 0));
     if (cheb_emi && c->amg.size() && c->amg[0].ready) {
         if (!f->tmp_emi) HIPCHK(c, hipMalloc((void**)&f->tmp_emi, sizeof(double) * f->n[KNP_F_PHI]));
         kv.tmp = f->tmp_emi;
@@ -825,6 +825,8 @@ int knp_knp_solve(knp_ctx* c, double rtol, double atol, int maxit, int min_it, i
     // action potential at r=2, -10 % per step).  lambda_max(Binv A) comes from a power iteration at the first solve.
     // Degree 1 only by default: the assembled P2 apply is 3x as expensive and the trade does not pay (21 -> 25 ms/step).
     static const int cheb_env = getenv("KNP_KNP_CHEB") ? atoi(getenv("KNP_KNP_CHEB")) : -1;
+    // (round 3, matrix-free P2 applies: with the step DG-P2 takes 8.1 -> 6.1 KNP iterations and steps 5 % faster at r=2, but 40 steps of
+    // the P2 configuration then end with 1.08e-6 in the concentrations against the 1e-6 bound: not enabled)
     const int cheb = cheb_env >= 0 ? cheb_env : (c->degree == 1 ? 1 : 0);
     if (cheb && c->p.n_sys <= 4) {
         if (!f->tmp_knp) HIPCHK(c, hipMalloc((void**)&f->tmp_knp, sizeof(double) * f->n[KNP_F_C]));

@@ -1,11 +1,8 @@
 #!/bin/bash
-# DG-level Chebyshev step of the EMI preconditioner: default (decided per mesh by Solver._emi_dg_chebyshev) against forced on / off
+# DG-P2 with the DG-level Chebyshev steps by the new default rule: accuracy (P2 r=1, 40 steps) + tests + bench lines
 cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out
-o=gpurun_out/r03_emi_dg_smoother.txt
-echo "# tools/ab_tmp.sh: bench.py --steps 20 --warmup 5 (r=3: 8 + 3) with the DG-level Chebyshev step of the EMI preconditioner by default rule, forced on (KNP_EMI_CHEB=1) and forced off (KNP_EMI_CHEB=0); ms/step, EMI / KNP iterations per step" > $o
-for env in "KNP_DEBUG=0" "KNP_EMI_CHEB=1" "KNP_EMI_CHEB=0"; do
- for w in "--resolution 2" "--resolution 1" "--workload emix" "--resolution 3 --steps 8 --warmup 3"; do
-  env $env python bench.py --steps 20 --warmup 5 $w --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$env'.replace('KNP_DEBUG=0','default      '),'$w', round(d['ms_per_step'],3), d['config']['emi_iters_per_step'], d['config']['knp_iters_per_step'])" >> $o
- done
+
+timeout -k 10 600 python -m pytest tests/test_gpu_solver.py tests/test_gpu_trajectory.py -x -q > gpurun_out/q_p2.log 2>&1; tail -3 gpurun_out/q_p2.log
+for w in "--resolution 1 --steps 20 --warmup 5" "--resolution 2 --steps 10 --warmup 3"; do
+  python bench.py --degree 2 $w --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('default','$w', round(d['ms_per_step'],3), d['config']['emi_iters_per_step'], d['config']['knp_iters_per_step'])"
 done
-cat $o
