@@ -274,3 +274,95 @@ def share_count(D, n):
     for d in D:
         cnt[d.verts] += 1.0
     return cnt
+
+
+def _dist0_worker(rank, world, port, q, method, degree):
+    """One rank of test_row_distributed_level0_gloo: holds only ITS rows of the finest conforming level, exchanges the shared dofs with
+    its peers through torch.distributed (gloo) and all-reduces the level-1 right-hand side -- the communication pattern of
+    csrc/comm.hip interface_accumulate + csrc/amg.hip amg_vcycle_dist0."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["KNP_AMG_MAXCOARSE"] = "60"
+    for p in (os.path.join(ROOT, "knp-emi-dg_amd"), os.path.join(ROOT, "tests")):
+        sys.path.insert(0, p)
+    import torch
+    import torch.distributed as dist
+    from common import small_3d
+    from knpemidg import amg
+    from knpemidg.partition import Partition
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        mesh, sub, surf = small_3d((8, 4, 4))
+        cs = amg.ConformingSpace(mesh, surf.array(), [1])
+        space = cs if degree == 1 else amg.ConformingSpaceP2(cs)
+        rng = np.random.default_rng(5)                                     # same stream on every rank: global data, as in a partitioned run
+        kappa = rng.uniform(0.5, 1.5, size=(mesh.num_cells(), space.dof.shape[1]))
+        mem = np.nonzero((mesh.facet_cells[:, 1] >= 0) & np.isin(surf.array(), [1]))[0]
+        levels = amg.build_emi_levels(cs, space if degree == 2 else None, surf.array(), [1], kappa, 2.0e2)
+        g = levels[0]
+        A = g.A
+        part = Partition(mesh, world, method=method)
+        d0 = amg.Dist0Space(space, part.owner, mem, rank, world)
+        loc = d0.localize(levels, d0.local_matrix(kappa, membrane_C=2.0e2))[0]
+        peers, lists, uvtx, aptr, asrc = d0.interface_tables()
+        off = np.concatenate([[0], np.cumsum([len(l) for l in lists])]).astype(int)
+
+        def accumulate(v):
+            send = [torch.from_numpy(np.ascontiguousarray(v[l])) for l in lists]
+            recv = [torch.empty(len(l), dtype=torch.float64) for l in lists]
+            reqs = [dist.isend(s_, p_) for s_, p_ in zip(send, peers)] + [dist.irecv(r_, p_) for r_, p_ in zip(recv, peers)]
+            for rq in reqs:
+                rq.wait()
+            rbuf = np.concatenate([r_.numpy() for r_ in recv]) if recv else np.zeros(0)
+            w = v.copy()
+            for u in range(len(uvtx)):
+                s_ = 0.0
+                for k in range(aptr[u], aptr[u + 1]):
+                    s_ += v[uvtx[u]] if asrc[k] < 0 else rbuf[asrc[k]]
+                w[uvtx[u]] = s_
+            return w
+        assert off[-1] == sum(len(l) for l in lists)
+        lmax, lmin = g.rho, g.cheb_lower * g.rho
+        theta = 0.5 * (lmax + lmin)
+        b = A @ rng.standard_normal(space.n) + 0.1 * rng.standard_normal(space.n)
+        Cmap = rng.standard_normal(g.P.shape[1]) * 1e-3
+        # global reference (one Chebyshev step per smoothing: the shipped level-0 smoother of the P1 hierarchies)
+        xg = g.dinv * b / theta
+        xg = xg + g.P @ (Cmap * (g.P.T @ (b - A @ xg)))
+        xg = xg + g.dinv * (b - A @ xg) / theta
+        # this rank's share of b: full values on dofs it alone holds, an equal split on shared ones (what matters is that the parts add up)
+        cnt = np.zeros(space.n)
+        for vq in d0.rank_verts:
+            cnt[vq] += 1.0
+        bp = b[d0.verts] / cnt[d0.verts]
+        x = loc.dinv * accumulate(bp) / theta
+        r1 = torch.from_numpy(loc.R @ (bp - loc.A @ x))
+        dist.all_reduce(r1)
+        x = x + loc.P @ (Cmap * r1.numpy())
+        x = x + loc.dinv * accumulate(bp - loc.A @ x) / theta
+        q.put((rank, float(np.abs(x - xg[d0.verts]).max() / np.abs(xg).max())))
+    except Exception:                                                     # pragma: no cover
+        import traceback
+        q.put((rank, "ERR " + traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,method,degree", [(2, "slab", 1), (3, "rcb", 1), (2, "slab", 2)])
+def test_row_distributed_level0_gloo(world, method, degree):
+    """The row-distributed finest conforming level with one PROCESS per rank: every rank builds only its own rows and tables
+    (knpemidg.amg.Dist0Space), the shared dofs travel point to point and the level-1 right-hand side through an all-reduce (gloo); one
+    level-0 visit of the V-cycle equals the global one on every rank's rows."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000) + world + 10 * degree
+    procs = [ctx.Process(target=_dist0_worker, args=(r, world, port, q, method, degree)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, e in res:
+        assert not isinstance(e, str), e
+        assert e < 1e-10, (rank, e)
