@@ -453,6 +453,46 @@ __global__ __launch_bounds__(KNP_BLOCK) void k_cg_update(VecDims d, const double
     write_partials<3>(partial, 1, acc);
 }
 
+// The same update fused with stage 1 of the tile-wise restriction of the auxiliary-space correction (amg.hip: k_restrict_tiles), for
+// preconditioners WITHOUT the DG-level Chebyshev step (large uniform meshes, knp_set_emi_dg_smoother): the restricted vector is the new
+// residual, which this kernel has in registers -- one pass over r less per PCG iteration (r=3: 104 us).  No partial sums: with a
+// hierarchy k_prolong_dot forms them from the corrected z.  grid = tiles of tile_cells consecutive owned cells.
+template <int NV>
+__global__ __launch_bounds__(256) void k_cg_update_restrict(VecDims d, const double* __restrict__ scal, const int* __restrict__ status,
+                                                            const double* __restrict__ p, const double* __restrict__ w,
+                                                            const bjreal* __restrict__ binv, double* __restrict__ x, double* __restrict__ r,
+                                                            double* __restrict__ z, int tile_cells, const int32_t* __restrict__ tile_off,
+                                                            const int32_t* __restrict__ slot_ptr, const uint16_t* __restrict__ slot_idx,
+                                                            double* __restrict__ part) {
+    extern __shared__ double s_r[];
+    if (status[0]) return;                                     // converged: the V-cycle's output is not used either
+    const double alpha = scal[KS_ALPHA];
+    const int64_t c0 = (int64_t)blockIdx.x * tile_cells;
+    const int ncell = (int)((d.nc_owned - c0 < tile_cells) ? (d.nc_owned - c0) : tile_cells);
+    for (int i = threadIdx.x; i < ncell; i += 256) {
+        const int64_t c = c0 + i;
+        double pv[NV], wv[NV], xv[NV], rv[NV], zv[NV];
+        ldv<NV>(p, c, pv);
+        ldv<NV>(w, c, wv);
+        ldv<NV>(x, c, xv);
+        ldv<NV>(r, c, rv);
+#pragma unroll
+        for (int a = 0; a < NV; ++a) { xv[a] += alpha * pv[a]; rv[a] -= alpha * wv[a]; s_r[i * NV + a] = rv[a]; }
+        block_matvec<NV>(binv, c, rv, zv);
+        stv<NV>(x, c, xv);
+        stv<NV>(r, c, rv);
+        stv<NV>(z, c, zv);
+    }
+    __syncthreads();
+    const int p1 = tile_off[blockIdx.x + 1];
+    for (int q = tile_off[blockIdx.x] + threadIdx.x; q < p1; q += 256) {
+        double acc = 0.0;
+        const int e = slot_ptr[q + 1];
+        for (int k = slot_ptr[q]; k < e; ++k) acc += s_r[slot_idx[k]];
+        part[q] = acc;
+    }
+}
+
 // z += P e (conforming correction, gathered through dg2cg) ; partials r.z, z.z, ||r||_w^2 (NR = 3)  |  on init (NR = 4): r.z, z.z,
 // (Minv b).(Minv b), ||r||_w^2
 template <int NV, int NR>
@@ -905,6 +945,11 @@ static bool fuse_restrict(const knp_ctx* c, const KrylovVecs& kv, const AmgHiera
     return on && kv.bj_lmax > 0.0 && H.ready && H.ntiles > 0 && H.ncol == nsys && H.tile_cells * c->nd * sizeof(double) <= 65536;
 }
 
+static bool fuse_update_restrict(const knp_ctx* c, const AmgHierarchy& H) {
+    const char* e = getenv("KNP_FUSE_CG_RESTRICT");        // read per call: tests switch it inside one process
+    return !(e && atoi(e) == 0) && H.ready && H.ntiles > 0 && H.ncol == 1 && H.tile_cells * c->nd * sizeof(double) <= 65536;
+}
+
 // power iteration for lambda_max(Binv A) of the batched KNP operator (inf-norm normalisation; max over the species)
 template <int NV, bool EMI>
 static int bj_lambda_max_impl(knp_ctx* c, KrylovVecs& kv, int iters, double* out) {
@@ -982,10 +1027,22 @@ static int pcg_impl(knp_ctx* c, KrylovVecs& kv, double rtol, double atol, int ma
             hipLaunchKernelGGL(k_dot2<NV>, dim3(g.x, 1), b, 0, c->stream, d, kv.p, kv.w, (const double*)nullptr,
                                (const double*)nullptr, c->partial, c->status);
             if ((rc = finalize(c, OP_CG_ALPHA, 1, 1, rtol, atol, 0))) return rc;
-            hipLaunchKernelGGL(k_cg_update<NV>, g, b, 0, c->stream, d, c->scal, c->status, kv.p, kv.w, kv.binv, kv.x, kv.r, kv.z,
-                               c->partial);
+            // no DG-level Chebyshev step: the update and stage 1 of the restriction of the new residual in one pass (KNP_FUSE_CG_RESTRICT=0: two)
+            const bool fuse_upd = H && !(kv.bj_lmax > 0.0) && fuse_update_restrict(c, *H);
+            if (fuse_upd) {
+                if ((rc = amg_restrict_tiles_prepare(c, *H))) return rc;
+                hipLaunchKernelGGL(k_cg_update_restrict<NV>, dim3((unsigned)H->ntiles), dim3(256), sizeof(double) * H->tile_cells * NV, c->stream, d,
+                                   c->scal, c->status, kv.p, kv.w, kv.binv, kv.x, kv.r, kv.z, H->tile_cells, (const int32_t*)H->tile_off,
+                                   (const int32_t*)H->slot_ptr, (const uint16_t*)H->slot_idx, H->part);
+                if ((rc = amg_restrict_finish(c, *H))) return rc;
+            } else {
+                hipLaunchKernelGGL(k_cg_update<NV>, g, b, 0, c->stream, d, c->scal, c->status, kv.p, kv.w, kv.binv, kv.x, kv.r, kv.z,
+                                   c->partial);
+            }
             if (H) {
-                if (fuse_restrict(c, kv, *H, 1)) {
+                if (fuse_upd) {
+                    // restricted already
+                } else if (fuse_restrict(c, kv, *H, 1)) {
                     if ((rc = bj_cheb2<NV, true>(c, d, kv, kv.r, kv.z, true, H, 0.0))) return rc;
                 } else {
                     if (kv.bj_lmax > 0.0 && (rc = bj_cheb2<NV, true>(c, d, kv, kv.r, kv.z))) return rc;

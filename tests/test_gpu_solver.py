@@ -174,11 +174,12 @@ def test_active_time_loop(hip_lib, dim, degree):
     assert abs(float(t) - 3e-4) < 1e-12
 
 
-@pytest.mark.parametrize("switch", ["KNP_FUSE_RESTRICT", "KNP_FUSE_FIRST0"])
+@pytest.mark.parametrize("switch", ["KNP_FUSE_RESTRICT", "KNP_FUSE_FIRST0", "KNP_FUSE_CG_RESTRICT"])
 def test_fused_chebyshev_restriction_equals_two_passes(hip_lib, monkeypatch, switch):
     """The second Chebyshev block-Jacobi step fused with stage 1 of the tile-wise restriction (k_bj_cheb2_restrict, default) against
     the two separate kernels (KNP_FUSE_RESTRICT=0), and the finest conforming level's first Chebyshev update written by stage 2 of the
-    restriction -- into the buffers the captured V-cycle reads -- against its own launch (KNP_FUSE_FIRST0=0): same preconditioner, so the
+    restriction -- into the buffers the captured V-cycle reads -- against its own launch (KNP_FUSE_FIRST0=0), and the PCG update fused with
+    stage 1 of the restriction of the new residual (k_cg_update_restrict) against two kernels (KNP_FUSE_CG_RESTRICT=0): same preconditioner, so the
     same iteration counts and, to rounding, the same fields after three stimulated steps of the 4-axon mesh with its AMG hierarchies
     (PCG for EMI, BiCGStab and GMRES for KNP).  The coarse-size limit leaves a level below the finest one on this small mesh."""
     monkeypatch.setenv("KNP_AMG_MAXCOARSE", "300")
@@ -188,7 +189,13 @@ def test_fused_chebyshev_restriction_equals_two_passes(hip_lib, monkeypatch, swi
         for fused in ("1", "0"):
             monkeypatch.setenv(switch, fused)
             S = make_solver(dim=3, resolution=0, n_axons=4)
-            S._unpack_solver_params(solver_parameters(3, 0))
+            sp = solver_parameters(3, 0)
+            if switch == "KNP_FUSE_CG_RESTRICT":
+                # the PCG update fused with the restriction of the new residual (k_cg_update_restrict) exists for EMI preconditioners
+                # without the DG-level Chebyshev step, which a mesh of this size would keep: switched off explicitly
+                from collections import namedtuple
+                sp = namedtuple("solver_params", sp._fields + ("emi_dg_chebyshev",))(*sp, False)
+            S._unpack_solver_params(sp)
             S.save_fields = S.save_solver_stats = False
             S.splitting_scheme = True
             S.setup_varform_emi(); S.setup_varform_knp(); S.setup_solver_emi(); S.setup_solver_knp()
