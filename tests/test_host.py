@@ -346,3 +346,35 @@ def test_knp_hierarchy_helper_process_matches_in_process(degree):
         assert a.A.shape == b.A.shape and (a.A != b.A).nnz == 0
     bad = setup_worker.start({"coords": None})
     assert setup_worker.collect(bad) is None
+
+
+def test_emi_dg_smoother_rule_uses_global_mesh_quantities_only():
+    """knpemidg/solver.py: Solver._emi_dg_chebyshev -- the DG-level Chebyshev step of the EMI preconditioner is dropped on large uniform 3D
+    meshes only, kept on small and on badly shaped ones, decided from the GLOBAL mesh (every rank of a partitioned run must build the same
+    symmetric preconditioner), and solver_params decides explicitly when it says so."""
+    import types
+    from collections import namedtuple
+    from knpemidg.solver import Solver
+    from knpemidg.mesh import make_mesh_3D
+
+    def rule(mesh, degree=1, global_mesh=None, explicit=None):
+        S = Solver.__new__(Solver)
+        S.degree_knp = degree
+        S.mesh = mesh
+        if global_mesh is not None:
+            S.global_mesh_tuple = (global_mesh, None, None)
+        if explicit is not None:
+            S.solver_params = namedtuple("solver_params", ("emi_dg_chebyshev",))(explicit)
+        return S._emi_dg_chebyshev()
+    small = make_mesh_3D(0)[0]
+    large = make_mesh_3D(2)[0]
+    assert large.num_cells() >= 400000 > small.num_cells()
+    assert rule(small) is True and rule(large) is False
+    assert rule(small, global_mesh=large) is False and rule(large, global_mesh=small) is True      # a partition follows the global mesh
+    assert rule(large, degree=2) is False and rule(small, degree=2) is False                        # DG-P2 keeps plain block-Jacobi
+    assert rule(large, explicit=True) is True and rule(small, explicit=False) is False
+    # the same cell count with cell volumes over two decades (graded in x): the step stays
+    x = large.coords.copy()
+    x[:, 0] = x[:, 0].min() + (x[:, 0] - x[:, 0].min()) ** 3 / (np.ptp(x[:, 0]) ** 2)
+    graded = types.SimpleNamespace(coords=x, cells=large.cells, gdim=3, num_cells=large.num_cells)
+    assert rule(graded) is True
