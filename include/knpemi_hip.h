@@ -305,6 +305,11 @@ int knp_set_interior(knp_ctx* ctx, int64_t n_interior);
 int knp_halo_tables(knp_ctx* ctx, int npeers, const int32_t* peers, const int64_t* send_counts,
                     const int32_t* send_cells, const int64_t* recv_offsets, const int64_t* recv_counts);
 int knp_halo_exchange(knp_ctx* ctx, int field);
+/* Sum of n <= 56 host scalars over the ranks of a partitioned run (one ncclAllReduce on the solver's stream; every rank receives the
+ * same bits); leaves the values untouched without a communicator.  The host side uses it where a quantity that steers the solve
+ * must be the SAME on all ranks: the step-0 residual target of the EMI solve (the reference gets this from PETSc's VecNorm over
+ * the MPI communicator, src/knpemidg/solver.py:505-509) and the timings of the smoother selection (knpemidg/solver.py). */
+int knp_allreduce_sum(knp_ctx* ctx, double* values, int n);
 
 #ifdef __cplusplus
 }

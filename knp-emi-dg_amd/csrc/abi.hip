@@ -25,6 +25,7 @@ struct Fields {
     double bj_lmax_knp = 0.0;      // lambda_max(Binv A_knp) estimate (power iteration; redone after every reset of the lagged
     int bj_lmax_age = 0;           // inverses, every 64 solves, and when the iteration count jumps by > 1.5x)
     int it_ref_knp = 0, it_ref_emi = 0;   // iteration counts right after the last estimate
+    int bj_used_tab = -1;          // block set of the last KNP solve (1: drift-free class table, 0: per-cell inverses); a flip redoes the estimate
     double* tmp_emi = nullptr;
     double bj_lmax_emi = 0.0;
     int bj_lmax_emi_age = 0;
@@ -623,7 +624,14 @@ int knp_update_dnphi(knp_ctx* c) {
         hipLaunchKernelGGL(k_cell_peclet, dim3((unsigned)((c->m.nc_owned + 255) / 256)), dim3(256), 0, c->stream, c->m.nc_owned, c->nd,
                            (const double*)f->f[KNP_F_PHI], c->p.psi * zmax, c->status + KNP_PECLET_SLOT);
     HIPCHK(c, hipGetLastError());
+    // partitioned runs: the max over ALL ranks, so that every rank of a solve applies the same preconditioner blocks (knp_knp_solve)
+    if (c->dist) { int rc = allreduce_max_word(c, c->status + KNP_PECLET_SLOT); if (rc) return rc; }
     return launch_dnphi(c, f->f[KNP_F_PHI], f->f[KNP_F_DNPHI]);
+}
+
+int knp_allreduce_sum(knp_ctx* c, double* values, int n) {
+    if (!c || !values) return -1;
+    return allreduce_sum_host(c, values, n);
 }
 
 static int chk_vec(knp_ctx* c, int fx, int fy, int64_t need) {
@@ -800,6 +808,11 @@ int knp_knp_solve(knp_ctx* c, double rtol, double atol, int maxit, int min_it, i
         memcpy(&c->last_peclet, &bits, sizeof(float));
     }
     if (use_tab && !(c->last_peclet <= pe_limit)) use_tab = false;
+    if ((int)use_tab != f->bj_used_tab) {         // another block set: its lambda_max and reference iteration count are not this one's
+        f->bj_lmax_knp = 0.0;
+        f->it_ref_knp = 0;
+        f->bj_used_tab = (int)use_tab;
+    }
     if (use_tab) {
         f->bj_age_knp = 0;                        // a later fall-back to the per-cell array starts with a rebuild (its content is the drift-free one)
     } else {

@@ -37,16 +37,16 @@ constexpr int RCLS = 43;          // LDS stride of a geometry-class record (odd:
 static_assert(RB == KNP_HALO_BLK, "the halo tables are built for 256-cell blocks");
 
 // one LDS-DMA instruction: lane l copies 16 bytes from its own source address to (lds_dst + 16 l); lds_dst is wave-uniform.  M0 is
-// written in the statement that reads it and not restored: nothing else in these kernels reads M0 (plain LDS accesses do not).
+// written in the statement that reads it and declared clobbered, so the compiler never assumes a value of its own survives.
 __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gsrc), "s"(lds_dst) : "memory");
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gsrc), "s"(lds_dst) : "memory", "m0");
 }
 // four consecutive 1 KiB pieces from ONE address register and ONE M0 value: the instruction offset moves both the global and the
 // LDS address (checked by tools/microbench/glds_ring.hip)
 __device__ __forceinline__ void glds16_run4(const void* gsrc, unsigned lds_dst) {
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off\n\tglobal_load_lds_dwordx4 %0, off offset:1024\n\t"
                  "global_load_lds_dwordx4 %0, off offset:2048\n\tglobal_load_lds_dwordx4 %0, off offset:3072"
-                 : : "v"(gsrc), "s"(lds_dst) : "memory");
+                 : : "v"(gsrc), "s"(lds_dst) : "memory", "m0");
 }
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory"); }
 // workgroup barrier that orders LDS traffic only: the loader's DMAs stay in flight across it (it counts them itself), the
@@ -598,7 +598,11 @@ template <typename KernelT> bool ring_grant_lds(KernelT kernel, size_t lds) {
 dim3 ring_grid(const MeshDev& m, int device, int reserve_cus) {
     const int64_t nblk = (m.c_end - 1) / RB - m.c_begin / RB + 1;
     const int cus = std::max(device_cus(device) - std::max(reserve_cus, 0), 8);
-    const int64_t per_xcd = std::max<int64_t>(1, std::min<int64_t>(cus / 8, (nblk + 7) / 8));
+    int64_t per_xcd = std::max<int64_t>(1, std::min<int64_t>(cus / 8, (nblk + 7) / 8));
+    // tests only: KNP_RING_WG = workgroups of the launch (rounded down to a multiple of 8), so that small oracle-sized meshes put many
+    // blocks on a workgroup (slot reuse, list-buffer wrap, counted vmcnt with two blocks in flight: the steady state of the r=2 runs)
+    const int wg = env_int_ring("KNP_RING_WG", 0);
+    if (wg >= 8) per_xcd = std::min<int64_t>(per_xcd, wg / 8);
     return dim3((unsigned)(8 * per_xcd));
 }
 

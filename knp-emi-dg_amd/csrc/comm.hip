@@ -69,6 +69,42 @@ int allreduce_max(knp_ctx* c, double* host_value) {
     return 0;
 }
 
+// max over the ranks of a status word holding the bits of a non-negative float (they order like ints): the cell Peclet number of
+// knp_update_dnphi, so that every rank of a solve picks the same block-Jacobi data.  RCCL: enqueued on the solver's stream, no host
+// synchronisation; shm (validation transport): staged through the host.
+int allreduce_max_word(knp_ctx* c, int* dev_word) {
+    if (c->shm) {
+        int bits = 0;
+        HIPCHK(c, hipMemcpyAsync(&bits, dev_word, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        float pe;
+        memcpy(&pe, &bits, sizeof(pe));
+        double v = pe;
+        int rc = allreduce_max(c, &v);
+        if (rc) return rc;
+        pe = (float)v;
+        memcpy(&bits, &pe, sizeof(pe));
+        HIPCHK(c, hipMemcpy(dev_word, &bits, sizeof(int), hipMemcpyHostToDevice));
+        return 0;
+    }
+    if (!c->comm) { c->err = "allreduce without communicator"; return -6; }
+    NCCLCHK(c, ncclAllReduce(dev_word, dev_word, 1, ncclInt32, ncclMax, (ncclComm_t)c->comm, c->stream));
+    return 0;
+}
+
+// sum over the ranks of n host values (n <= KNP_MAX_SYS * KNP_MAX_RED = 56), identical bits on every rank
+int allreduce_sum_host(knp_ctx* c, double* host_values, int n) {
+    if (n < 0 || n > KNP_MAX_SYS * KNP_MAX_RED) { c->err = "allreduce_sum_host: at most 56 values"; return -1; }
+    if (!c->dist || n == 0) return 0;
+    double* d = c->scal + KNP_MAX_SYS * 12;            // reduction scratch: KNP_MAX_SYS * KNP_MAX_RED doubles (krylov.hip)
+    HIPCHK(c, hipMemcpyAsync(d, host_values, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+    int rc = allreduce_red(c, d, n);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(host_values, d, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
 // out layout for one peer: [field][cell][nv]
 __global__ void k_halo_pack(const double* __restrict__ v, const int32_t* __restrict__ idx, int64_t cnt, int nfields,
                             int64_t field_stride, int nv, double* __restrict__ out) {
@@ -96,7 +132,7 @@ struct ShmHeader {
     std::atomic<uint32_t> arrive;
     std::atomic<uint32_t> gen;
     uint32_t nranks;
-    uint32_t pad;
+    std::atomic<uint32_t> fail;       // raised by a rank that cannot take part in an exchange; read by every rank behind the next barrier
     uint64_t red_cap, out_cap;
 };
 struct ShmDirEntry { int64_t peer, off, cnt; };
@@ -154,8 +190,9 @@ static int shm_halo_exchange(knp_ctx* c, double* v, int nfields, hipStream_t st)
     const int NV = c->nd;
     const int64_t stride = c->m.nc * NV;
     const int np = (int)c->halo_peer.size();
-    if ((uint64_t)(c->halo_send_total * KNP_MAX_SYS * NV) > s->out_cap) { c->err = "shm communicator: outbox too small (KNP_SHM_OUT_DOUBLES)"; return -6; }
-    for (int p = 0; p < np; ++p) {
+    const bool fits = (uint64_t)(c->halo_send_total * KNP_MAX_SYS * NV) <= s->out_cap;
+    if (!fits) s->hdr()->fail.store(1, std::memory_order_release);
+    for (int p = 0; p < np && fits; ++p) {
         const int64_t cnt = c->halo_send_cnt[p];
         if (!cnt) continue;
         const int64_t n = cnt * NV;
@@ -168,6 +205,7 @@ static int shm_halo_exchange(knp_ctx* c, double* v, int nfields, hipStream_t st)
     HIPCHK(c, hipStreamSynchronize(st));
     int rc;
     if ((rc = shm_barrier(c, s))) return rc;
+    if (s->hdr()->fail.load(std::memory_order_acquire)) { c->err = "shm communicator: outbox too small on a rank (KNP_SHM_OUT_DOUBLES)"; return -6; }
     for (int p = 0; p < np; ++p) {
         const int peer = c->halo_peer[p];
         const int64_t want = c->halo_recv_cnt[p];
@@ -219,12 +257,20 @@ __global__ void k_if_add(double* __restrict__ v, const int32_t* __restrict__ uvt
 
 static int shm_interface_exchange(knp_ctx* c, int ncol) {
     ShmComm* s = (ShmComm*)c->shm;
-    if ((uint64_t)(c->if_total * ncol) > s->out_cap) { c->err = "shm communicator: outbox too small for the interface exchange (KNP_SHM_OUT_DOUBLES)"; return -6; }
-    if (c->if_total)
+    // a rank whose outbox is too small must not leave before the barrier its peers wait in: it raises the segment's fail word and
+    // every rank returns the error behind the barrier
+    const bool fits = (uint64_t)(c->if_total * ncol) <= s->out_cap;
+    if (!fits) s->hdr()->fail.store(1, std::memory_order_release);
+    else if (c->if_total)
         HIPCHK(c, hipMemcpyAsync(s->out(s->rank), c->if_send, sizeof(double) * c->if_total * ncol, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     int rc;
     if ((rc = shm_barrier(c, s))) return rc;
+    if (s->hdr()->fail.load(std::memory_order_acquire)) {
+        c->err = fits ? "shm communicator: a peer's outbox is too small for the interface exchange"
+                      : "shm communicator: outbox too small for the interface exchange (KNP_SHM_OUT_DOUBLES)";
+        return -6;
+    }
     for (size_t p = 0; p < c->if_peer.size(); ++p) {
         const int peer = c->if_peer[p];
         const ShmDirEntry* d = s->dir_if(peer);

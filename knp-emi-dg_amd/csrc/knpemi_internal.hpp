@@ -232,6 +232,8 @@ int launch_nernst_only(knp_ctx* c, const double* cc, const double* celim, double
 void comm_destroy(knp_ctx* c);
 int allreduce_red(knp_ctx* c, double* red, int count);
 int allreduce_max(knp_ctx* c, double* host_value);
+int allreduce_max_word(knp_ctx* c, int* dev_word);                 // max of a float-bits status word over the ranks, on the solver's stream
+int allreduce_sum_host(knp_ctx* c, double* host_values, int n);    // sum of n <= 56 host values over the ranks (synchronous)
 // v [ncol / nil][n][nil] holds per-rank partial sums at the shared conforming dofs: afterwards every owner holds the full sum
 // (same bits on every owner: added in rank order).  On the context's stream; 2 messages per peer (comm.hip)
 int interface_accumulate(knp_ctx* c, double* v, int64_t n, int ncol);

@@ -78,6 +78,7 @@ SIGNATURES = {
     "knp_set_interior": (C.c_int, [_ctxp, C.c_int64]),
     "knp_halo_tables": (C.c_int, [_ctxp, C.c_int, _i32p, _i64p, _i32p, _i64p, _i64p]),
     "knp_halo_exchange": (C.c_int, [_ctxp, C.c_int]),
+    "knp_allreduce_sum": (C.c_int, [_ctxp, _f64p, C.c_int]),
     "knp_ode_create": (C.c_int, [_ctxp, C.c_int, C.c_int64, _i32p, C.c_int, C.c_int, _f64p, _f64p]),
     "knp_ode_table": (C.c_int, [_ctxp, C.c_int, C.c_int, C.c_int, _f64p]),
     "knp_ode_exchange": (C.c_int, [_ctxp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int]),
@@ -652,6 +653,13 @@ class Device:
 
     def amg_clear(self, which):
         self._chk(self.lib.knp_amg_clear(self.ctx, which), "knp_amg_clear")
+
+    def allreduce_sum(self, values):
+        """Sum of a few host scalars over the ranks of a partitioned run (identical bits on every rank); the values themselves
+        without a communicator."""
+        v = np.ascontiguousarray(np.asarray(values, dtype=np.float64).ravel())
+        self._chk(self.lib.knp_allreduce_sum(self.ctx, _p(v, _f64p), len(v)), "knp_allreduce_sum")
+        return v
 
     def halo_exchange(self, field):
         self._chk(self.lib.knp_halo_exchange(self.ctx, field), "knp_halo_exchange")

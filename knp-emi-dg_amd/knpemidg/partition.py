@@ -182,7 +182,9 @@ def distribute_solver(solver_factory, mesh_tuple, ode_models, stim_params, rank,
         # (every rank must ask for the same segment layout: capacities from global quantities only)
         ncg_bound = 4 * (mesh.coords.shape[0] + 8 * mesh.num_cells() // 4)            # conforming P1 / P2 dofs, two columns
         most_sent = max(sum(len(sl) for sl in part.local(r).send_lists) for r in range(world))
-        S.dev.comm_init_shm(rank, world, shm, max(ncg_bound, 1 << 16), max(most_sent, 1) * 7 * S.nd)
+        # outbox: the cell halo ([field <= 7][cell][nd]) or the interface exchange of the row-distributed conforming level
+        # ([shared dof, peer][column <= 7]; a cut cell touches nd conforming dofs, each shared with at most a handful of peers)
+        S.dev.comm_init_shm(rank, world, shm, max(ncg_bound, 1 << 16), max(most_sent, 1) * 7 * S.nd * 4)
     else:
         # RCCL communicators: rank 0 creates the ids, torch.distributed carries them to the others
         uid = [(_abi.comm_unique_id(), _abi.comm_unique_id()) if rank == 0 else None]

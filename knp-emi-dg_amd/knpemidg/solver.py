@@ -71,6 +71,7 @@ class Solver:
         self.stimulus = None
         self.stimulus_locator = None
         self.emi_niter = []
+        self.emi_targets = []            # absolute residual targets handed to the EMI solves (error-controlled stop)
         self.knp_niter = []
         # Krylov caps: the reference sets ksp_max_it 1000 behind BoomerAMG (solver.py:429,687);
         # the block-Jacobi preconditioner here needs more, so the cap is a solver_params option.
@@ -668,7 +669,9 @@ class Solver:
             self.file_emi_assem.write("ass_time: %.4f \n" % (res))
         ts = time.perf_counter()
         if self._emi_target:
-            dev.emi_residual_target(self._emi_target * _f(self.F) * self._knp_load_norm())
+            r_abs = self._emi_target * _f(self.F) * self._knp_load_norm()
+            self.emi_targets.append(r_abs)            # identical on every rank of a partitioned run (tests/test_gpu_multirank.py)
+            dev.emi_residual_target(r_abs)
         niter, r = dev.emi_solve(self._rtol_emi, self._atol_emi, maxit=self.max_it_emi)
         te = time.perf_counter()
         res = te - ts
@@ -696,11 +699,12 @@ class Solver:
             x = self.mesh.coords[self.mesh.cells[:n_own]]
             vol = np.abs(np.linalg.det(x[:, 1:] - x[:, :1])) / (2.0 if self.mesh.gdim == 2 else 6.0)
             bK2 = (b[:, :n_own] ** 2).sum(axis=2)
-            world = getattr(self.dev, "nranks", 1)                     # a partition sees its own cells only: balanced parts assumed for step 0
+            # a partition sums over its owned cells and all-reduces the sums: every rank must hand the SAME target to the PCG
+            # stopping test (ranks that disagree about convergence leave the loop of collectives at different iterations)
             if os.environ.get("KNP_KNP_NORM2", "0") == "1":
-                bn = np.sqrt((bK2 / vol[None, :]).sum(axis=1) * world)
+                bn = np.sqrt(dev.allreduce_sum((bK2 / vol[None, :]).sum(axis=1)))
             else:                                                      # order-8 norm of the load density (csrc/krylov.hip)
-                bn = ((bK2 / vol[None, :] ** 2) ** 4).sum(axis=1) ** 0.125 * world ** 0.125
+                bn = dev.allreduce_sum(((bK2 / vol[None, :] ** 2) ** 4).sum(axis=1)) ** 0.125
             self._knp_bnorm = bn
         return float(np.min(z * np.asarray(bn)))
 

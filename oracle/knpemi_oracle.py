@@ -751,6 +751,45 @@ def build_idealized(mesh, subdomains, surfaces, p=1, membrane_tags=(1, 2)):
     return pb
 
 
+def tortuosity_params():
+    """Physical parameters and initial values of examples/local-astrocyte-depolarization/run_tortuosity.py:78-165 (cm / ms / mV /
+    mM), variant M2 (lambda_i = 12.8, lambda_e = 6.4): the one shipped configuration with a NON-ZERO background charge rho_sub
+    (:116-121) and diffusion coefficients that differ per subdomain (D / lambda^2, :154-156).  Tuples by subdomain
+    0 ECS / 1 neuronal / 2 glial."""
+    dt = 0.1
+    C_M = 1.0
+    init = dict(K=(3.092970607490389, 124.13988964240784, 99.3100014897692),
+                Na=(144.60625137617149, 12.850454639128186, 15.775818906083778),
+                Cl=(133.62525154406637, 5.0, 5.203660274163705))
+    lam = (1.6 * 4, 3.2 * 4, 3.2 * 4)
+    return dict(dt=dt, C_M=C_M, temperature=307e3, F=96500e3, R=8.315e3, C_phi=C_M / dt,
+                D=dict(Na=1.33e-8, K=1.96e-8, Cl=2.03e-8), lam=lam,
+                z=dict(Na=1.0, K=1.0, Cl=-1.0), init=init,
+                rho=tuple(-(init["Na"][s] + init["K"][s] - init["Cl"][s]) for s in range(3)),
+                phi_M_init={1: -83.08511451850003, 2: -74.3848784437955})
+
+
+def build_tortuosity(mesh, subdomains, surfaces, p=1, membrane_tags=(1, 2)):
+    """Problem of run_tortuosity.py:78-230 on any mesh with subdomain tags 0 / 1 / 2 (coordinates in cm): ion_list = [K, Na, Cl]
+    with Cl (z = -1) ELIMINATED (:229), D_k / lambda_sub^2 per subdomain, rho_sub != 0 entering the eliminated concentration
+    (solver.py:831-838)."""
+    P = tortuosity_params()
+    tags = np.asarray(subdomains).astype(np.int64)
+    nc = mesh.num_cells()
+    lam2 = np.asarray(P["lam"])[tags] ** 2
+    ions = [dict(name=n, z=P["z"][n], D=P["D"][n] / lam2) for n in ("K", "Na", "Cl")]
+    pb = Problem(mesh, tags, np.asarray(surfaces), p, ions, P, membrane_tags=membrane_tags, rho=np.asarray(P["rho"])[tags])
+    ones = np.ones((nc, pb.nd))
+    for i, n in enumerate(("K", "Na")):
+        pb.c[i] = np.asarray(P["init"][n])[tags][:, None] * ones
+    pb.c_prev_n = pb.c.copy()
+    pb.c_elim = np.asarray(P["init"]["Cl"])[tags][:, None] * ones
+    for tag, v in P["phi_M_init"].items():
+        if tag in membrane_tags:
+            pb.phi_M[pb.mem[pb.facet_tags[pb.mem] == tag]] = v
+    return pb
+
+
 def emix_params():
     """Physical parameters and initial values of examples/emix-simulations/run_EMIx_simulation.py:56-91 (cm / ms / mV / mM:
     temperature in mK, F in mC/mol, R in mJ/(K mol), D in cm^2/ms).  init = (ECS, glial, neuronal) by subdomain 0 / 1 / 2."""

@@ -69,3 +69,16 @@ def mean_free(phi, vol):
     phi = np.asarray(phi).reshape(len(vol), -1)
     mean = (phi.mean(axis=1) * vol).sum() / vol.sum()
     return phi - mean
+
+
+def tortuosity_3d(resolution=0, p=1):
+    """The 4-axon idealized mesh with the coefficients of run_tortuosity.py (oracle.build_tortuosity): coordinates in cm, the cells
+    of the three tag-2 axons relabelled as subdomain 2 (glial), so that the structured kernels see three materials, a non-zero
+    background charge rho_sub and an eliminated ion with z = -1."""
+    from knpemidg.mesh import make_mesh_3D, Mesh
+    m, s, f = make_mesh_3D(resolution)
+    sub = s.array().astype(np.int64).copy()
+    mid = m.coords[m.cells].mean(axis=1)
+    sub[(sub == 1) & ((mid[:, 1] > 0.45e-6) | (mid[:, 2] > 0.45e-6))] = 2
+    mesh = Mesh(m.coords * 100.0, m.cells)
+    return ko.build_tortuosity(mesh, sub, f.array(), p=p)

@@ -48,5 +48,5 @@ nc = loc.mesh.num_cells()
 c = S.c.array().reshape(S.N_ions, nc, S.nd)[:, :n_own]
 phi = S.phi.array().reshape(nc, S.nd)[:n_own]
 np.savez(os.path.join(outdir, "rank%d.npz" % rank), cells=loc.cells_global[:n_own], c=c, phi=phi, emi_its=np.asarray(S.emi_niter),
-         knp_its=np.asarray([max(n) for n in S.knp_niter]), dist0=int(getattr(S, "amg_dist0", 0)))
+         knp_its=np.asarray([max(n) for n in S.knp_niter]), dist0=int(getattr(S, "amg_dist0", 0)), emi_targets=np.asarray(S.emi_targets))
 S.dev.close()

@@ -40,7 +40,7 @@ def _single_rank(n_axons, steps, method, degree=1):
     x = S.mesh.coords[S.mesh.cells]
     vol = np.abs(np.linalg.det(x[:, 1:] - x[:, :1])) / 6.0
     out = (S.c.array().reshape(S.N_ions, nc, S.nd).copy(), S.phi.array().reshape(nc, S.nd).copy(), vol, list(S.emi_niter),
-           [max(n) for n in S.knp_niter])
+           [max(n) for n in S.knp_niter], np.asarray(S.emi_targets))
     S.dev.close()
     return out
 
@@ -68,11 +68,17 @@ def test_partitioned_solver_with_several_ranks_on_one_gpu(hip_lib, tmp_path, mon
             if p.poll() is None:
                 p.kill()
     assert all(p.returncode == 0 for p in procs), "\n".join(l[-2000:] for l in logs)
-    c_ref, phi_ref, vol, emi_ref, knp_ref = _single_rank(n_axons, steps, method, degree=2 if method == "p2" else 1)
+    c_ref, phi_ref, vol, emi_ref, knp_ref, targets_ref = _single_rank(n_axons, steps, method, degree=2 if method == "p2" else 1)
     nc = c_ref.shape[1]
     c = np.full_like(c_ref, np.nan)
     phi = np.full_like(phi_ref, np.nan)
     seen = np.zeros(nc, dtype=int)
+    targets = [np.load(os.path.join(str(tmp_path), "rank%d.npz" % r))["emi_targets"] for r in range(world)]
+    # the residual target of the EMI stopping test must be the SAME number on every rank (ranks that disagree about
+    # convergence leave the loop of collectives at different iterations) -- bit for bit, step 0 (all-reduced load norm of the initial
+    # state) included -- and the single-rank one up to the summation order
+    assert len(targets[0]) == steps and all(np.array_equal(t, targets[0]) for t in targets[1:]), targets
+    assert np.abs(targets[0] / targets_ref - 1.0).max() < 1e-6, (targets[0], targets_ref)
     for r in range(world):
         d = np.load(os.path.join(str(tmp_path), "rank%d.npz" % r))
         c[:, d["cells"]] = d["c"]

@@ -11,29 +11,45 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-11
 
 
-def _problems():
-    from knpemidg.mesh import make_mesh_2D, make_mesh_3D, make_mesh_MMS, BoxMesh, MeshFunction
-    out = {}
-    m, s, f = make_mesh_2D(0)
-    out["2D_neuron_r0"] = ko.build_idealized(m, s.array(), f.array(), membrane_tags=(1,))
-    m, s, f = make_mesh_3D(0)
-    out["3D_4axon_r0"] = ko.build_idealized(m, s.array(), f.array())
-    m, s, f = make_mesh_3D(0, n_axons=1)
-    out["3D_1axon_r0"] = ko.build_idealized(m, s.array(), f.array())
-    # DG-P2 (BASELINE configs[2] degree): assembled cell-block path (csrc/tab_dg.hip)
-    m, s, f = make_mesh_2D(1)
-    out["2D_neuron_r1_P2"] = ko.build_idealized(m, s.array(), f.array(), p=2, membrane_tags=(1,))
+def _problem(name):
+    """One seeded-input problem by name (built on demand: each one costs the oracle's geometry and space tables)."""
+    from knpemidg.mesh import make_mesh_2D, make_mesh_3D
     from common import small_3d
-    m, s, f = small_3d((8, 4, 4))
-    out["3D_box_P2"] = ko.build_idealized(m, s.array(), f.array(), p=2, membrane_tags=(1,))
-    return out
+    if name == "2D_neuron_r0":
+        m, s, f = make_mesh_2D(0)
+        return ko.build_idealized(m, s.array(), f.array(), membrane_tags=(1,))
+    if name == "3D_4axon_r0":
+        m, s, f = make_mesh_3D(0)
+        return ko.build_idealized(m, s.array(), f.array())
+    if name == "3D_1axon_r0":
+        m, s, f = make_mesh_3D(0, n_axons=1)
+        return ko.build_idealized(m, s.array(), f.array())
+    if name == "3D_1axon_r1":
+        m, s, f = make_mesh_3D(1, n_axons=1)
+        return ko.build_idealized(m, s.array(), f.array(), membrane_tags=(1,))
+    if name == "2D_neuron_r1_P2":       # DG-P2 (BASELINE configs[2] degree)
+        m, s, f = make_mesh_2D(1)
+        return ko.build_idealized(m, s.array(), f.array(), p=2, membrane_tags=(1,))
+    if name == "3D_box_P2":
+        m, s, f = small_3d((8, 4, 4))
+        return ko.build_idealized(m, s.array(), f.array(), p=2, membrane_tags=(1,))
+    # rho_sub != 0, D per subdomain, eliminated ion with z = -1 (run_tortuosity.py:116-121, 154-156, 229; solver.py:831-838)
+    if name == "3D_4axon_r0_rho":
+        from common import tortuosity_3d
+        return tortuosity_3d(0)
+    if name == "emix_sub_rho":
+        import emix_sub
+        m, s, f = emix_sub.emix_submesh()
+        return ko.build_tortuosity(m, s.array(), f.array())
+    raise KeyError(name)
 
 
-@pytest.fixture(scope="module", params=["2D_neuron_r0", "3D_1axon_r0", "3D_4axon_r0", "2D_neuron_r1_P2", "3D_box_P2"])
+@pytest.fixture(scope="module", params=["2D_neuron_r0", "3D_1axon_r0", "3D_4axon_r0", "2D_neuron_r1_P2", "3D_box_P2", "3D_4axon_r0_rho",
+                                        "emix_sub_rho"])
 def case(request, hip_lib):
     from knpemidg import _abi as A
-    pb = _problems()[request.param]
-    x = synthetic_state(pb)
+    pb = _problem(request.param)
+    x = synthetic_state(pb, volt=1.0e3 if request.param.endswith("_rho") else 1.0)      # the run_tortuosity.py units are cm / ms / mV
     dev = device_for(pb)
     push_state(dev, pb)
     yield pb, dev, x, A
@@ -96,7 +112,7 @@ def test_knp_apply_kernel_variants(hip_lib, monkeypatch, env, variant):
     LDS-DMA ring, default), the halo-staged persistent kernel with the material table, with per-cell D, with strided instead of drawn
     blocks, other queue counts / one workgroup per CU (many blocks per workgroup), and the LDS-staged kernel of round 1."""
     from knpemidg import _abi as A
-    pb = _problems()["3D_4axon_r0"]
+    pb = _problem("3D_4axon_r0")
     x = synthetic_state(pb)
     for k, v in env.items():
         monkeypatch.setenv(k, v)
@@ -120,7 +136,7 @@ def test_emi_apply_kernel_variants(hip_lib, monkeypatch, env, evariant, which):
     """Both EMI apply kernels of the structured 3D P1 path (ring-staged: default; LDS-staged thread-per-cell kernel) against the
     oracle matrix, on meshes with membrane facets of one and of four cells."""
     from knpemidg import _abi as A
-    pb = _problems()[which]
+    pb = _problem(which)
     x = synthetic_state(pb)
     for k, v in env.items():
         monkeypatch.setenv(k, v)
@@ -133,6 +149,78 @@ def test_emi_apply_kernel_variants(hip_lib, monkeypatch, env, evariant, which):
         dev.emi_apply(A.F_X, A.F_Y)
         Aemi, _, _ = ko.assemble_emi(pb, want_B=False)
         assert relerr(dev.download(A.F_Y, 0, pb.ndof), Aemi @ x[0].ravel()) < TOL
+    finally:
+        dev.close()
+
+
+_STEADY = {}
+
+
+def _steady_case(which):
+    """Problem, seeded inputs and the oracle products A x (assembled once per mesh: the r=1 matrices take the longest)."""
+    if which not in _STEADY:
+        pb = _problem(which)
+        x = synthetic_state(pb)
+        Aemi, _, _ = ko.assemble_emi(pb, want_B=False)
+        ye = Aemi @ x[0].ravel()
+        del Aemi
+        yk = [ko.assemble_knp(pb, k) @ x[k].ravel() for k in range(pb.N_ions)]
+        _STEADY[which] = (pb, x, ye, yk)
+    return _STEADY[which]
+
+
+@pytest.mark.parametrize("split", ["0", "1"])
+@pytest.mark.parametrize("which,wg", [("3D_4axon_r0", 8), ("3D_4axon_r0", 16), ("3D_1axon_r1", 8), ("3D_1axon_r1", 24)])
+def test_ring_kernels_steady_state_vs_oracle(hip_lib, monkeypatch, which, wg, split):
+    """The ring-staged applies in the regime the benchmarked r=2 run spends its time in: KNP_RING_WG shrinks the launch so that one
+    workgroup walks MANY blocks (r=0 4-axon mesh: 61 blocks on 8 / 16 workgroups = 7-8 / 3-4 each; single-axon r=1 mesh: 486 blocks on
+    8 / 24 workgroups = 61 / 20-21 each) -- slot reuse in the three- / four-slot rings, the wrap of the four list buffers, the counted
+    s_waitcnt vmcnt(N) that leaves block n + 2 in flight across the barrier, and the short last block -- against the oracle's assembled
+    CSR operators (src/knpemidg/solver.py:325-328, 586-594) at 1e-11; KNP with one consumer group and species-split groups."""
+    from knpemidg import _abi as A
+    pb, x, ye, yk = _steady_case(which)
+    monkeypatch.setenv("KNP_RING_WG", str(wg))
+    monkeypatch.setenv("KNP_RING_SPLIT", split)
+    dev = device_for(pb)
+    try:
+        push_state(dev, pb)
+        assert dev.apply_variant(0) == 3 and dev.apply_variant(1) == 7
+        dev.update_kappa(); dev.update_dnphi()
+        if split == "0":
+            dev.upload(A.F_X, x[0]); dev.emi_apply(A.F_X, A.F_Y)
+            assert relerr(dev.download(A.F_Y, 0, pb.ndof), ye) < TOL
+        dev.upload(A.F_X, x); dev.knp_apply(A.F_X, A.F_Y)
+        y = dev.download(A.F_Y).reshape(pb.N_ions, -1)
+        for k in range(pb.N_ions):
+            assert relerr(y[k], yk[k]) < TOL
+    finally:
+        dev.close()
+
+
+def test_ring_kernel_one_species_steady_state_vs_oracle(hip_lib, monkeypatch):
+    """NS = 1 instance of the ring-staged KNP apply with 7-8 blocks per workgroup against the oracle."""
+    from knpemidg import _abi as A
+    from knpemidg.mesh import make_mesh_3D
+    m, s, f = make_mesh_3D(0)
+    P = ko.idealized_params()
+    nc = m.num_cells()
+    ions = [dict(name=n, z=P["z"][n], D=np.full(nc, P["D"][n])) for n in ("K", "Cl")]
+    pb = ko.Problem(m, s.array().astype(np.int64), f.array(), 1, ions, P, membrane_tags=(1, 2))
+    rng = np.random.default_rng(11)
+    pb.c = rng.uniform(50.0, 150.0, size=pb.c.shape)
+    pb.c_prev_n = pb.c.copy()
+    pb.c_elim = rng.uniform(50.0, 150.0, size=pb.c_elim.shape)
+    x = synthetic_state(pb)
+    monkeypatch.setenv("KNP_RING_WG", "8")
+    dev = device_for(pb)
+    try:
+        push_state(dev, pb)
+        assert dev.apply_variant(1) == 7
+        dev.update_dnphi()
+        dev.upload(A.F_X, x); dev.knp_apply(A.F_X, A.F_Y)
+        y = dev.download(A.F_Y).reshape(pb.N_ions, -1)
+        for k in range(pb.N_ions):
+            assert relerr(y[k], ko.assemble_knp(pb, k) @ x[k].ravel()) < TOL
     finally:
         dev.close()
 
@@ -173,7 +261,7 @@ def test_knp_apply_with_cellwise_diffusion(hip_lib):
     """D that differs from cell to cell (more distinct coefficient tuples than the material table holds): the halo-staged kernel
     stages D itself; same operator as the oracle's."""
     from knpemidg import _abi as A
-    pb = _problems()["3D_4axon_r0"]
+    pb = _problem("3D_4axon_r0")
     rng = np.random.default_rng(5)
     for ion in pb.ions:
         ion["D"] = np.asarray(ion["D"], dtype=float) * rng.uniform(0.5, 1.5, size=len(pb.cell_tags))
@@ -493,6 +581,9 @@ def test_full_size_properties_r2(hip_lib):
     assert dev.nc == 995328 and dev.n_geometry_classes > 0
     ndof = dev.nc * 4
     rng = np.random.default_rng(3)
+    c_rest, ce_rest = dev.download(A.F_C), dev.download(A.F_C_ELIM)                        # restored before the rest-state step below
+    dev.upload(A.F_C, c_rest * (1 + 0.01 * rng.uniform(-1, 1, size=c_rest.shape)))         # kappa varies inside every cell
+    dev.upload(A.F_C_ELIM, ce_rest * (1 + 0.01 * rng.uniform(-1, 1, size=ce_rest.shape)))
     dev.update_kappa()
     x = rng.uniform(-1, 1, size=(2, ndof))
     pad = np.zeros(ndof)
@@ -504,6 +595,35 @@ def test_full_size_properties_r2(hip_lib):
     assert np.abs(emi(np.ones(ndof))).max() < 1e-9 * np.abs(y0).max()                     # constants in the null space
     assert abs(x[1] @ y0 - x[0] @ y1) < 1e-10 * abs(x[1] @ y0)                             # symmetry
     assert relerr(emi(2.0 * x[0] - 0.5 * x[1]), 2.0 * y0 - 0.5 * y1) < 1e-12              # linearity
+    # the ring-staged kernels in their steady state (15 of 15.2 rounds at this size: every slot and list buffer reused many times)
+    # against the thread-per-cell LDS-staged kernels (oracle-verified, no persistence, no ring) on RANDOM vectors, a rough potential
+    # (drift and upwinding active on every facet) and the perturbed kappa: the same floating-point sums up to their order
+    import os
+    phi_r = 0.07 * rng.uniform(-1, 1, size=ndof)
+    dev.upload(A.F_PHI, phi_r); dev.update_dnphi()
+    xk = rng.uniform(-1, 1, size=2 * ndof)
+
+    def knp(v):
+        dev.upload(A.F_X, v); dev.knp_apply(A.F_X, A.F_Y)
+        return dev.download(A.F_Y)
+    assert dev.apply_variant(0) == 3 and dev.apply_variant(1) == 7
+    yk_ring = knp(xk)
+    os.environ["KNP_RING_SPLIT"] = "1"
+    try:
+        yk_split = knp(xk)
+    finally:
+        del os.environ["KNP_RING_SPLIT"]
+    os.environ["KNP_APPLY_HALO"] = "0"; os.environ["KNP_EMI_RING"] = "0"
+    try:
+        assert dev.apply_variant(0) == 1 and dev.apply_variant(1) == 1
+        yk_staged = knp(xk)
+        y0_staged = emi(x[0])
+    finally:
+        del os.environ["KNP_APPLY_HALO"], os.environ["KNP_EMI_RING"]
+    assert np.abs(yk_staged).max() > 0
+    assert relerr(yk_ring, yk_staged) < 1e-12 and relerr(yk_split, yk_staged) < 1e-12
+    assert relerr(y0, y0_staged) < 1e-12
+    del yk_ring, yk_split, yk_staged, y0_staged
     dev.upload(A.F_PHI, np.zeros(ndof)); dev.update_dnphi()                                # no drift
     dev.upload(A.F_X, np.ones(2 * ndof)); dev.knp_apply(A.F_X, A.F_Y)
     yk = dev.download(A.F_Y).reshape(2, -1)
@@ -511,6 +631,7 @@ def test_full_size_properties_r2(hip_lib):
     for k in range(2):
         assert abs(yk[k].sum() - vol_total / 1e-4) < 1e-9 * vol_total / 1e-4                # 1^T (M/dt + K_sipg) 1
     # one unstimulated splitting step from the calibrated rest state (run_3D.py:80-86)
+    dev.upload(A.F_C, c_rest); dev.upload(A.F_C_ELIM, ce_rest); dev.update_kappa()
     S.stimulus = {}
     S._unpack_solver_params(solver_parameters(3, 2))
     S.save_fields = S.save_solver_stats = False

@@ -526,6 +526,69 @@ def test_baseline_config5_emix_mesh(hip_lib):
     assert np.isfinite(S.phi.array()).all()
 
 
+def test_rho_sub_and_subdomain_diffusion_two_steps_vs_oracle(hip_lib):
+    """The one shipped configuration with a non-zero background charge: run_tortuosity.py (rho_sub = -(Na + K - Cl) per subdomain
+    :116-121, D_k / lambda_sub^2 :154-156, ion_list = [K, Na, Cl] with Cl, z = -1, eliminated :229) through the `Solver` API on a
+    17 920-tet piece of the tissue mesh (glial + neuronal membranes): two full splitting steps against the oracle's assembled forms
+    and direct solves fed with the same membrane outputs; rho enters the eliminated concentration (solver.py:831-838) and through
+    it kappa and the KNP right-hand side of the second step."""
+    from collections import namedtuple
+    ex = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "emix_simulations")
+    if ex not in sys.path:
+        sys.path.insert(0, ex)
+    import emix_common as E
+    from emix_sub import emix_submesh
+    from knpemidg.models import mm_glial, mm_hh_emix
+    P = ko.tortuosity_params()
+    C = E.Constant
+    params = namedtuple('params', ('dt', 'n_steps_ODE', 'F', 'psi', 'C_phi', 'C_M', 'R', 'temperature', 'phi_M_init_type', 'rho_sub'))(
+        P["dt"], 25, P["F"], P["F"] / (P["R"] * P["temperature"]), P["C_phi"], P["C_M"], P["R"], P["temperature"], 'constant',
+        {s: C(P["rho"][s]) for s in range(3)})
+
+    def ion(name):
+        return {'c_init_sub': {s: C(P["init"][name][s]) for s in range(3)}, 'c_init_sub_type': 'constant', 'bdry': C(0),
+                'z': P["z"][name], 'name': name, 'D_sub': {s: C(P["D"][name] / P["lam"][s] ** 2) for s in range(3)}, 'f_source': C(0)}
+    ion_list = [ion('K'), ion('Na'), ion('Cl')]
+    stim = namedtuple('membrane_params', ('g_syn_bar', 'stimulus', 'stimulus_locator'))(5, {'stim_amplitude': 5}, lambda x: (x[0] < 3.0e-4))
+    mt = emix_submesh()
+    S = E.SolverEMIx(params, ion_list)
+    S.verbose = False
+    S.setup_domain(*mt)
+    S.setup_parameters()
+    S.setup_FEM_spaces()
+    S.setup_membrane_model(stim, {1: mm_glial, 2: mm_hh_emix})
+    S._unpack_solver_params(E.solver_parameters()._replace(rtol_emi=1e-11, rtol_knp=1e-13))
+    S.save_fields = S.save_solver_stats = False
+    S.splitting_scheme = True
+    S.setup_varform_emi(); S.setup_varform_knp(); S.setup_solver_emi(); S.setup_solver_knp()
+    pb = ko.build_tortuosity(mt[0], mt[1].array(), mt[2].array())
+    assert np.abs(pb.rho).min() > 10.0 and len(np.unique(pb.ions[0]["D"])) == 2
+    assert relerr(S.c.array(), pb.c) < 1e-15 and relerr(S.ion_list[-1]['c'].array(), pb.c_elim) < 1e-15
+    vol = pb.geom.vol
+    t = E.Constant(0.0)
+    for k in range(2):
+        S.step_membrane_models(k)
+        pb.phi_M = S.phi_M_prev_PDE.array().copy()
+        for name in pb.I_ch:
+            pb.I_ch[name] = np.zeros(pb.mesh.num_facets())
+            for mm in S.mem_models:
+                a = mm['I_ch_k'][name].array()
+                pb.I_ch[name][mm['ode'].indices] = a[mm['ode'].indices]
+        S.solve_for_time_step(k, t)
+        Eo = ko.solve_for_time_step(pb, direct=True)
+        assert relerr(mean_free(S.phi.array(), vol), mean_free(pb.phi, vol)) < 1e-6
+        assert relerr(S.c.array(), pb.c) < 1e-8
+        assert relerr(S.ion_list[-1]['c'].array(), pb.c_elim) < 1e-8
+        assert relerr(S.phi_M_prev_PDE.array()[pb.mem], pb.phi_M[pb.mem]) < 1e-6
+        for ion_ in S.ion_list:
+            assert relerr(ion_['E'].array()[pb.mem], Eo[ion_['name']]) < 1e-7
+    # the background charge is what keeps the bulk electroneutral: z = (+1, +1, -1), rho != 0
+    c = S.c.array().reshape(2, -1, 4)
+    cl = S.ion_list[-1]['c'].array().reshape(-1, 4)
+    assert np.abs(c[0] + c[1] - cl + pb.rho[:, None]).max() < 1e-9 * np.abs(cl).max()
+    S.dev.close()
+
+
 def test_solver_emi_variant(hip_lib):
     """`SolverEMI` (reference: src/knpemidg/solver_emi.py): potential-only stepping with frozen concentrations, HH membrane
     ODEs in the loop; every step's phi and phi_M against the oracle's EMI solve fed with the same ODE outputs."""
