@@ -125,6 +125,7 @@ def main():
     ap.add_argument("--workload", choices=["idealized", "emix"], default="idealized",
                     help="idealized = the headline 4-axon BoxMesh (default); emix = BASELINE configs[4], the reference's bundled tissue "
                          "reconstruction (121 617 unstructured tets, coordinate-path kernels, cm / ms / mV)")
+    ap.add_argument("--refine", type=int, default=0, help="--workload emix: regular refinements of the tissue mesh (1: 972 936 tets)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -180,9 +181,10 @@ def main():
         sys.path.insert(0, os.path.join(ROOT, "examples", "emix_simulations"))
         import emix_common
         if world > 1 or force_dist:
-            S = emix_common.make_distributed_solver(rank, world, local_rank, dist, degree=args.degree)
+            S = emix_common.make_distributed_solver(rank, world, local_rank, dist, degree=args.degree,
+                                                    mesh_tuple=emix_common.load_mesh(refine=args.refine) if args.refine else None)
         else:
-            S = emix_common.make_solver(degree=args.degree)
+            S = emix_common.make_solver(degree=args.degree, refine=args.refine)
         sp = emix_common.solver_parameters()
     elif world > 1 or force_dist:
         from knpemidg.partition import make_distributed_solver
@@ -211,11 +213,13 @@ def main():
         S.dev.sync()
 
     k = 0
+    t_first_step = time.perf_counter() - t_setup
     for _ in range(args.warmup):
         S.step_membrane_models(k); S.solve_for_time_step(k, t); k += 1
     barrier()
     progress("warm-up done")
     t_ready = time.perf_counter() - t_setup
+    timers0 = (S.emi_solve_timer, S.knp_solve_timer, S.emi_ass_timer + S.knp_ass_timer, S.ode_solve_timer)   # config.*_s cover the timed steps only
     t0 = time.perf_counter()
     for _ in range(args.steps):
         ts = time.perf_counter()
@@ -224,6 +228,10 @@ def main():
             progress("step %d enqueued/solved in %.2f ms" % (k, 1e3 * (time.perf_counter() - ts)))
     barrier()
     elapsed = time.perf_counter() - t0
+    timers1 = (S.emi_solve_timer, S.knp_solve_timer, S.emi_ass_timer + S.knp_ass_timer, S.ode_solve_timer)
+    emi_s, knp_s, ass_s, ode_s = (b - a for a, b in zip(timers0, timers1))
+    its_emi = list(S.emi_niter[-args.steps:])
+    its_knp = [max(n) for n in S.knp_niter[-args.steps:]]
     if dist is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if shm_ranks else "cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -258,10 +266,10 @@ def main():
     # (counters cannot be read from inside this process); null when the workload differs
     cls = bool(S.dev.n_geometry_classes)
     if args.degree == 1:
-        emi_name = {3: "k_emi_apply_ring", 1: "k_emi_apply_cls_staged<3,256>"}.get(S.dev.apply_variant(0), "k_emi_apply<3,3>")
+        emi_name = {3: "k_emi_apply_ring", 1: "k_emi_apply_cls_staged<3,256>", 10: "k_emi_apply_ring_u"}.get(S.dev.apply_variant(0), "k_emi_apply<3,3>")
         kv = S.dev.apply_variant(1)
         knp_name = {7: "k_knp_apply_ring<2>", 2: "k_knp_apply_halo<2,false>", 6: "k_knp_apply_halo<2,true>",
-                    1: "k_knp_apply_cls_staged<3,2,256>"}.get(kv, "k_knp_apply<3,2>")
+                    1: "k_knp_apply_cls_staged<3,2,256>", 10: "k_knp_apply_ring_u<2>"}.get(kv, "k_knp_apply<3,2>")
     else:
         emi_name = "k_emi_apply_p2<3,256,%s>" % ("true" if cls else "false")
         knp_name = "k_knp_apply_p2<3,256,%s>" % ("true" if cls else "false")
@@ -279,16 +287,26 @@ def main():
         ach = n * nc_local / (ms * 1e-3) / 1e12
         return {"fp64_instructions_per_cell": n, "achieved": ach, "peak": FP64_PEAK_TINST, "unit": "T lane-instructions/s",
                 "frac": ach / FP64_PEAK_TINST}
+    # A record counts only for the code it was measured on: it carries the sha256 (first 16 hex digits) of the kernel's source file at the
+    # time of the counter pass (tools/pmc_traffic_update.py), and a kernel edited since then reports null until a new pass is committed.
     traffic = traffic_emi = None
     try:
+        import hashlib
         pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        sha = {}
+
+        def current(src):
+            if src not in sha:
+                with open(os.path.join(ROOT, "knp-emi-dg_amd", "csrc", src), "rb") as fh:
+                    sha[src] = hashlib.sha256(fh.read()).hexdigest()[:16]
+            return sha[src]
         for key, rec in pmc.items():
-            if isinstance(rec, dict) and rec.get("cells_per_launch") == nc_local:
+            if isinstance(rec, dict) and rec.get("cells_per_launch") == nc_local and rec.get("source") and rec.get("source_sha16") == current(rec["source"]):
                 if key.split(":")[0] == emi_name:
                     traffic_emi = rec["traffic_bytes"]
                 if key.split(":")[0] == knp_name:
                     traffic = rec["traffic_bytes"]
-    except (OSError, ValueError):
+    except (OSError, ValueError, KeyError):
         pass
 
     progress("timed region: %.2f ms/step; a %d-step run of examples/idealized-geometries/run_3D.py:60-62 at this rate + the %.1f s of setup "
@@ -298,8 +316,9 @@ def main():
             "metric": "DoF-updates/sec per PDE timestep", "value": dofs * args.steps / elapsed, "unit": "DoF/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": ("EMIx tissue reconstruction volume_ncells_5_size_5000 (%d unstructured tets, %d P%d-DG DoFs), glial + "
-                                    "neuronal membranes + stimulus, full splitting step" % (nc_global, dofs, args.degree)) if emix else
+            "config": {"workload": ("EMIx tissue reconstruction volume_ncells_5_size_5000%s (%d unstructured tets, %d P%d-DG DoFs), glial + "
+                                    "neuronal membranes + stimulus, full splitting step" % (
+                                        ", %d regular refinement(s)" % args.refine if args.refine else "", nc_global, dofs, args.degree)) if emix else
                                    ("3D idealized 4-axon mesh r=%d (%d tets, %d P%d-DG DoFs: phi + K,Cl solved, Na eliminated), "
                                     "HH membranes + stimulus, full splitting step" % (r, nc_global, dofs, args.degree)),
                        "parallelism": ("rcb%d" if emix else "slab%d") % world,
@@ -308,10 +327,12 @@ def main():
                                                 "sample the default run may spend" % r,
                        "preconditioner": ("cell-block-Jacobi + conforming-P%d auxiliary space, smoothed-aggregation AMG V-cycle" % args.degree) if S.use_amg
                        else "cell-block-Jacobi",
-                       "emi_iters_per_step": float(np.mean(S.emi_niter[-args.steps:])),
-                       "knp_iters_per_step": float(np.mean([max(n) for n in S.knp_niter[-args.steps:]])),
-                       "emi_solve_s": S.emi_solve_timer, "knp_solve_s": S.knp_solve_timer,
-                       "assemble_s": S.emi_ass_timer + S.knp_ass_timer, "ode_s": S.ode_solve_timer},
+                       "emi_iters_per_step": float(np.mean(its_emi)), "knp_iters_per_step": float(np.mean(its_knp)),
+                       # host wall time of the phases over the TIMED steps only (each phase ends in a device sync)
+                       "emi_solve_s": emi_s, "knp_solve_s": knp_s, "assemble_s": ass_s, "ode_s": ode_s,
+                       "setup_s_before_first_step": t_first_step,
+                       # DG-level smoother of the EMI preconditioner as measured by the run itself on its solves 1-4 (knpemidg/solver.py)
+                       "emi_dg_smoother": getattr(S, "emi_dg_chebyshev_measured", None)},
             # dominant kernel of a step = the KNP operator apply (all solved species in one launch; ~30 % of the kernel time
             # of the profiled run, profiles/): the EMI apply, same design, is reported next to it
             "roofline": {"bound": "hbm", "kernel": knp_name, "achieved": knp_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -38,11 +38,17 @@ class SolverEMIx(Solver):
         ode_model.set_parameter('Na_i', pcws_constant_project(Na_i, self.Q))
 
 
-def load_mesh(path=MESH_XDMF):
-    """(mesh [cm], subdomains, surfaces): membrane facet tag 1 = glial, 2 = neuronal, 10 = exterior boundary."""
+def load_mesh(path=MESH_XDMF, refine=0):
+    """(mesh [cm], subdomains, surfaces): membrane facet tag 1 = glial, 2 = neuronal, 10 = exterior boundary.
+    refine = n: n regular refinements (every tet -> 8, labels inherited) -- the same tissue at 8^n times the cells, for measurements
+    of the unstructured kernels at a roofline-relevant size (bench.py --workload emix --refine 1)."""
     coords, cells, attrs = read_xdmf_mesh(path)
     label = np.asarray(attrs["label"]).astype(np.int64)
     mesh = Mesh(coords, cells)
+    for _ in range(int(refine)):
+        from knpemidg.mesh import refine_uniform
+        mesh, parent = refine_uniform(mesh)
+        label = label[parent]
     sub = np.vectorize(LABEL_TO_SUBDOMAIN.get)(label).astype(np.uint32)
     fc = mesh.facet_cells
     interior = fc[:, 1] >= 0
@@ -96,9 +102,9 @@ def solver_parameters(**extra):
     return namedtuple('solver_params', names + tuple(extra))(*(vals + tuple(extra.values())))
 
 
-def make_solver(dt=0.1, degree=1, verbose=False, mesh_tuple=None):
+def make_solver(dt=0.1, degree=1, verbose=False, mesh_tuple=None, refine=0):
     params, ion_list, stim = physical_setup(dt)
-    mesh, subdomains, surfaces = mesh_tuple or load_mesh()
+    mesh, subdomains, surfaces = mesh_tuple or load_mesh(refine=refine)
     S = SolverEMIx(params, ion_list, degree_emi=degree, degree_knp=degree)
     S.verbose = verbose
     S.setup_domain(mesh, subdomains, surfaces)

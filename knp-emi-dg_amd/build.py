@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "knpemidg", "libknpemi_hip.so")
 HOST_SOURCES = ["host_sparse.cpp"]
-SOURCES = ["abi.hip", "apply_p1.hip", "rhs_p1.hip", "krylov.hip", "comm.hip", "amg.hip", "ode.hip", "tab_dg.hip", "apply_p2.hip", "apply_ring.hip"]
+SOURCES = ["abi.hip", "apply_p1.hip", "rhs_p1.hip", "krylov.hip", "comm.hip", "amg.hip", "ode.hip", "tab_dg.hip", "apply_p2.hip", "apply_ring.hip", "apply_ring_u.hip"]
 
 
 def _stale():

@@ -60,7 +60,13 @@ __global__ void k_extrapolate_guess(int64_t n, int nh, int order, double* __rest
 static int extrapolate_guess(knp_ctx* c, double* x, double** hist, int* nh, int64_t n, bool emi) {
     // KNP_EXTRAPOLATE = 1: both solves, 2: EMI only, 3: KNP only
     static const int mode = getenv("KNP_EXTRAPOLATE") ? atoi(getenv("KNP_EXTRAPOLATE")) : 1;
-    static const int order = getenv("KNP_EXTRAPOLATE_ORDER") ? atoi(getenv("KNP_EXTRAPOLATE_ORDER")) : 1;
+    // order 1: x0 = 2 x_{k-1} - x_{k-2}; order 2: x0 = 3 x_{k-1} - 3 x_{k-2} + x_{k-3}.  KNP_EXTRAPOLATE_ORDER sets both solves,
+    // KNP_EXTRAPOLATE_ORDER_KNP / _EMI one of them (r=2: order 2 costs the EMI solve 4.7 -> 7.0 iterations per step -- the potential
+    // jumps with the membrane currents -- and saves the KNP solve 0.45 of 5.05: profiles/r04_min_it.txt)
+    static const int order_all = getenv("KNP_EXTRAPOLATE_ORDER") ? atoi(getenv("KNP_EXTRAPOLATE_ORDER")) : 0;
+    static const int order_emi = getenv("KNP_EXTRAPOLATE_ORDER_EMI") ? atoi(getenv("KNP_EXTRAPOLATE_ORDER_EMI")) : (order_all ? order_all : 1);
+    static const int order_knp = getenv("KNP_EXTRAPOLATE_ORDER_KNP") ? atoi(getenv("KNP_EXTRAPOLATE_ORDER_KNP")) : (order_all ? order_all : 1);
+    const int order = emi ? order_emi : order_knp;
     const bool on = mode == 1 || (mode == 2 && emi) || (mode == 3 && !emi);
     if (!on || c->p.splitting == 2) return 0;
     if (!*hist) HIPCHK(c, hipMalloc((void**)hist, sizeof(double) * 2 * n));
@@ -327,6 +333,7 @@ void knp_ctx_destroy(knp_ctx* c) {
         delete fl;
         g_fields.erase(c);
     }
+    ring_u_free(c);
     hipFree(c->m.hb_src); hipFree(c->m.hb_loc);
     hipFree(c->m.cls); hipFree(c->m.cls_table); hipFree(c->m.cls_ext); hipFree(c->m.coords); hipFree(c->m.h); hipFree(c->m.cells); hipFree(c->m.nbr); hipFree(c->m.fflag); hipFree(c->m.cfacet); hipFree(c->m.mf);
     hipFree(c->mat); hipFree(c->nmat4); hipFree(c->dtab); hipFree(c->halo_ctr);
@@ -840,7 +847,10 @@ int knp_knp_solve(knp_ctx* c, double rtol, double atol, int maxit, int min_it, i
     static const int cheb_env = getenv("KNP_KNP_CHEB") ? atoi(getenv("KNP_KNP_CHEB")) : -1;
     // (round 3, matrix-free P2 applies: with the step DG-P2 takes 8.1 -> 6.1 KNP iterations and steps 5 % faster at r=2, but 40 steps of
     // the P2 configuration then end with 1.08e-6 in the concentrations against the 1e-6 bound: not enabled)
-    const int cheb = cheb_env >= 0 ? cheb_env : (c->degree == 1 ? 1 : 0);
+    // (round 4: the step is on for DG-P2 too.  Round 3 had to keep it off because the EMI stop let more error through with better
+    // preconditioners; with the stops of round 4 the P2 configuration stays within c <= 1e-6 with it -- 6.8e-7 over 25 steps,
+    // profiles/r04_stop_sweep.txt -- and steps 6 % faster, KNP 7.4 -> 5.2 iterations)
+    const int cheb = cheb_env >= 0 ? cheb_env : 1;
     if (cheb && c->p.n_sys <= 4) {
         if (!f->tmp_knp) HIPCHK(c, hipMalloc((void**)&f->tmp_knp, sizeof(double) * f->n[KNP_F_C]));
         kv.tmp = f->tmp_knp;

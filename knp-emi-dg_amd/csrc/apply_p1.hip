@@ -1075,6 +1075,12 @@ static int emi_apply_impl(knp_ctx* c, const double* x, const double* kappa, doub
         if (rc || m.c_end >= c->m.c_end) return rc;
         m.c_begin = m.c_end;                   // blocks with long neighbour lists (a partition's cut cells): LDS-staged kernel below
         m.c_end = c->m.c_end;
+    } else if (const int64_t ucells = ring_u_cells(c, 0); ucells > m.c_begin) {
+        m.c_end = std::min<int64_t>(c->m.c_end, ucells);          // meshes without geometry classes: ring-staged, geometry from staged coordinates
+        const int rc = ring_u_emi_apply(c, m, x, kappa, y, (c->dist && c->halo_stream) ? env_int("KNP_HALO_RESERVE_CU", 8) : 0);
+        if (rc || m.c_end >= c->m.c_end) return rc;
+        m.c_begin = m.c_end;                   // blocks beyond the staging limits: coordinate-path kernel below
+        m.c_end = c->m.c_end;
     }
     const int64_t n = m.c_end - m.c_begin;
     const dim3 g((unsigned)grid8(n)), b(KNP_BLOCK);
@@ -1103,11 +1109,12 @@ static bool knp_halo_usable(const knp_ctx* c, size_t* lds_bytes, bool* with_mate
 
 // which kernel an operator apply runs (bench.py / tests name the kernel they measured): 0 coordinate path, 1 geometry classes +
 // LDS staging, 2 halo-staged persistent (+ 4 when D comes from the material table), 3 ring-staged (EMI) / 7 ring-staged (KNP,
-// material table), 8 matrix-free P2, 9 assembled P2 blocks
+// material table), 8 matrix-free P2, 9 assembled P2 blocks, 10 ring-staged without geometry classes (apply_ring_u.hip)
 int apply_variant(knp_ctx* c, int which) {
     if (c->degree != 1) return p2_assembled() ? 9 : 8;
     bool matp = false;
     if ((which == 0 || which == 1) && ring_usable(c, which)) return which == 1 ? 7 : 3;
+    if ((which == 0 || which == 1) && ring_u_cells(c, which) > 0) return 10;
     if (which == 1 && knp_halo_usable(c, nullptr, &matp)) return matp ? 6 : 2;
     if (c->m.dim == 3 && c->m.cls && c->m.ncls <= CLS_MAX_LDS && (which == 0 || c->p.n_sys <= 3)) return 1;
     return 0;
@@ -1134,6 +1141,13 @@ template <int D> static int knp_apply_dispatch(knp_ctx* c, const double* x, cons
         m.c_end = std::min<int64_t>(c->m.c_end, c->m.hb_long0 * KNP_HALO_BLK);
         const int reserve = (c->dist && c->halo_stream) ? env_int("KNP_HALO_RESERVE_CU", 8) : 0;
         const int rc = ring_knp_apply(c, m, x, gphi, y, ka, reserve);
+        if (rc || m.c_end >= c->m.c_end) return rc;
+        m.c_begin = m.c_end;
+        m.c_end = c->m.c_end;
+    } else if (const int64_t ucells = (D == 3 ? ring_u_cells(c, 1) : 0); ucells > m.c_begin) {
+        m.c_end = std::min<int64_t>(c->m.c_end, ucells);
+        const int reserve = (c->dist && c->halo_stream) ? env_int("KNP_HALO_RESERVE_CU", 8) : 0;
+        const int rc = ring_u_knp_apply(c, m, x, gphi, y, ka, reserve);
         if (rc || m.c_end >= c->m.c_end) return rc;
         m.c_begin = m.c_end;
         m.c_end = c->m.c_end;

@@ -25,6 +25,7 @@
 #include "../../include/knpemi_hip.h"
 #include "cell_geom.hpp"
 #include "p2_tables.hpp"
+#include "p2_mono_tables.hpp"
 #include <cstdlib>
 
 namespace {
@@ -203,6 +204,32 @@ __device__ __forceinline__ void facet_geometry(const MeshDev& m, const CellGeom<
     }
 }
 
+// ---- monomial-product form of the triangle-facet integrals (p2_mono_tables.hpp; tools/gen_p2_tables.py: mono_tables) --------------
+// a P2 trace given by its six facet-node values (v0 v1 v2 e01 e02 e12) as a polynomial in the facet's barycentric coordinates:
+// coefficients of l0^2 l1^2 l2^2 l0l1 l0l2 l1l2  (Lagrange P2 with 1 = l0 + l1 + l2 folded in)
+__device__ __forceinline__ void p2_to_mono(const double* u, double* a) {
+    a[0] = u[0]; a[1] = u[1]; a[2] = u[2];
+    a[3] = fma(4.0, u[3], -(u[0] + u[1]));
+    a[4] = fma(4.0, u[4], -(u[0] + u[2]));
+    a[5] = fma(4.0, u[5], -(u[1] + u[2]));
+}
+// q (degree 4, 15 coefficients) = a * b for two degree-2 polynomials; the index map is a compile-time table, so every q[.] is a register
+__device__ __forceinline__ void mono_mul22(const double* a, const double* b, double* q) {
+#pragma unroll
+    for (int k = 0; k < P2Mono::N4; ++k) q[k] = 0.0;
+#pragma unroll
+    for (int i = 0; i < P2Mono::N2; ++i)
+#pragma unroll
+        for (int j = 0; j < P2Mono::N2; ++j) q[P2Mono::IDX22[i][j]] = fma(a[i], b[j], q[P2Mono::IDX22[i][j]]);
+}
+// c (degree 3, 10 coefficients) += a (degree 2) * sum_m d[m] l_m
+__device__ __forceinline__ void mono_mul21_add(const double* a, const double* d, double* c) {
+#pragma unroll
+    for (int i = 0; i < P2Mono::N2; ++i)
+#pragma unroll
+        for (int m = 0; m < 3; ++m) c[P2Mono::IDX21[i][m]] = fma(a[i], d[m], c[P2Mono::IDX21[i][m]]);
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // EMI:  y = A(kappa) x     (forms: apply_p1.hip header; reference solver.py:325-328, 346)
 // ------------------------------------------------------------------------------------------------------------------
@@ -271,6 +298,51 @@ __device__ __forceinline__ void emi_facet_p2(const MeshDev& m, const CellGeom<D>
     for (int n = 0; n < NF; ++n) r[n] = 0.0;
 #pragma unroll
     for (int mm = 0; mm < D; ++mm) T[mm] = 0.0;
+    if constexpr (D == 3) {
+        // Round 4: every integrand of a_emi is a polynomial of degree <= 6 on the facet (kappa, [u] P2; d_n u P1; test function P2 / P1), so
+        // the traces are multiplied AS POLYNOMIALS in the facet's barycentric coordinates and the products integrated exactly
+        // against the test functions (tables of p2_mono_tables.hpp) instead of being sampled at the 12 points of the degree-6 rule:
+        //   flux = pen (ko + kn) [u] - 1/2 (ko d_n u + kn d_n u')    degree 4 (the cubic part times 1 = l0 + l1 + l2)
+        //   t    = -1/2 ko [u]                                          degree 4
+        // 327 instead of 480 FP64 instructions per facet (profiles/r04_p2_mono.txt); same numbers to rounding (any exact rule gives them).
+        double kon[NF], kom[NF], knm[NF], jm[NF], sm[NF];
+#pragma unroll
+        for (int n = 0; n < NF; ++n) kon[n] = kv[P2<D>::fs(I, 1 + n)];
+        p2_to_mono(kon, kom);
+        p2_to_mono(Kn, knm);
+        p2_to_mono(ju, jm);
+#pragma unroll
+        for (int n = 0; n < NF; ++n) sm[n] = kom[n] + knm[n];
+        double q4[P2Mono::N4], t4[P2Mono::N4], c3[P2Mono::N3];
+        mono_mul22(sm, jm, q4);
+        mono_mul22(kom, jm, t4);
+        double hdo[D], hdn[D];
+#pragma unroll
+        for (int mm = 0; mm < D; ++mm) { hdo[mm] = -0.5 * dno[mm]; hdn[mm] = -0.5 * dnn[mm]; }
+#pragma unroll
+        for (int k = 0; k < P2Mono::N3; ++k) c3[k] = 0.0;
+        mono_mul21_add(kom, hdo, c3);
+        mono_mul21_add(knm, hdn, c3);
+        // g = pen q4 + (l0 + l1 + l2) c3, held in q4's registers
+#pragma unroll
+        for (int k = 0; k < P2Mono::N4; ++k) q4[k] *= pen;
+#pragma unroll
+        for (int k = 0; k < P2Mono::N3; ++k)
+#pragma unroll
+            for (int mm = 0; mm < 3; ++mm) q4[P2Mono::IDX31[k][mm]] += c3[k];
+#pragma unroll
+        for (int k = 0; k < P2Mono::N4; ++k) {
+#pragma unroll
+            for (int n = 0; n < NF; ++n) r[n] = fma(q4[k], P2Mono::I4[k][n], r[n]);
+#pragma unroll
+            for (int mm = 0; mm < D; ++mm) T[mm] = fma(t4[k], P2Mono::I4L[k][mm], T[mm]);
+        }
+        const double ht = -0.5 * area;
+#pragma unroll
+        for (int n = 0; n < NF; ++n) r[n] *= area;
+#pragma unroll
+        for (int mm = 0; mm < D; ++mm) T[mm] *= ht;
+    } else {
 #pragma unroll
     for (int q = 0; q < P2Tab<D>::NQE; ++q) {
         double ko = 0.0, kn = 0.0, jq = 0.0, do_ = 0.0, dn_ = 0.0;
@@ -293,6 +365,7 @@ __device__ __forceinline__ void emi_facet_p2(const MeshDev& m, const CellGeom<D>
         for (int n = 0; n < NF; ++n) r[n] = fma(flux, P2Tab<D>::PSIE[q][n], r[n]);
 #pragma unroll
         for (int mm = 0; mm < D; ++mm) T[mm] = fma(t, P2Tab<D>::LAME[q][mm], T[mm]);
+    }
     }
 #pragma unroll
     for (int n = 0; n < NF; ++n) y[P2<D>::fs(I, 1 + n)] += r[n];

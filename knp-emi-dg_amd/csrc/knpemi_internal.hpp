@@ -214,6 +214,11 @@ bool p2_assembled();                 // KNP_P2_ASSEMBLED=1: round-1 path (quadra
 
 // ring-staged P1 applies on structured 3D meshes (apply_ring.hip): loader wave + LDS-DMA ring + consumer waves
 bool ring_usable(const knp_ctx* c, int which);       // which: 0 EMI, 1 KNP
+// apply_ring_u.hip: the ring-staged applies for 3D P1 meshes WITHOUT geometry classes (geometry from staged vertex coordinates)
+int64_t ring_u_cells(knp_ctx* c, int which);         // leading owned cells the unstructured ring covers (0: not usable); builds its tables once
+void ring_u_free(knp_ctx* c);
+int ring_u_emi_apply(knp_ctx* c, const MeshDev& m, const double* x, const double* kappa, double* y, int reserve_cus);
+int ring_u_knp_apply(knp_ctx* c, const MeshDev& m, const double* x, const double* gphi, double* y, const KnpArgs& ka, int reserve_cus);
 int ring_emi_apply(knp_ctx* c, const MeshDev& m, const double* x, const double* kappa, double* y, int reserve_cus);
 int ring_knp_apply(knp_ctx* c, const MeshDev& m, const double* x, const double* gphi, double* y, const KnpArgs& ka, int reserve_cus);
 

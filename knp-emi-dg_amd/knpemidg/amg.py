@@ -424,8 +424,9 @@ def build_hierarchy(A, theta=0.08, max_coarse=4000, max_levels=12, cheb_degree=N
     # EMI 6.55 -> 6.35 / KNP 5.7 -> 5.75 iterations, degree 3 8.41; profiles/r03_amg_degree_sweep.txt).  The DG-P2 hierarchies (top_interp)
     # keep degree 2: with degree 1 the P2 configuration steps 4 % faster, but its EMI solve meets the stopping test on the preconditioned
     # norm after two iterations with 1.35e-6 left in the concentrations (test_production_tolerances_r1_against_tight_solves[2])
+    # (round 4: degree 1 for the DG-P2 hierarchies too -- the EMI stop no longer depends on the preconditioner, profiles/r04_stop_sweep.txt)
     if cheb_degree is None:
-        cheb_degree = 1 if top_interp is None else 2
+        cheb_degree = 1
     cheb_degree = int(os.environ.get("KNP_AMG_DEGREE", cheb_degree))
     cheb_lower = float(os.environ.get("KNP_AMG_LOWER", cheb_lower))
     max_coarse = int(os.environ.get("KNP_AMG_MAXCOARSE", max_coarse))

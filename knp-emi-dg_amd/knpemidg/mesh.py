@@ -213,6 +213,29 @@ def cell_diameters(mesh):
     return h
 
 
+def refine_uniform(mesh):
+    """Regular (red) refinement of a tetrahedral mesh: every tet -> 8 (four corner tets + the inner octahedron cut along the
+    diagonal m02 - m13, Bey's rule), every edge gets one midpoint vertex.  Returns (refined Mesh, parent cell of every new cell).
+    Old vertices keep their ids.  Used to bring the reference's bundled EMIx reconstruction (121 617 tets) to a size at which its
+    unstructured kernels are measured outside the launch-latency regime (bench.py --workload emix --refine 1: 972 936 tets)."""
+    assert mesh.gdim == 3
+    cells = mesh.cells.astype(np.int64)
+    nv = mesh.coords.shape[0]
+    pairs = [(0, 1), (0, 2), (0, 3), (1, 2), (1, 3), (2, 3)]
+    e = np.stack([np.stack([cells[:, a], cells[:, b]], axis=1) for a, b in pairs], axis=1)       # [Nc, 6, 2], ascending ids
+    key = e[:, :, 0] * nv + e[:, :, 1]
+    uniq, inv = np.unique(key.ravel(), return_inverse=True)
+    mid = (nv + inv).reshape(-1, 6)                                                              # midpoint vertex of each cell edge
+    coords = np.concatenate([mesh.coords, 0.5 * (mesh.coords[uniq // nv] + mesh.coords[uniq % nv])])
+    v0, v1, v2, v3 = cells.T
+    m01, m02, m03, m12, m13, m23 = mid.T
+    kids = [(v0, m01, m02, m03), (v1, m01, m12, m13), (v2, m02, m12, m23), (v3, m03, m13, m23),
+            (m01, m02, m03, m13), (m01, m02, m12, m13), (m02, m03, m13, m23), (m02, m12, m13, m23)]
+    new_cells = np.stack([np.stack(k, axis=1) for k in kids], axis=1).reshape(-1, 4)
+    parent = np.repeat(np.arange(cells.shape[0]), 8)
+    return Mesh(coords, new_cells), parent
+
+
 class MeshFunction:
     """One unsigned tag per mesh entity of dimension `dim` (dolfin.MeshFunction('size_t') stand-in)."""
 

@@ -29,14 +29,16 @@ from knpemidg.utils import interface_normal, plus, minus, pcws_constant_project
 JUMP = lambda f, n: ("JUMP", f, n)   # symbolic marker; the device evaluates minus - plus
 
 
-# factor theta of the error-controlled EMI stop (Solver._read_solver_params): ONE number for every mesh family and degree.  The
-# bound behind the target is pessimistic (alpha_k <= 1, no credit for the smoothing of the KNP step).  Measured against runs converged
-# to 1e-11 / 1e-13 (tools/stop_criterion_sweep.py, profiles/r03_error_controlled_stop.txt), worst concentration error over a
-# stimulated run on the idealized mesh with P1 / with P2 / on the EMIx reconstruction (bound asked: 1e-6):
-#   theta 10: 2.2e-7 / 5.2e-7 / 2.3e-7      theta 20: 4.0e-7 / 7.3e-7 / 3.1e-7      theta 30: 3.6e-7 / 9.4e-7 / 4.8e-7
+# factor theta of the residual half of the error-controlled EMI stop (Solver._read_solver_params): the solve ends when the TRUE residual,
+# in the order-8 norm of its density, is below theta / p^2 * 0.1 rtol_emi * F min|z_k| ||b_knp / vol||_8 (p = polynomial degree: the
+# error behind a given residual density grows with the degree, round 2's "DG-P2 needs a 4x tighter potential"; no mesh quantity enters).
+# Measured against runs converged to 1e-11 / 1e-13 with BOTH DG-level smoothers of the EMI preconditioner (tools/stop_sweep_r04.py,
+# profiles/r04_stop_sweep.txt; bound asked: c <= 1e-6, phi <= 1e-4).
 EMI_TARGET_SAFETY = 20.0
-# factor on rtol_emi of the (necessary) preconditioned-norm test of the EMI solve, the same for every configuration (see there)
-PHI_PRECOND_FACTOR = 2.0e-3
+# factor on rtol_emi of the energy-norm half of the EMI stop: the solve ends when the estimated ||phi - phi_k||_A (Hestenes-Stiefel
+# identity, valid for any SPD preconditioner; csrc/krylov.hip: cg_converged) is below PHI_ENERGY_FACTOR * rtol_emi * ||phi||_A.  It bounds
+# the error of the potential itself (north_star: 1e-4 in the max norm at the reference's rtol_emi 1e-5), smooth components included.
+PHI_ENERGY_FACTOR = 0.5
 
 
 class bcolors:
@@ -311,29 +313,44 @@ class Solver:
         return
 
     def _emi_dg_chebyshev(self):
-        """Whether the EMI preconditioner smooths the DG level with a two-step Chebyshev block-Jacobi (one more operator apply per PCG
-        iteration) or with plain block-Jacobi.  With the finest conforming level smoothed (round 3) the extra step no longer pays on LARGE
-        UNIFORM meshes -- r=2: 4.25 -> 4.7 iterations for a quarter less work per iteration (7.35 -> 7.14 ms/step), r=3 48.9 -> 46.0 -- while
-        small meshes (launch-latency regime: the apply is a small part of an iteration) and badly shaped ones (EMIx reconstruction, cell
-        volumes over 6 decades: 9.2 -> 13.5 iterations without it) keep it (profiles/r03_emi_dg_smoother.txt).  Decided from GLOBAL mesh
-        quantities only, so that every rank of a partitioned run builds the same (symmetric) preconditioner; `emi_dg_chebyshev` in
-        solver_params decides explicitly."""
+        """DG-level smoother of the EMI preconditioner at setup time: the two-step Chebyshev block-Jacobi (one more operator apply per PCG
+        iteration, fewer iterations) unless `emi_dg_chebyshev` in solver_params decides explicitly.  Whether the extra apply pays depends
+        on where the run sits between the launch-latency and the bandwidth regime and on the mesh quality (r=2: 4.25 -> 4.7 iterations
+        without it for a quarter less work per iteration; EMIx reconstruction: 9.2 -> 13.5 iterations), so it is MEASURED on the first
+        solves of the run itself (_emi_smoother_trial) instead of being read off mesh-size thresholds (round 3)."""
         sp = getattr(self, "solver_params", None)
         explicit = getattr(sp, "emi_dg_chebyshev", None)
-        if explicit is not None:
-            return bool(explicit)
-        if self.degree_knp != 1:
-            # DG-P2: with the step the P2 configuration steps 6 % faster at r=1 (EMI 9.45 -> 7.6 iterations) but its EMI solve then meets the
-            # stopping tests with 1.45e-6 left in the concentrations over 40 steps (bound 1e-6; tools/tolerance_sweep.py, DEGREE=2): stays off
-            return False
-        g = getattr(self, "global_mesh_tuple", None)
-        mesh = g[0] if g is not None else self.mesh
-        if mesh.gdim != 3 or mesh.num_cells() < 400000:
-            return True
-        x = mesh.coords[mesh.cells]
-        e = x[:, 1:] - x[:, :1]
-        vol = np.abs(np.einsum("ci,ci->c", e[:, 0], np.cross(e[:, 1], e[:, 2])))        # 6 x cell volume
-        return bool(vol.max() > 10.0 * vol.min())
+        if explicit is None and os.environ.get("KNP_EMI_CHEB") is not None:
+            explicit = int(os.environ["KNP_EMI_CHEB"]) != 0                # the device reads the same variable as an override (csrc/abi.hip)
+        self._emi_trial = None if explicit is not None else {"solve": 0, "cost": {True: [], False: []}}
+        return True if explicit is None else bool(explicit)
+
+    def _emi_smoother_trial(self, seconds, res):
+        """Measured choice of the EMI DG-level smoother.  Solve 0 carries one-off work (eigenvalue estimate, graph capture) and is not
+        counted; solves 1 and 3 run with, solves 2 and 4 without the Chebyshev step; each is charged its wall time per decade of
+        TRUE-residual reduction (the norm of the residual target, so that steps of different difficulty compare), the times summed over the
+        ranks of a partitioned run (one all-reduce: every rank takes the same decision and keeps ONE symmetric preconditioner).  The step
+        stays unless dropping it is at least 3 % cheaper.  Nothing else has to change with the choice: both variants meet the same
+        stopping test, which does not depend on the preconditioner (csrc/krylov.hip: cg_converged)."""
+        tr = self._emi_trial
+        k = tr["solve"]
+        tr["solve"] += 1
+        if 1 <= k <= 4:
+            decades = max(np.log10(max(float(res[0]), 1e-300) / max(float(res[1]), 1e-300)), 0.25)
+            tr["cost"][k % 2 == 1].append(seconds / decades)
+        if k in (1, 3):
+            self.dev.set_emi_dg_smoother(False)
+        elif k == 2:
+            self.dev.set_emi_dg_smoother(True)
+        elif k == 4:
+            on, off = self.dev.allreduce_sum([sum(tr["cost"][True]), sum(tr["cost"][False])])
+            keep = not (off < 0.97 * on)
+            self.dev.set_emi_dg_smoother(keep)
+            self.emi_dg_chebyshev_measured = {"chebyshev_s_per_decade": float(on), "plain_s_per_decade": float(off), "chosen": bool(keep)}
+            if self.verbose:
+                print(" EMI DG-level smoother: Chebyshev step %.3f ms / decade, plain block-Jacobi %.3f ms / decade -> %s"
+                      % (1e3 * on, 1e3 * off, "Chebyshev" if keep else "plain"))
+            self._emi_trial = None
 
     def _host_initial_kappa(self):
         """kappa = F psi sum_k z_k^2 D_k c_k of the initial state, nodal [nc, nd] (what k_kappa computes on the device)."""
@@ -605,15 +622,13 @@ class Solver:
             self._rtol_emi = max(rt * float(dflt), min(rt, 1.0e-11))
         else:
             c_tol = float(getattr(sp, "c_tol", None) or 0.1 * rt)
-            theta = float(getattr(sp, "emi_target_safety", None) or os.environ.get("KNP_EMI_TARGET_SAFETY", EMI_TARGET_SAFETY))
+            theta = float(getattr(sp, "emi_target_safety", None) or os.environ.get("KNP_EMI_TARGET_SAFETY", EMI_TARGET_SAFETY / self.degree_emi ** 2))
             self._emi_target = theta * c_tol
-            # The test on the preconditioned norm stays NECESSARY (csrc/krylov.hip: cg_converged): it is what bounds the error of the
-            # potential itself (north_star: 1e-4), in particular its smooth components, which neither residual density sees and the
-            # concentrations do not feel.  ||M^-1 r|| under-reports the error by up to the condition number of the preconditioned
-            # operator -- 1 for the reference's BoomerAMG, 40-100 for this build's two-level method on every mesh family -- hence
-            # PHI_PRECOND_FACTOR = 2e-3 on rtol_emi for ALL configurations (the 2D configuration meets the residual target after 1-2
-            # iterations and is left with 2e-4 in phi at 0.1 rtol_emi).
-            self._rtol_emi = PHI_PRECOND_FACTOR * rt
+            # Second half of the stop (csrc/krylov.hip: cg_converged): the energy-norm error of the iterate, estimated from the CG
+            # coefficients, relative to ||phi||_A.  Round 3 tested the preconditioned norm ||M^-1 r|| here, which under-reports the
+            # error by a factor that depends on M (a better preconditioner met it with MORE error left); the Hestenes-Stiefel estimate
+            # measures the error itself and holds for any SPD preconditioner.
+            self._rtol_emi = float(getattr(sp, "emi_energy_factor", None) or os.environ.get("KNP_EMI_ENERGY_FACTOR", PHI_ENERGY_FACTOR)) * rt
         self._atol_emi = 1e-40 if self.direct_emi else float(self.atol_emi)
         ks = getattr(sp, "knp_rtol_scale", None)
         if ks is None and "KNP_KNP_RTOL_SCALE" in os.environ:
@@ -626,12 +641,17 @@ class Solver:
                 ("residual target %.2e x F min|z| ||b_knp||" % self._emi_target) if self._emi_target else "rtol %.2e" % self._rtol_emi,
                 self._rtol_knp))
         self._atol_knp = 1e-40 if self.direct_knp else float(self.atol_knp)
-        # ksp_min_it 5 of the reference's GMRES (solver.py:686) = five preconditioner applications; kept as five iterations of either method
-        # here (BiCGStab: ten applications) -- KNP_KNP_MIN_IT / solver_params.knp_min_it change it
-        self._knp_min_it = int(getattr(sp, "knp_min_it", None) or os.environ.get("KNP_KNP_MIN_IT", 5))
         # KNP Krylov method: the device default is BiCGStab; `knp_krylov = "gmres"` (+ `gmres_restart`, default 30) in solver_params,
         # or KNP_KNP_KRYLOV=gmres, selects the reference's restarted GMRES (ksp_type gmres / ksp_gmres_restart 30, solver.py:684-701)
         meth = getattr(sp, "knp_krylov", None) or os.environ.get("KNP_KNP_KRYLOV", "bicgstab")
+        # ksp_min_it 5 of the reference's GMRES (solver.py:686) = at least five operator + preconditioner applications.  A BiCGStab
+        # iteration makes two of each, so three iterations (six applications) would honour it; rounds 1-3 forced five iterations = ten
+        # applications, and the solves of the quiet phases of a run stopped at exactly that floor.  FOUR is the measured optimum: the
+        # forced iterations of the quiet steps are what keeps the per-step errors from adding up over a run (r=1, 40 steps, worst c
+        # against tight solves: min_it 3: 9.0e-7 at 3.95 iterations per step, 4: 2.2e-7 at 4.47, 5: 2.1e-7 at 5.12; tightening the
+        # residual test instead buys less per iteration: factor 10 at min_it 3: 5.8e-7 at 4.70; profiles/r04_min_it.txt,
+        # r04_stop_sweep.txt).  KNP_KNP_MIN_IT / solver_params.knp_min_it change it.
+        self._knp_min_it = int(getattr(sp, "knp_min_it", None) or os.environ.get("KNP_KNP_MIN_IT", 5 if meth == "gmres" else 4))
         if self.dev is not None and meth != getattr(self, "_knp_krylov", "bicgstab"):
             self.dev.set_knp_krylov(meth, int(getattr(sp, "gmres_restart", None) or os.environ.get("KNP_GMRES_RESTART", 30)))
             self._knp_krylov = meth
@@ -679,6 +699,8 @@ class Solver:
             print(f"{bcolors.OKGREEN} GPU Execution time PDE solve emi: {res:.4f} seconds ({niter} its) {bcolors.ENDC}")
         self.emi_solve_timer += res
         self.emi_niter.append(niter)
+        if getattr(self, "_emi_trial", None) is not None and self._emi_target and self.use_amg and not self.direct_emi:
+            self._emi_smoother_trial(res, r)
         self._maybe_refresh_amg_emi(niter)
         if self.save_solver_stats:
             if not self.direct_emi:

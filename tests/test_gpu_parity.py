@@ -435,7 +435,7 @@ def test_emix_mesh_vs_oracle(hip_lib):
     tets, three subdomain classes, slivers, glial + neuronal membrane tags, membranes between equal-tag cells; parameters of
     examples/emix-simulations/run_EMIx_simulation.py:56-170 in cm / ms / mV) -- both operator applies against the oracle's assembled
     CSR matrices, both right-hand sides in both splitting modes, the step-III projections and the update_ode traces, on seeded
-    inputs.  Runs the coordinate-path kernels (no geometry classes on this mesh)."""
+    inputs.  No geometry classes on this mesh: the applies run the unstructured ring-staged kernels (apply_ring_u.hip)."""
     import os, sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "emix_simulations"))
     from emix_common import load_mesh
@@ -447,6 +447,7 @@ def test_emix_mesh_vs_oracle(hip_lib):
     dev = device_for(pb)
     try:
         assert dev.n_geometry_classes == 0
+        assert dev.apply_variant(0) == 10 and dev.apply_variant(1) == 10       # ring-staged, geometry from staged vertex coordinates (apply_ring_u.hip)
         push_state(dev, pb)
         dev.update_kappa(); dev.update_dnphi()
         assert relerr(dev.download(A.F_KAPPA), pb.kappa()) < 1e-14
@@ -478,6 +479,75 @@ def test_emix_mesh_vs_oracle(hip_lib):
         E = dev.download(A.F_E).reshape(len(pb.ions), -1)
         for k in range(len(pb.ions)):
             assert relerr(E[k][pb.mem], ko.nernst(pb, k)) < 1e-12
+    finally:
+        dev.close()
+
+
+@pytest.mark.parametrize("env,variant", [({}, 10), ({"KNP_RING_WG": "8"}, 10), ({"KNP_APPLY_RING_U": "0"}, 0)])
+@pytest.mark.parametrize("which", ["emix_sub", "emix_sub_refined", "jittered_box"])
+def test_unstructured_apply_kernel_variants(hip_lib, monkeypatch, env, variant, which):
+    """Both apply paths for 3D P1 meshes WITHOUT geometry classes against the oracle's assembled operators (solver.py:325-328, 586-594):
+    the ring-staged kernels that form the geometry from staged vertex coordinates (apply_ring_u.hip; default), the same kernels with
+    the launch shrunk to 8 workgroups (KNP_RING_WG: a workgroup walks 9-70 blocks -- both slots and both list buffers reused many
+    times, the short last block) and the thread-per-cell coordinate kernels (KNP_APPLY_RING_U=0).  Meshes: a 17 920-tet piece of the
+    tissue reconstruction (glial + neuronal membranes, slivers), its regular refinement (143 360 tets: the measured bench workload's
+    shape) and a jittered box (cells of a structured mesh with every interior vertex moved)."""
+    from knpemidg import _abi as A
+    if which == "jittered_box":
+        from common import small_3d
+        m, s, f = small_3d((16, 6, 6))
+        rng = np.random.default_rng(11)
+        inner = np.ones(m.num_vertices(), dtype=bool)
+        inner[np.unique(m.facets[m.exterior_facets()])] = False
+        jit = rng.uniform(-1, 1, size=m.coords.shape) * np.array([0.2e-6, 0.02e-6, 0.02e-6])
+        m.coords[inner] += jit[inner]
+        pb = ko.build_idealized(m, s.array(), f.array(), membrane_tags=(1,))
+        volt = 1.0
+    else:
+        import emix_sub
+        m, s, f = emix_sub.emix_submesh()
+        if which == "emix_sub_refined":
+            from knpemidg.mesh import refine_uniform, MeshFunction
+            m, parent = refine_uniform(m)
+            sub = s.array()[parent]
+            fc = m.facet_cells
+            tags = np.full(m.num_facets(), 10, dtype=np.uint32)
+            it = fc[:, 1] >= 0
+            s0, s1 = sub[fc[it, 0]], sub[fc[it, 1]]
+            p0, p1 = parent[fc[it, 0]], parent[fc[it, 1]]
+            # a child facet is a membrane facet iff it lies on a parent's membrane facet: the two children stem from different parents
+            # whose shared facet carries that tag
+            pf = emix_sub.emix_submesh()
+            key = {}
+            pm = pf[0]
+            for fid in np.nonzero(pf[2].array() % 10 != 0)[0]:
+                a, b = pm.facet_cells[fid]
+                key[(min(a, b), max(a, b))] = int(pf[2].array()[fid])
+            t = np.zeros(int(it.sum()), dtype=np.uint32)
+            for q, (a, b) in enumerate(zip(np.minimum(p0, p1), np.maximum(p0, p1))):
+                if a != b:
+                    t[q] = key.get((int(a), int(b)), 0)
+            tags[it] = t
+            s, f = MeshFunction(m, 3, sub.astype(np.uint32)), MeshFunction(m, 2, tags)
+        pb = ko.build_emix(m, s.array(), f.array())
+        volt = 1.0e3
+    x = synthetic_state(pb, volt=volt)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    dev = device_for(pb)
+    try:
+        assert dev.n_geometry_classes == 0
+        assert dev.apply_variant(0) == variant and dev.apply_variant(1) == variant
+        push_state(dev, pb)
+        dev.update_kappa(); dev.update_dnphi()
+        Aemi, _, _ = ko.assemble_emi(pb, want_B=False)
+        dev.upload(A.F_X, x[0]); dev.emi_apply(A.F_X, A.F_Y)
+        assert relerr(dev.download(A.F_Y, 0, pb.ndof), Aemi @ x[0].ravel()) < TOL
+        del Aemi
+        dev.upload(A.F_X, x); dev.knp_apply(A.F_X, A.F_Y)
+        y = dev.download(A.F_Y).reshape(pb.N_ions, -1)
+        for k in range(pb.N_ions):
+            assert relerr(y[k], ko.assemble_knp(pb, k) @ x[k].ravel()) < TOL
     finally:
         dev.close()
 
@@ -529,8 +599,9 @@ def test_partitioned_emix_mesh_on_one_gpu(hip_lib, monkeypatch):
 
 def test_unstructured_geometry_uses_coordinate_kernels(hip_lib):
     """Randomly jittered vertices destroy the translation invariance of the BoxMesh: no geometry classes can be
-    formed, so the general coordinate-path kernels (geometry recomputed from vertex coordinates in registers) run.
-    Also exercises non-uniform h, varying facet areas and cell volumes."""
+    formed, so the kernels that recompute the geometry from vertex coordinates run (ring-staged for the operator applies,
+    thread-per-cell for the right-hand sides and the block inverses).  Also exercises non-uniform h, varying facet areas and
+    cell volumes, and a converged solve on such a mesh."""
     from knpemidg import _abi as A
     from common import small_3d
     m, s, f = small_3d((10, 4, 4))

@@ -348,33 +348,52 @@ def test_knp_hierarchy_helper_process_matches_in_process(degree):
     assert setup_worker.collect(bad) is None
 
 
-def test_emi_dg_smoother_rule_uses_global_mesh_quantities_only():
-    """knpemidg/solver.py: Solver._emi_dg_chebyshev -- the DG-level Chebyshev step of the EMI preconditioner is dropped on large uniform 3D
-    meshes only, kept on small and on badly shaped ones, decided from the GLOBAL mesh (every rank of a partitioned run must build the same
-    symmetric preconditioner), and solver_params decides explicitly when it says so."""
-    import types
+def test_emi_dg_smoother_is_chosen_by_measurement():
+    """knpemidg/solver.py: Solver._emi_dg_chebyshev / _emi_smoother_trial -- round 3 read the DG-level smoother of the EMI preconditioner
+    off mesh-size thresholds; round 4 measures it: solve 0 is not counted, solves 1 / 3 run with and 2 / 4 without the Chebyshev step,
+    each charged its time per decade of true-residual reduction, the sums all-reduced (every rank of a partitioned run takes the same
+    decision), the step dropped only if that is >= 3 % cheaper; solver_params / KNP_EMI_CHEB decide explicitly when they say so."""
     from collections import namedtuple
     from knpemidg.solver import Solver
-    from knpemidg.mesh import make_mesh_3D
 
-    def rule(mesh, degree=1, global_mesh=None, explicit=None):
+    class Dev:
+        def __init__(self):
+            self.calls = []
+            self.reduced = []
+
+        def set_emi_dg_smoother(self, on):
+            self.calls.append(bool(on))
+
+        def allreduce_sum(self, v):
+            self.reduced.append(list(v))
+            return np.asarray(v, dtype=float) * 3.0          # three ranks with the same timings
+
+    def run(costs_on, costs_off, explicit=None):
         S = Solver.__new__(Solver)
-        S.degree_knp = degree
-        S.mesh = mesh
-        if global_mesh is not None:
-            S.global_mesh_tuple = (global_mesh, None, None)
+        S.verbose = False
+        S.dev = Dev()
         if explicit is not None:
             S.solver_params = namedtuple("solver_params", ("emi_dg_chebyshev",))(explicit)
-        return S._emi_dg_chebyshev()
-    small = make_mesh_3D(0)[0]
-    large = make_mesh_3D(2)[0]
-    assert large.num_cells() >= 400000 > small.num_cells()
-    assert rule(small) is True and rule(large) is False
-    assert rule(small, global_mesh=large) is False and rule(large, global_mesh=small) is True      # a partition follows the global mesh
-    assert rule(large, degree=2) is False and rule(small, degree=2) is False                        # DG-P2 keeps plain block-Jacobi
-    assert rule(large, explicit=True) is True and rule(small, explicit=False) is False
-    # the same cell count with cell volumes over two decades (graded in x): the step stays
-    x = large.coords.copy()
-    x[:, 0] = x[:, 0].min() + (x[:, 0] - x[:, 0].min()) ** 3 / (np.ptp(x[:, 0]) ** 2)
-    graded = types.SimpleNamespace(coords=x, cells=large.cells, gdim=3, num_cells=large.num_cells)
-    assert rule(graded) is True
+        first = S._emi_dg_chebyshev()
+        if S._emi_trial is None:
+            return first, S.dev.calls, None
+        # (seconds, [r0, r1]) of solves 0..4: one decade of reduction each, so seconds = cost per decade
+        seq = [(9.9, [1.0, 0.1]), (costs_on[0], [1.0, 0.1]), (costs_off[0], [1.0, 0.1]), (costs_on[1], [1.0, 0.1]), (costs_off[1], [1.0, 0.1])]
+        for sec, res in seq:
+            assert S._emi_trial is not None
+            S._emi_smoother_trial(sec, res)
+        assert S._emi_trial is None and len(S.dev.reduced) == 1
+        return first, S.dev.calls, S.emi_dg_chebyshev_measured
+
+    first, calls, m = run((1.0, 1.0), (0.8, 0.8))            # plain block-Jacobi 20 % cheaper per decade: dropped
+    assert first is True and calls == [False, True, False, False] and m["chosen"] is False
+    first, calls, m = run((1.0, 1.0), (0.99, 0.99))          # within the 3 % margin: the step stays
+    assert calls[-1] is True and m["chosen"] is True
+    first, calls, m = run((1.0, 1.0), (1.3, 1.2))
+    assert calls[-1] is True and abs(m["plain_s_per_decade"] - 3.0 * 2.5) < 1e-12
+    assert run(None, None, explicit=False)[0] is False and run(None, None, explicit=True)[0] is True      # explicit: no trial
+    os.environ["KNP_EMI_CHEB"] = "0"
+    try:
+        assert run(None, None)[0] is False
+    finally:
+        del os.environ["KNP_EMI_CHEB"]

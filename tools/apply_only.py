@@ -1,6 +1,7 @@
 """Runs only the operator-apply kernels on the r=R idealized 3D mesh (profiling helper)."""
 import os, sys, time
 import numpy as np
+os.environ.setdefault("KNP_AMG_SERIAL_SETUP", "1")     # no preconditioner is built here: do not start the setup helper processes
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "knp-emi-dg_amd")); sys.path.insert(0, os.path.join(ROOT, "examples", "idealized_geometries"))
 from idealized_common import make_solver

@@ -94,7 +94,62 @@ def tables(D):
     return out
 
 
+def mono_tables():
+    """Tables of the MONOMIAL-PRODUCT form of the facet integrals of a_emi on triangles (csrc/apply_p2.hip, round 4): every integrand
+    is a polynomial, so instead of sampling at the 12 points of the degree-6 rule the kernel multiplies the P2 traces as polynomials in
+    the facet's barycentric coordinates and integrates the product exactly.
+      degree-2 monomials (order of a P2 trace after conversion):  l0^2 l1^2 l2^2 l0l1 l0l2 l1l2
+      IDX22[i][j]  degree-4 monomial of (degree-2 monomial i) * (degree-2 monomial j)
+      IDX21[i][m]  degree-3 monomial of (degree-2 monomial i) * l_m
+      IDX31[k][m]  degree-4 monomial of (degree-3 monomial k) * l_m          (multiplication by 1 = l0 + l1 + l2)
+      I4[a][n]     int l^a psi_n   (psi_n: the facet P2 Lagrange basis, frame order v0 v1 v2 e01 e02 e12; reference measure 1)
+      I4L[a][m]    int l^a l_m"""
+    import itertools
+    from math import factorial
+    M1 = [(1, 0, 0), (0, 1, 0), (0, 0, 1)]
+    M2 = [(2, 0, 0), (0, 2, 0), (0, 0, 2), (1, 1, 0), (1, 0, 1), (0, 1, 1)]
+
+    def mons(d):
+        return [a for a in itertools.product(range(d + 1), repeat=3) if sum(a) == d]
+    M3, M4 = mons(3), mons(4)
+    i3 = {a: k for k, a in enumerate(M3)}
+    i4 = {a: k for k, a in enumerate(M4)}
+    add = lambda a, b: tuple(x + y for x, y in zip(a, b))
+    integ = lambda a: 2.0 * factorial(a[0]) * factorial(a[1]) * factorial(a[2]) / factorial(sum(a) + 2)
+    psi = np.zeros((6, 6))                       # Lagrange P2 in degree-2 monomials (1 = l0 + l1 + l2 folded in)
+    for v in range(3):
+        psi[v, v] = 1.0
+        for k, (a, b) in enumerate([(0, 1), (0, 2), (1, 2)]):
+            if v in (a, b):
+                psi[v, 3 + k] = -1.0
+    for k in range(3):
+        psi[3 + k, 3 + k] = 4.0
+    out = {"IDX22": np.array([[i4[add(a, b)] for b in M2] for a in M2]),
+           "IDX21": np.array([[i3[add(a, m)] for m in M1] for a in M2]),
+           "IDX31": np.array([[i4[add(a, m)] for m in M1] for a in M3]),
+           "I4": np.array([[sum(psi[n, b] * integ(add(al, M2[b])) for b in range(6)) for n in range(6)] for al in M4]),
+           "I4L": np.array([[integ(add(al, m)) for m in M1] for al in M4])}
+    return out
+
+
+def write_mono():
+    t = mono_tables()
+    s = ("// GENERATED by tools/gen_p2_tables.py -- do not edit.  Monomial-product form of the triangle-facet integrals of a_emi (DG-P2, 3D):\n"
+         "// index maps of the polynomial products and the exact integrals of degree-4 monomials against the facet bases; see the generator.\n"
+         "#pragma once\n\nstruct P2Mono {\n    static constexpr int N2 = 6, N3 = 10, N4 = 15;\n")
+    for k in ("IDX22", "IDX21", "IDX31"):
+        s += carr(k, t[k], "int")
+    for k in ("I4", "I4L"):
+        s += carr(k, t[k], exact=True)
+    s += "};\n"
+    path = os.path.join(ROOT, "knp-emi-dg_amd", "csrc", "p2_mono_tables.hpp")
+    with open(path, "w") as f:
+        f.write(s)
+    print("wrote", path)
+
+
 def main():
+    write_mono()
     s = ("// GENERATED by tools/gen_p2_tables.py -- do not edit.  Reference-element constants of the matrix-free DG-P2 applies\n"
          "// (apply_p2.hip); see the generator for definitions.\n#pragma once\n#include <cstdint>\n\n"
          "template <int D> struct P2Tab;\n\n")
