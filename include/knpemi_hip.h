@@ -153,18 +153,26 @@ int knp_emi_rhs(knp_ctx* ctx);             /* B_EMI <- L_emi(C, C_ELIM, PHI_M, I
 int knp_knp_rhs(knp_ctx* ctx);             /* B_KNP <- L_knp(C, C_PREV, C_ELIM, PHI, PHI_M, I_CH) solver.py:731 */
 
 /* ---- solves (KSP.solve) ----------------------------------------------------------------------
- * EMI: PCG, cell-block-Jacobi; converged when ||M^-1 r|| <= max(rtol ||M^-1 b||, atol) (PETSc's default
- *      preconditioned-norm test, solver.py:425-444); initial guess = PHI (ksp_initial_guess_nonzero).
- * KNP: per-species BiCGStab, cell-block-Jacobi, true residual: converged when ||r / vol||_8 <= max(20 rtol ||b / vol||_8, atol) --
- *      order-8 norms of the residual and load DENSITIES (sum_K (||.||_K / vol_K)^8)^(1/8), a sum-type stand-in for the max norm: the
- *      concentrations are asked for in the max norm, and their max-norm error was measured at 0.03-0.055 of that ratio on uniform
- *      AND on sliver-ridden meshes (csrc/krylov.hip, profiles/r03_knp_norms_*.txt), i.e. the test asks for an estimated relative
- *      max-norm error of about rtol; at least min_it iterations (ksp_min_it, solver.py:686); initial guess = C.
- *      bnorm is reported as ||b||_w, ||.||_w^2 = sum_K |.|_K^2 / vol_K (the L2 norm of the Riesz representative).
- * niter: iterations (EMI: 1 int, KNP: n_sys ints); res: per system {res0, res, bnorm} in the norm of the stopping test.
- * Returns -3 if not converged within maxit (ksp_error_if_not_converged, solver.py:428).
- * knp_emi_residual_target: r_abs > 0 makes the following EMI solves stop on ||b - A phi||_w <= r_abs instead (an error-controlled stop
- *      derived from the concentration accuracy wanted: csrc/abi.hip, knpemidg/solver.py); 0 restores the preconditioned-norm test. */
+ * EMI: PCG, cell-block-Jacobi (+ auxiliary-space AMG when uploaded); initial guess = PHI (ksp_initial_guess_nonzero).
+ *      Without a residual target (knp_emi_residual_target(ctx, 0), the state after knp_ctx_create): PETSc's default test on the
+ *      preconditioned norm, ||M^-1 r|| <= max(rtol ||M^-1 b||, atol) (solver.py:425-444); res = {||M^-1 r0||, ||M^-1 r||, ||M^-1 b||}.
+ *      With a residual target r_abs > 0 (what knpemidg.Solver uses; csrc/krylov.hip: cg_converged) the solve ends when BOTH
+ *        (i)  ||(b - A phi) / vol||_8 <= r_abs      -- the TRUE residual in the order-8 norm of its density (sum_K (|r_K| / vol_K)^8)^(1/8),
+ *             a sum-type stand-in for the max norm; the caller derives r_abs from the accuracy wanted in the concentrations, and
+ *        (ii) ||phi - phi_k||_A <= rtol ||phi||_A   -- the energy-norm error of the iterate, estimated from the CG coefficients through the
+ *             Hestenes-Stiefel identity ||x - x_k||_A^2 = sum_{j >= k} alpha_j (r_j . z_j), which holds for ANY SPD preconditioner
+ *      hold, at the latest when ||M^-1 r|| <= 1e-11 ||M^-1 b|| (targets below what fp64 reaches must not loop forever); atol is not used;
+ *      res = {||r0 / vol||_8, ||r / vol||_8, estimated ||phi - phi_k||_A / ||phi||_A}.  Neither (i) nor (ii) depends on the preconditioner.
+ * KNP: per-species BiCGStab (or GMRES, knp_set_knp_krylov), same preconditioner family, TRUE residual: converged when
+ *      ||r / vol||_8 <= max(20 rtol ||b / vol||_8, atol) -- order-8 norms of the residual and load DENSITIES: the concentrations are asked
+ *      for in the max norm, and their max-norm error was measured at 0.03-0.055 of that ratio on uniform AND on sliver-ridden meshes
+ *      (csrc/krylov.hip, profiles/r03_knp_norms_*.txt), i.e. the test asks for an estimated relative max-norm error of about rtol; the
+ *      factor 20 (KNP_D8_FACTOR) applies to whatever rtol is passed (callers that mean the residual itself, e.g. a direct-solve
+ *      emulation, divide it out); at least min_it iterations (ksp_min_it, solver.py:686); initial guess = C.
+ *      res per system = {||r0 / vol||_8, ||r / vol||_8, ||b / vol||_8} (KNP_KNP_NORM2=1: the cell-volume-weighted 2-norms instead).
+ * niter: iterations (EMI: 1 int, KNP: n_sys ints).  Returns -3 if not converged within maxit (ksp_error_if_not_converged, solver.py:428).
+ * knp_emi_residual_target: r_abs > 0 arms the error-controlled stop above for the following EMI solves; 0 restores PETSc's test.
+ *      Every rank of a partitioned run must pass the same number (knp_allreduce_sum). */
 int knp_emi_residual_target(knp_ctx* ctx, double r_abs);
 int knp_emi_solve(knp_ctx* ctx, double rtol, double atol, int maxit, int check_every, int* niter, double* res);
 int knp_knp_solve(knp_ctx* ctx, double rtol, double atol, int maxit, int min_it, int check_every, int* niter, double* res);

@@ -292,7 +292,7 @@ def _dist0_worker(rank, world, port, q, method, degree):
     from knpemidg.partition import Partition
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        mesh, sub, surf = small_3d((8, 4, 4))
+        mesh, sub, surf = small_3d((max(8, 2 * world), 4, 4))
         cs = amg.ConformingSpace(mesh, surf.array(), [1])
         space = cs if degree == 1 else amg.ConformingSpaceP2(cs)
         rng = np.random.default_rng(5)                                     # same stream on every rank: global data, as in a partitioned run
@@ -348,7 +348,7 @@ def _dist0_worker(rank, world, port, q, method, degree):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,method,degree", [(2, "slab", 1), (3, "rcb", 1), (2, "slab", 2)])
+@pytest.mark.parametrize("world,method,degree", [(2, "slab", 1), (3, "rcb", 1), (2, "slab", 2), (4, "slab", 1), (8, "rcb", 1), (4, "rcb", 2)])
 def test_row_distributed_level0_gloo(world, method, degree):
     """The row-distributed finest conforming level with one PROCESS per rank: every rank builds only its own rows and tables
     (knpemidg.amg.Dist0Space), the shared dofs travel point to point and the level-1 right-hand side through an all-reduce (gloo); one
