@@ -29,6 +29,67 @@ EMI_BYTES_PER_CELL = 137.0                 # algorithmic bytes / cell, 3D P1 (SU
 KNP_BYTES_PER_CELL = 217.0                 # 2 species batched
 
 
+# ---- cpu_baseline: the oracle's assembled-CSR path on the host cores ---------------------------------------------------------------
+_CPU_PART = {}
+
+
+def _cpu_part_init(resolution, world):
+    """Worker state of the parallel assembly: the x-slab part `rank` of the mesh (owned cells + one ghost layer, exactly what a rank
+    of the partitioned GPU run holds: knpemidg/partition.py) with the oracle problem on it.  Rows of owned cells assembled on the
+    part are the rows of the global matrix (DG couples a cell to its facet neighbours only; tests/test_gpu_parity.py:
+    test_partitioned_kernels_on_one_gpu checks the same statement for the kernels)."""
+    for q in (os.path.join(ROOT, "oracle"), os.path.join(ROOT, "knp-emi-dg_amd")):
+        if q not in sys.path:
+            sys.path.insert(0, q)
+    _CPU_PART.clear()
+    _CPU_PART.update(resolution=resolution, world=world, parts={})
+
+
+def _cpu_part_problem(rank):
+    import knpemi_oracle as ko
+    from knpemidg.mesh import make_mesh_3D
+    from knpemidg.partition import Partition
+    st = _CPU_PART
+    if rank not in st["parts"]:
+        if "mesh" not in st:
+            st["mesh"] = make_mesh_3D(st["resolution"])
+            st["partition"] = Partition(st["mesh"][0], st["world"], method="slab")
+        m, s, f = st["mesh"]
+        loc = st["partition"].local(rank)
+        sub_l, surf_l = loc.localize(s, f, (1, 2))
+        pb = ko.build_idealized(loc.mesh, sub_l.array(), surf_l.array())
+        st["parts"][rank] = (loc, pb)
+    return st["parts"][rank]
+
+
+def _cpu_part_warm(rank):
+    _cpu_part_problem(rank)
+    return rank
+
+
+def _cpu_part_assemble(job):
+    """One part of one operator: kind 'emi' -> (rows of a_emi, L_emi), 'knp' -> (rows of A_knp,k, L_knp,k) of the owned cells, global
+    column ids.  state: the global fields the forms read, sliced here to the part."""
+    import knpemi_oracle as ko
+    import scipy.sparse as sp
+    kind, rank, k, state = job
+    loc, pb = _cpu_part_problem(rank)
+    cg, fg, no, nd = loc.cells_global, loc.facets_global, loc.nc_owned, pb.nd
+    pb.phi_M = state["phi_M"][fg]
+    for name in pb.I_ch:
+        pb.I_ch[name] = state["I_ch"][name][fg]
+    if "phi" in state:
+        pb.phi = state["phi"][cg]
+    if kind == "emi":
+        A, b, _ = ko.assemble_emi(pb, want_B=False)
+    else:
+        A, b = ko.assemble_knp(pb, k), ko.knp_rhs(pb, k)
+    A = A.tocsr()[:no * nd]
+    gcol = (cg[:, None] * nd + np.arange(nd)[None, :]).ravel()
+    A = sp.csr_matrix((A.data, gcol[A.indices], A.indptr), shape=(no * nd, state["ndof"]))
+    return rank, A, np.asarray(b).ravel()[:no * nd], cg[:no]
+
+
 def cpu_baseline(resolution=1):
     """CPU restatement of ONE splitting step of the same workload class, timed on this host: the oracle's assembled-CSR forms
     (reference: solver.py:270-403, 534-663) on the 4-axon mesh at `resolution` (r=1: 124 416 tets, 1.49 M DoFs), PETSc-like
@@ -36,12 +97,121 @@ def cpu_baseline(resolution=1):
     auxiliary-space operator the GPU applies (block-Jacobi + V-cycle of the product's smoothed-aggregation hierarchy,
     oracle/cpu_precond.py), so that iteration counts are comparable.  Reports assemble time, solve time and iterations separately,
     the three quantities the reference logs per step (solver.py:499-525, 745-784).  kind = "port": FEniCS itself is not
-    installable here (BASELINE.md section 2); scipy's sparse kernels are single-threaded and BLAS / LAPACK are pinned to one thread (threadpoolctl), so `cores` = 1;
-    `host_cores` records what the box has."""
+    installable here.
+    Round 4: the host's cores are used the way an MPI run of the reference would use them -- the mesh is cut into x-slabs, one
+    process per slab assembles the rows of its cells (the oracle's own functions on the owned + ghost sub-mesh), the sparse products
+    of the Krylov solves run on the same number of threads (knp_host_spmv); `cores` = processes / threads actually used,
+    KNP_CPU_BASELINE_CORES overrides (1 = the single-process run of rounds 1-3)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    from threadpoolctl import threadpool_limits
-    with threadpool_limits(limits=1):                 # BLAS / LAPACK pinned to one thread: `cores` = 1 is what really ran
-        return _cpu_baseline_one_core(resolution)
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = int(os.environ.get("KNP_CPU_BASELINE_CORES", min(16, avail)))
+    if cores <= 1:
+        from threadpoolctl import threadpool_limits
+        with threadpool_limits(limits=1):                 # BLAS / LAPACK pinned to one thread: `cores` = 1 is what really ran
+            return _cpu_baseline_one_core(resolution)
+    return _cpu_baseline_parallel(resolution, cores)
+
+
+def _cpu_baseline_parallel(resolution, cores):
+    import multiprocessing as mp
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spla
+    import knpemi_oracle as ko
+    import membrane_oracle as mo
+    from cpu_precond import aux_space_preconditioner
+    from knpemidg import amg, _abi
+    from knpemidg.mesh import make_mesh_3D
+    m, s, f = make_mesh_3D(resolution)
+    pb = ko.build_idealized(m, s.array(), f.array())
+    nd, ndof = pb.nd, pb.ndof
+    # spawn, not fork: this process has initialised the GPU
+    pool = mp.get_context("spawn").Pool(cores, initializer=_cpu_part_init, initargs=(resolution, cores))
+    try:
+        E = {ion["name"]: ko.nernst(pb, k) for k, ion in enumerate(pb.ions)}
+        models = [mo.MembraneOracle(pb, 1, True, pb.C_M), mo.MembraneOracle(pb, 2, False, pb.C_M)]
+        t0 = time.perf_counter()
+        mo.oracle_membrane_step(pb, E, models, 0, pb.dt, {"stim_amplitude": 10.0}, lambda x: x[0] < 20.0e-6)
+        t_ode = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        cs = amg.ConformingSpace(m, f.array(), (1, 2))
+        lv_emi = amg.build_hierarchy(cs.stiffness(pb.kappa(), membrane=(pb.mem, pb.C_phi)), psmooth=3, level0_degree=0)
+        D_mean = np.mean([ion["D"] for ion in pb.ions[:-1]], axis=0)
+        lv_knp = amg.build_hierarchy(cs.stiffness(D_mean, mass_coef=np.full(m.num_cells(), 1.0 / pb.dt)), psmooth=2, level0_degree=1)
+        t_setup = time.perf_counter() - t0
+        # mesh parts + oracle problems of the workers (setup, like the GPU's); a worker that cannot start must not hang the bench
+        pool.map_async(_cpu_part_warm, range(cores)).get(timeout=600)
+        state = {"phi_M": pb.phi_M, "I_ch": pb.I_ch, "ndof": ndof}
+
+        def assemble(kind, k=0):
+            parts = pool.map_async(_cpu_part_assemble, [(kind, r, k, state) for r in range(cores)]).get(timeout=900)
+            rows = np.concatenate([(cg[:, None] * nd + np.arange(nd)[None, :]).ravel() for _, _, _, cg in parts])
+            A = sp.vstack([A_ for _, A_, _, _ in parts], format="csr")
+            b = np.concatenate([b_ for _, _, b_, _ in parts])
+            perm = np.argsort(rows)                                    # part-major rows -> global row order
+            return A[perm].tocsr(), b[perm]
+
+        def threaded(A):
+            A = A.tocsr()
+            ip, ix, dv = A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data
+            lib = _abi.load()
+
+            def mv(x):
+                x = np.ascontiguousarray(x, dtype=np.float64).ravel()
+                y = np.empty(A.shape[0])
+                lib.knp_host_spmv(A.shape[0], _abi._p(ip, _abi._i32p), _abi._p(ix, _abi._i32p), _abi._p(dv, _abi._f64p), _abi._p(x, _abi._f64p),
+                                  _abi._p(y, _abi._f64p), cores)
+                return y
+            return spla.LinearOperator(A.shape, matvec=mv, dtype=np.float64)
+        t0 = time.perf_counter()
+        A, b = assemble("emi")
+        t_ass_emi = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        M = aux_space_preconditioner(A, nd, cs.dof, lv_emi)
+        it_emi = [0]
+        b = b - b.mean()
+        x, info = spla.cg(threaded(A), b, x0=pb.phi.ravel(), rtol=1e-5, atol=0.0, maxiter=500, M=M,
+                          callback=lambda xk: it_emi.__setitem__(0, it_emi[0] + 1))
+        assert info == 0, "CPU baseline: EMI CG did not converge"
+        pb.phi = x.reshape(-1, nd)
+        t_sol_emi = time.perf_counter() - t0
+        state["phi"] = pb.phi
+        t_ass_knp = t_sol_knp = 0.0
+        it_knp = []
+        out = np.zeros_like(pb.c)
+        for k in range(pb.N_ions):
+            t0 = time.perf_counter()
+            Ak, bk = assemble("knp", k)
+            t_ass_knp += time.perf_counter() - t0
+            t0 = time.perf_counter()
+            Mk = aux_space_preconditioner(Ak, nd, cs.dof, lv_knp)
+            it = [0]
+            xk, info = spla.gmres(threaded(Ak), bk, x0=pb.c[k].ravel(), rtol=1e-7, atol=0.0, restart=30, maxiter=200, M=Mk,
+                                  callback=lambda r: it.__setitem__(0, it[0] + 1), callback_type="pr_norm")
+            assert info == 0, "CPU baseline: KNP GMRES did not converge"
+            out[k] = xk.reshape(-1, nd)
+            it_knp.append(it[0])
+            t_sol_knp += time.perf_counter() - t0
+        pb.c = out
+        t0 = time.perf_counter()
+        ko.update_phi_M(pb); ko.update_c_elim(pb)
+        for k in range(len(pb.ions)):
+            ko.nernst(pb, k)
+        t_upd = time.perf_counter() - t0
+    finally:
+        pool.terminate()
+        pool.join()
+    step = t_ode + t_ass_emi + t_sol_emi + t_ass_knp + t_sol_knp + t_upd
+    dofs = ndof * (1 + pb.N_ions)
+    return {"value": dofs / step, "unit": "DoF/s", "cores": cores, "host_cores": os.cpu_count(), "kind": "port",
+            "assemble_s": t_ass_emi + t_ass_knp, "solve_s": t_sol_emi + t_sol_knp, "ode_s": t_ode, "precond_setup_s": t_setup,
+            "emi_iters": it_emi[0], "knp_iters": it_knp,
+            "sample": "ONE splitting step on the 4-axon mesh r=%d (%d tets, %d P1-DG DoFs), %.1f s: CSR assembly by %d processes, one x-slab "
+                      "each, %.1f s + scipy CG rtol 1e-5 (%d its) / GMRES(30) rtol 1e-7 (%s its) with %d-thread sparse products %.1f s, "
+                      "preconditioned with the product's auxiliary-space AMG hierarchy applied in numpy (its one-off setup, %.1f s, and "
+                      "the workers' start-up are not in the step), membrane ODEs by LSODA %.1f s (one process); %d of the host's %d cores; "
+                      "CPU restatement, not FEniCS"
+                      % (resolution, m.num_cells(), dofs, step, cores, t_ass_emi + t_ass_knp, it_emi[0], it_knp, cores,
+                         t_sol_emi + t_sol_knp, t_setup, t_ode, cores, os.cpu_count() or 0)}
 
 
 def _cpu_baseline_one_core(resolution):

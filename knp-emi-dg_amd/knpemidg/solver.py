@@ -327,21 +327,25 @@ class Solver:
 
     def _emi_smoother_trial(self, seconds, res):
         """Measured choice of the EMI DG-level smoother.  Solve 0 carries one-off work (eigenvalue estimate, graph capture) and is not
-        counted; solves 1 and 3 run with, solves 2 and 4 without the Chebyshev step; each is charged its wall time per decade of
-        TRUE-residual reduction (the norm of the residual target, so that steps of different difficulty compare), the times summed over the
-        ranks of a partitioned run (one all-reduce: every rank takes the same decision and keeps ONE symmetric preconditioner).  The step
-        stays unless dropping it is at least 3 % cheaper.  Nothing else has to change with the choice: both variants meet the same
-        stopping test, which does not depend on the preconditioner (csrc/krylov.hip: cg_converged)."""
+        counted; solves 1 and 4 run with, solves 2 and 3 without the Chebyshev step (the first solves of a run get easier from one to the
+        next: the with / without / without / with order cancels that trend, a plain alternation charged it to the first variant); each is
+        charged its wall time per decade of TRUE-residual reduction (the norm of the residual target, so that steps of different
+        difficulty compare), the times summed over the ranks of a partitioned run (one all-reduce: every rank takes the same decision
+        and keeps ONE symmetric preconditioner).  The step stays unless dropping it is at least 3 % cheaper.  Nothing else has to
+        change with the choice: both variants meet the same stopping test, which does not depend on the preconditioner
+        (csrc/krylov.hip: cg_converged)."""
         tr = self._emi_trial
         k = tr["solve"]
         tr["solve"] += 1
         if 1 <= k <= 4:
             decades = max(np.log10(max(float(res[0]), 1e-300) / max(float(res[1]), 1e-300)), 0.25)
-            tr["cost"][k % 2 == 1].append(seconds / decades)
-        if k in (1, 3):
+            tr["cost"][k in (1, 4)].append(seconds / decades)
+        if k == 1:
             self.dev.set_emi_dg_smoother(False)
-        elif k == 2:
+        elif k == 3:
             self.dev.set_emi_dg_smoother(True)
+        elif k == 2:
+            pass
         elif k == 4:
             on, off = self.dev.allreduce_sum([sum(tr["cost"][True]), sum(tr["cost"][False])])
             keep = not (off < 0.97 * on)

@@ -350,7 +350,7 @@ def test_knp_hierarchy_helper_process_matches_in_process(degree):
 
 def test_emi_dg_smoother_is_chosen_by_measurement():
     """knpemidg/solver.py: Solver._emi_dg_chebyshev / _emi_smoother_trial -- round 3 read the DG-level smoother of the EMI preconditioner
-    off mesh-size thresholds; round 4 measures it: solve 0 is not counted, solves 1 / 3 run with and 2 / 4 without the Chebyshev step,
+    off mesh-size thresholds; round 4 measures it: solve 0 is not counted, solves 1 / 4 run with and 2 / 3 without the Chebyshev step,
     each charged its time per decade of true-residual reduction, the sums all-reduced (every rank of a partitioned run takes the same
     decision), the step dropped only if that is >= 3 % cheaper; solver_params / KNP_EMI_CHEB decide explicitly when they say so."""
     from collections import namedtuple
@@ -378,7 +378,7 @@ def test_emi_dg_smoother_is_chosen_by_measurement():
         if S._emi_trial is None:
             return first, S.dev.calls, None
         # (seconds, [r0, r1]) of solves 0..4: one decade of reduction each, so seconds = cost per decade
-        seq = [(9.9, [1.0, 0.1]), (costs_on[0], [1.0, 0.1]), (costs_off[0], [1.0, 0.1]), (costs_on[1], [1.0, 0.1]), (costs_off[1], [1.0, 0.1])]
+        seq = [(9.9, [1.0, 0.1]), (costs_on[0], [1.0, 0.1]), (costs_off[0], [1.0, 0.1]), (costs_off[1], [1.0, 0.1]), (costs_on[1], [1.0, 0.1])]
         for sec, res in seq:
             assert S._emi_trial is not None
             S._emi_smoother_trial(sec, res)
@@ -386,7 +386,7 @@ def test_emi_dg_smoother_is_chosen_by_measurement():
         return first, S.dev.calls, S.emi_dg_chebyshev_measured
 
     first, calls, m = run((1.0, 1.0), (0.8, 0.8))            # plain block-Jacobi 20 % cheaper per decade: dropped
-    assert first is True and calls == [False, True, False, False] and m["chosen"] is False
+    assert first is True and calls == [False, True, False] and m["chosen"] is False
     first, calls, m = run((1.0, 1.0), (0.99, 0.99))          # within the 3 % margin: the step stays
     assert calls[-1] is True and m["chosen"] is True
     first, calls, m = run((1.0, 1.0), (1.3, 1.2))

@@ -38,8 +38,8 @@ suffix = sys.argv[4] if len(sys.argv) > 4 else ""
 path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
 pmc = json.load(open(path))
 for raw, (key, src) in KERNELS.items():
-    f = next((v["FETCH_SIZE"] for k, v in fetch.items() if k.startswith(raw) and "FETCH_SIZE" in v), None)
-    w = next((v["WRITE_SIZE"] for k, v in write.items() if k.startswith(raw) and "WRITE_SIZE" in v), None)
+    f = next((v["FETCH_SIZE"] for k, v in fetch.items() if k == raw and "FETCH_SIZE" in v), None)
+    w = next((v["WRITE_SIZE"] for k, v in write.items() if k == raw and "WRITE_SIZE" in v), None)
     if f is None or w is None:
         continue
     with open(os.path.join(ROOT, "knp-emi-dg_amd", "csrc", src), "rb") as fh:
