@@ -265,6 +265,25 @@ int knp_host_spgemm(int64_t n, int64_t m, const int32_t* Ap, const int32_t* Aj, 
                     const double* Bx, int32_t* Cp, int32_t** Cj, double** Cx, int nthreads);
 int knp_host_spmv(int64_t n, const int32_t* Ap, const int32_t* Aj, const double* Ax, const double* x, double* y, int nthreads);
 void knp_host_free(void* p);
+/* Setup kernels of the conforming auxiliary operators (knpemidg/amg.py; the reference assembles BB_emi / AA_knp with dolfin.assemble at
+ * every solve, src/knpemidg/solver.py:477-479, 730-731, and hands them to BoomerAMG):
+ *  knp_host_cell_gram   : vol[nc], G[nc][(dim+1)^2] = grad lambda_a . grad lambda_b of every simplex cell from vertex coordinates
+ *  knp_host_segment_sum : out[p] = sum_{k in [starts[p], starts[p+1])} src[order[k]] -- per-cell blocks summed into the values of a CSR
+ *                         matrix whose pattern (sort order of the entry keys) is cached */
+int knp_host_cell_gram(int64_t nc, int dim, const double* coords, const int32_t* cells, double* vol, double* G, int nthreads);
+int knp_host_segment_sum(int64_t nseg, const int64_t* starts, const int64_t* order, const double* src, double* out, int nthreads);
+/*  knp_host_block_pattern: the cached pattern itself -- entry (c, a, b) of blocks [nc][nd][nd] lands in (dof[c][a], dof[c][b]) of an
+ *                         n x n matrix; order[nc nd nd], starts[<= nc nd nd + 1], cols[<= nc nd nd], indptr[n + 1] as a stable sort of the
+ *                         entry keys would give them; *nseg = number of distinct (row, column) pairs */
+/* Mesh tables on the host (knpemidg/mesh.py, knpemidg/_abi.py; the reference gets them from DOLFIN's mesh topology, solver.py:85-121):
+ *  knp_host_build_facets     : facet numbering by first appearance in (cell, local facet) order + the facet -> cells / local index tables
+ *  knp_host_geometry_classes : classes of cells with the same shape and neighbour configuration (structured meshes) */
+int64_t knp_host_build_facets(int64_t nc, int nv, const int32_t* cells, int32_t* cell_facets, int32_t* facets, int32_t* facet_cells,
+                              int8_t* facet_local);
+int64_t knp_host_geometry_classes(int64_t nc, const double* coords, const int32_t* cells, const int32_t* nbr, const int8_t* nbj, double quantum,
+                                  int64_t max_classes, int32_t* cls, int64_t* first, int nthreads);
+int knp_host_block_pattern(int64_t nc, int nd, int64_t n, const int32_t* dof, int64_t* order, int64_t* starts, int32_t* cols, int32_t* indptr,
+                           int64_t* nseg, int nthreads);
 
 /* ---- timing / sync ------------------------------------------------------------------------------ */
 int knp_sync(knp_ctx* ctx);

@@ -7,7 +7,9 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <cmath>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 namespace {
@@ -102,4 +104,255 @@ int knp_host_spmv(int64_t n, const int32_t* Ap, const int32_t* Aj, const double*
     return 0;
 }
 
+
+// Gram-form geometry of every simplex cell (the host setup's copy of csrc/cell_geom.hpp): vol[c] and G[c][a][b] = grad lambda_a . grad
+// lambda_b, from vertex coordinates.  Replaces a batched numpy inverse + determinant + einsum over the cells (0.6 s at 10^6 tets).
+int knp_host_cell_gram(int64_t nc, int dim, const double* coords, const int32_t* cells, double* vol, double* G, int nthreads) {
+    if (!coords || !cells || !vol || !G || (dim != 2 && dim != 3) || nc < 0) return -1;
+    if (nthreads <= 0) nthreads = (int)std::max(1u, std::thread::hardware_concurrency());
+    const int nv = dim + 1;
+    parallel_rows(nc, nthreads, [&](int64_t lo, int64_t hi, int) {
+        for (int64_t c = lo; c < hi; ++c) {
+            const int32_t* cv = cells + c * nv;
+            double g[4][3] = {{0.0}};
+            double det;
+            const double* X0 = coords + (int64_t)cv[0] * dim;
+            if (dim == 3) {
+                double e[3][3];
+                for (int a = 0; a < 3; ++a)
+                    for (int k = 0; k < 3; ++k) e[a][k] = coords[(int64_t)cv[a + 1] * 3 + k] - X0[k];
+                const double c23[3] = {e[1][1] * e[2][2] - e[1][2] * e[2][1], e[1][2] * e[2][0] - e[1][0] * e[2][2], e[1][0] * e[2][1] - e[1][1] * e[2][0]};
+                const double c31[3] = {e[2][1] * e[0][2] - e[2][2] * e[0][1], e[2][2] * e[0][0] - e[2][0] * e[0][2], e[2][0] * e[0][1] - e[2][1] * e[0][0]};
+                const double c12[3] = {e[0][1] * e[1][2] - e[0][2] * e[1][1], e[0][2] * e[1][0] - e[0][0] * e[1][2], e[0][0] * e[1][1] - e[0][1] * e[1][0]};
+                det = e[0][0] * c23[0] + e[0][1] * c23[1] + e[0][2] * c23[2];
+                const double inv = 1.0 / det;
+                for (int k = 0; k < 3; ++k) {
+                    g[1][k] = c23[k] * inv; g[2][k] = c31[k] * inv; g[3][k] = c12[k] * inv;
+                    g[0][k] = -(g[1][k] + g[2][k] + g[3][k]);
+                }
+                vol[c] = std::abs(det) / 6.0;
+            } else {
+                const double e1[2] = {coords[(int64_t)cv[1] * 2] - X0[0], coords[(int64_t)cv[1] * 2 + 1] - X0[1]};
+                const double e2[2] = {coords[(int64_t)cv[2] * 2] - X0[0], coords[(int64_t)cv[2] * 2 + 1] - X0[1]};
+                det = e1[0] * e2[1] - e1[1] * e2[0];
+                const double inv = 1.0 / det;
+                g[1][0] = e2[1] * inv; g[1][1] = -e2[0] * inv;
+                g[2][0] = -e1[1] * inv; g[2][1] = e1[0] * inv;
+                g[0][0] = -(g[1][0] + g[2][0]); g[0][1] = -(g[1][1] + g[2][1]);
+                vol[c] = std::abs(det) / 2.0;
+            }
+            double* Gc = G + c * nv * nv;
+            for (int a = 0; a < nv; ++a)
+                for (int b = 0; b < nv; ++b) {
+                    double v = 0.0;
+                    for (int k = 0; k < dim; ++k) v += g[a][k] * g[b][k];
+                    Gc[a * nv + b] = v;
+                }
+        }
+    });
+    return 0;
+}
+
+// out[p] = sum of src[order[k]] over k in [starts[p], starts[p + 1])  (starts has nseg + 1 entries): the scatter-add of per-cell blocks
+// into the values of a CSR matrix whose pattern (sort order of the entry keys) is known -- numpy's gather + add.reduceat, threaded.
+// Summation order inside a segment = ascending k, as in the numpy version.
+int knp_host_segment_sum(int64_t nseg, const int64_t* starts, const int64_t* order, const double* src, double* out, int nthreads) {
+    if (!starts || !order || !src || !out || nseg < 0) return -1;
+    if (nthreads <= 0) nthreads = (int)std::max(1u, std::thread::hardware_concurrency());
+    parallel_rows(nseg, nthreads, [&](int64_t lo, int64_t hi, int) {
+        for (int64_t p = lo; p < hi; ++p) {
+            double acc = 0.0;
+            for (int64_t k = starts[p]; k < starts[p + 1]; ++k) acc += src[order[k]];
+            out[p] = acc;
+        }
+    });
+    return 0;
+}
+
+// CSR pattern of a matrix assembled from per-cell dense blocks scattered through a dof map: entry e = (c, a, b) of blocks [nc][nd][nd]
+// lands in row dof[c][a], column dof[c][b].  Returns what numpy's stable argsort of the keys (row * n + col) gives -- order[] (entries
+// grouped by (row, col), ties in ascending e), starts[] (first position of every distinct key; nseg + 1 entries), cols[] / indptr[] of the
+// CSR matrix -- by a stable counting sort over the rows and a stable sort by column inside each row, threaded over the rows
+// (numpy's argsort of 16 M int64 keys was the largest single item of a first assembly: 0.3 s).
+int knp_host_block_pattern(int64_t nc, int nd, int64_t n, const int32_t* dof, int64_t* order, int64_t* starts, int32_t* cols, int32_t* indptr,
+                           int64_t* nseg_out, int nthreads) {
+    if (!dof || !order || !starts || !cols || !indptr || !nseg_out || nc < 0 || nd < 1 || n < 0) return -1;
+    if (nthreads <= 0) nthreads = (int)std::max(1u, std::thread::hardware_concurrency());
+    const int64_t nent = nc * nd * nd;
+    for (int64_t i = 0; i < nc * nd; ++i)
+        if (dof[i] < 0 || dof[i] >= n) return -1;
+    // stable counting sort over the rows, threaded: thread t owns a contiguous range of cells and its own histogram; its entries of row r
+    // go behind those of the threads before it, so every row lists its entries in ascending e
+    const int T = (int)std::max<int64_t>(1, std::min<int64_t>(nthreads, nc / 65536 + 1));
+    const int64_t cchunk = (nc + T - 1) / T;
+    std::vector<std::vector<int32_t>> hist((size_t)T, std::vector<int32_t>((size_t)n, 0));
+    {
+        std::vector<std::thread> pool;
+        for (int t = 0; t < T; ++t)
+            pool.emplace_back([&, t]() {
+                std::vector<int32_t>& h = hist[(size_t)t];
+                for (int64_t i = t * cchunk * nd; i < std::min(nc, (t + 1) * cchunk) * nd; ++i) h[(size_t)dof[i]] += nd;
+            });
+        for (auto& th : pool) th.join();
+    }
+    std::vector<int64_t> rowptr((size_t)n + 1, 0);
+    std::vector<std::vector<int64_t>> base((size_t)T, std::vector<int64_t>((size_t)n, 0));
+    for (int64_t r = 0; r < n; ++r) {
+        int64_t acc = rowptr[(size_t)r];
+        for (int t = 0; t < T; ++t) { base[(size_t)t][(size_t)r] = acc; acc += hist[(size_t)t][(size_t)r]; }
+        rowptr[(size_t)r + 1] = acc;
+    }
+    {
+        std::vector<std::thread> pool;
+        for (int t = 0; t < T; ++t)
+            pool.emplace_back([&, t]() {
+                std::vector<int64_t>& f = base[(size_t)t];
+                for (int64_t c = t * cchunk; c < std::min(nc, (t + 1) * cchunk); ++c)
+                    for (int a = 0; a < nd; ++a) {
+                        int64_t& q = f[(size_t)dof[c * nd + a]];
+                        for (int b = 0; b < nd; ++b) order[q++] = (c * nd + a) * nd + b;
+                    }
+            });
+        for (auto& th : pool) th.join();
+    }
+    // per row: stable sort by column, count the distinct columns
+    std::vector<int32_t> rowcnt((size_t)n, 0);
+    auto col_of = [&](int64_t e) { return dof[(e / ((int64_t)nd * nd)) * nd + (e % nd)]; };
+    parallel_rows(n, nthreads, [&](int64_t lo, int64_t hi, int) {
+        for (int64_t r = lo; r < hi; ++r) {
+            int64_t* b = order + rowptr[(size_t)r];
+            int64_t* e = order + rowptr[(size_t)r + 1];
+            std::stable_sort(b, e, [&](int64_t x, int64_t y) { return col_of(x) < col_of(y); });
+            int32_t cnt = 0, last = -1;
+            for (int64_t* p = b; p < e; ++p) { const int32_t cj = col_of(*p); if (p == b || cj != last) { ++cnt; last = cj; } }
+            rowcnt[(size_t)r] = cnt;
+        }
+    });
+    int64_t nseg = 0;
+    for (int64_t r = 0; r < n; ++r) {
+        if (nseg > 2147483647LL) return -3;
+        indptr[r] = (int32_t)nseg;
+        nseg += rowcnt[(size_t)r];
+    }
+    if (nseg > 2147483647LL) return -3;
+    indptr[n] = (int32_t)nseg;
+    parallel_rows(n, nthreads, [&](int64_t lo, int64_t hi, int) {
+        for (int64_t r = lo; r < hi; ++r) {
+            int64_t q = indptr[r];
+            int32_t last = -1;
+            for (int64_t p = rowptr[(size_t)r]; p < rowptr[(size_t)r + 1]; ++p) {
+                const int32_t cj = col_of(order[p]);
+                if (p == rowptr[(size_t)r] || cj != last) { starts[q] = p; cols[q] = cj; ++q; last = cj; }
+            }
+        }
+    });
+    starts[nseg] = nent;
+    *nseg_out = nseg;
+    return 0;
+}
+
+// Facet table of a simplicial mesh (knpemidg/mesh.py: Mesh._build_facets): facets are numbered by first appearance in (cell, local facet)
+// order, local facet i is the one opposite local vertex i, its vertices are the cell's other vertices in the cell's (ascending) order.
+//   cell_facets[nc][nv], facets[<= nc nv][d], facet_cells[..][2] (side 0 = the lower cell, -1 on the boundary), facet_local[..][2]
+// Returns the number of facets, or -1 (bad input) / -2 (a facet shared by more than two cells).
+int64_t knp_host_build_facets(int64_t nc, int nv, const int32_t* cells, int32_t* cell_facets, int32_t* facets, int32_t* facet_cells,
+                              int8_t* facet_local) {
+    if (!cells || !cell_facets || !facets || !facet_cells || !facet_local || nc < 0 || (nv != 3 && nv != 4)) return -1;
+    const int d = nv - 1;
+    struct Key { int32_t v[3]; bool operator==(const Key& o) const { return v[0] == o.v[0] && v[1] == o.v[1] && v[2] == o.v[2]; } };
+    struct Hash { size_t operator()(const Key& k) const {
+        uint64_t h = (uint64_t)(uint32_t)k.v[0] * 0x9E3779B97F4A7C15ull;
+        h ^= ((uint64_t)(uint32_t)k.v[1] + 0x7F4A7C15ull) * 0xC2B2AE3D27D4EB4Full + (h << 6) + (h >> 2);
+        h ^= ((uint64_t)(uint32_t)k.v[2] + 0x165667B1ull) * 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2);
+        return (size_t)h; } };
+    std::unordered_map<Key, int32_t, Hash> ids;
+    ids.reserve((size_t)(nc * nv * 0.6) + 16);
+    int64_t nf = 0;
+    for (int64_t c = 0; c < nc; ++c)
+        for (int i = 0; i < nv; ++i) {
+            Key k{{-1, -1, -1}};
+            int q = 0;
+            for (int a = 0; a < nv; ++a)
+                if (a != i) k.v[q++] = cells[c * nv + a];
+            auto it = ids.find(k);
+            int32_t f;
+            if (it == ids.end()) {
+                f = (int32_t)nf++;
+                ids.emplace(k, f);
+                for (int a = 0; a < d; ++a) facets[(int64_t)f * d + a] = k.v[a];
+                facet_cells[2 * (int64_t)f] = (int32_t)c; facet_cells[2 * (int64_t)f + 1] = -1;
+                facet_local[2 * (int64_t)f] = (int8_t)i; facet_local[2 * (int64_t)f + 1] = -1;
+            } else {
+                f = it->second;
+                if (facet_cells[2 * (int64_t)f + 1] >= 0) return -2;
+                facet_cells[2 * (int64_t)f + 1] = (int32_t)c;
+                facet_local[2 * (int64_t)f + 1] = (int8_t)i;
+            }
+            cell_facets[c * nv + i] = f;
+        }
+    return nf;
+}
+
+// Geometry classes of a 3D mesh (knpemidg/_abi.py: geometry_classes): cells whose own shape, neighbour-apex positions and diameters
+// coincide to `quantum` (an absolute length: tol x median diameter) share a class.  feat = 26 quantised numbers per cell (9 edge-vector
+// components, 12 apex offsets, own diameter, four neighbour diameters), hashed; classes are numbered by first appearance and every
+// member is compared with its class representative number by number (a hash collision returns -4).
+//   nbr[nc][4] neighbour cell or -1, nbj[nc][4] its local facet; cls[nc] out, first[max_classes] out (representative cell of each class)
+// Returns the class count, or -3 when there are more than max_classes.
+int64_t knp_host_geometry_classes(int64_t nc, const double* coords, const int32_t* cells, const int32_t* nbr, const int8_t* nbj, double quantum,
+                                  int64_t max_classes, int32_t* cls, int64_t* first, int nthreads) {
+    if (!coords || !cells || !nbr || !nbj || !cls || !first || nc < 0 || !(quantum > 0.0)) return -1;
+    if (nthreads <= 0) nthreads = (int)std::max(1u, std::thread::hardware_concurrency());
+    constexpr int NF = 26;
+    std::vector<double> h((size_t)nc);
+    parallel_rows(nc, nthreads, [&](int64_t lo, int64_t hi, int) {
+        for (int64_t c = lo; c < hi; ++c) {
+            double h2 = 0.0;
+            for (int a = 0; a < 4; ++a)
+                for (int b = a + 1; b < 4; ++b) {
+                    double d2 = 0.0;
+                    for (int k = 0; k < 3; ++k) { const double d = coords[(int64_t)cells[c * 4 + a] * 3 + k] - coords[(int64_t)cells[c * 4 + b] * 3 + k]; d2 += d * d; }
+                    h2 = std::max(h2, d2);
+                }
+            h[(size_t)c] = std::sqrt(h2);
+        }
+    });
+    std::vector<int64_t> feat((size_t)nc * NF);
+    std::vector<uint64_t> hash((size_t)nc);
+    const double inv = 1.0 / quantum;
+    parallel_rows(nc, nthreads, [&](int64_t lo, int64_t hi, int) {
+        for (int64_t c = lo; c < hi; ++c) {
+            int64_t* q = feat.data() + c * NF;
+            const double* X0 = coords + (int64_t)cells[c * 4] * 3;
+            int n = 0;
+            for (int a = 1; a < 4; ++a)
+                for (int k = 0; k < 3; ++k) q[n++] = (int64_t)std::nearbyint((coords[(int64_t)cells[c * 4 + a] * 3 + k] - X0[k]) * inv);
+            for (int i = 0; i < 4; ++i) {
+                const int32_t nb = nbr[c * 4 + i];
+                for (int k = 0; k < 3; ++k)
+                    q[n++] = nb >= 0 ? (int64_t)std::nearbyint((coords[(int64_t)cells[(int64_t)nb * 4 + nbj[c * 4 + i]] * 3 + k] - X0[k]) * inv) : 0;
+            }
+            q[n++] = (int64_t)std::nearbyint(h[(size_t)c] * inv);
+            for (int i = 0; i < 4; ++i) q[n++] = nbr[c * 4 + i] >= 0 ? (int64_t)std::nearbyint(h[(size_t)nbr[c * 4 + i]] * inv) : 0;
+            uint64_t hv = 0xcbf29ce484222325ull;
+            for (int k = 0; k < NF; ++k) { hv ^= (uint64_t)q[k] + 0x9E3779B97F4A7C15ull + (hv << 6) + (hv >> 2); hv *= 0x100000001b3ull; }
+            hash[(size_t)c] = hv;
+        }
+    });
+    std::unordered_map<uint64_t, int32_t> ids;
+    int64_t ncls = 0;
+    for (int64_t c = 0; c < nc; ++c) {
+        auto it = ids.find(hash[(size_t)c]);
+        if (it == ids.end()) {
+            if (ncls >= max_classes) return -3;
+            ids.emplace(hash[(size_t)c], (int32_t)ncls);
+            first[ncls] = c;
+            cls[c] = (int32_t)ncls++;
+        } else {
+            cls[c] = it->second;
+            if (std::memcmp(feat.data() + c * NF, feat.data() + first[it->second] * NF, sizeof(int64_t) * NF) != 0) return -4;
+        }
+    }
+    return ncls;
+}
 }  // extern "C"

@@ -71,6 +71,11 @@ SIGNATURES = {
                                   C.POINTER(_f64p), C.c_int]),
     "knp_host_spmv": (C.c_int, [C.c_int64, _i32p, _i32p, _f64p, _f64p, _f64p, C.c_int]),
     "knp_host_free": (None, [C.c_void_p]),
+    "knp_host_cell_gram": (C.c_int, [C.c_int64, C.c_int, _f64p, _i32p, _f64p, _f64p, C.c_int]),
+    "knp_host_segment_sum": (C.c_int, [C.c_int64, _i64p, _i64p, _f64p, _f64p, C.c_int]),
+    "knp_host_build_facets": (C.c_int64, [C.c_int64, C.c_int, _i32p, _i32p, _i32p, _i32p, _i8p]),
+    "knp_host_geometry_classes": (C.c_int64, [C.c_int64, _f64p, _i32p, _i32p, _i8p, C.c_double, C.c_int64, _i32p, _i64p, C.c_int]),
+    "knp_host_block_pattern": (C.c_int, [C.c_int64, C.c_int, C.c_int64, _i32p, _i64p, _i64p, _i32p, _i32p, _i64p, C.c_int]),
     "knp_comm_unique_id": (C.c_int, [C.c_char_p]),
     "knp_comm_init": (C.c_int, [_ctxp, C.c_int, C.c_int, C.c_char_p]),
     "knp_comm_init_halo": (C.c_int, [_ctxp, C.c_char_p]),
@@ -187,6 +192,9 @@ def geometry_classes(mesh, order, max_classes=4096, tol=1.0e-9):
     side = (fc[cf, 0] != np.arange(nc)[:, None]).astype(np.int64)          # which side of the facet this cell is
     nb = np.take_along_axis(fc[cf], (1 - side)[:, :, None], axis=2)[:, :, 0]     # neighbour cell or -1
     nj = np.take_along_axis(fl[cf], (1 - side)[:, :, None], axis=2)[:, :, 0]     # neighbour's local facet
+    native = _geometry_classes_native(mesh, order, nb, nj, max_classes, tol) if nc >= 20000 else None
+    if native is not None:
+        return native if native != "unstructured" else None
     X = mesh.coords[mesh.cells]                             # [nc, 4, 3]
     X0 = X[:, 0]
     has = nb >= 0
@@ -235,6 +243,69 @@ def geometry_classes(mesh, order, max_classes=4096, tol=1.0e-9):
         table[:, 11 + 6 * i + 4] = np.sqrt(G[:, i, i])
         table[:, 11 + 6 * i + 5] = np.where(hasr[:, i], 2.0 / (h[first] + np.where(hasr[:, i], hN[first, i], 1.0)), 0.0)
     return np.ascontiguousarray(inv[order].astype(np.uint16)), np.ascontiguousarray(table)
+
+
+def _class_table(mesh, first, nb, nj):
+    """Geometry records [ncls, 36] of the class representatives `first` (layout: include/knpemi_hip.h, knp_set_geometry_classes)."""
+    ncls = len(first)
+    X = mesh.coords[mesh.cells[first]]
+    nbf, njf = nb[first], nj[first]
+    has = nbf >= 0
+    apex = np.where(has[:, :, None], mesh.coords[mesh.cells[np.maximum(nbf, 0), np.maximum(njf, 0)]] - X[:, :1, :], 0.0)
+
+    def diam(Xc):
+        e = Xc[:, :, None, :] - Xc[:, None, :, :]
+        return np.sqrt((e ** 2).sum(axis=3).max(axis=(1, 2)))
+    h = diam(X)
+    hN = np.where(has, diam(mesh.coords[mesh.cells[np.maximum(nbf, 0).ravel()]]).reshape(ncls, 4), 0.0)
+    J = (X[:, 1:, :] - X[:, :1, :]).transpose(0, 2, 1)
+    Jinv = np.linalg.inv(J)
+    g = np.empty((ncls, 4, 3))
+    g[:, 1:, :] = Jinv
+    g[:, 0, :] = -Jinv.sum(axis=1)
+    G = np.einsum("cad,cbd->cab", g, g)
+    table = np.zeros((ncls, 36))
+    table[:, 0] = np.abs(np.linalg.det(J)) / 6.0
+    k = 1
+    for a in range(4):
+        for b in range(a, 4):
+            table[:, k] = G[:, a, b]
+            k += 1
+    L = np.einsum("cad,cid->cia", g, apex)
+    L[:, :, 0] += 1.0
+    for i in range(4):
+        table[:, 11 + 6 * i:11 + 6 * i + 4] = np.where(has[:, i:i + 1], L[:, i, :], 0.0)
+        table[:, 11 + 6 * i + 4] = np.sqrt(G[:, i, i])
+        table[:, 11 + 6 * i + 5] = np.where(has[:, i], 2.0 / (h + np.where(has[:, i], hN[:, i], 1.0)), 0.0)
+    return table
+
+
+def _geometry_classes_native(mesh, order, nb, nj, max_classes, tol):
+    """geometry_classes through the library's threaded hash grouping (csrc/host_sparse.cpp: knp_host_geometry_classes): the same
+    26 quantised features per cell, classes numbered by first appearance.  None: library not available (numpy path)."""
+    try:
+        lib = load()
+    except Exception:
+        return None
+    nc = mesh.cells.shape[0]
+    X = mesh.coords[mesh.cells[::max(1, nc // 4096)]]
+    e = X[:, :, None, :] - X[:, None, :, :]
+    hmed = float(np.median(np.sqrt((e ** 2).sum(axis=3).max(axis=(1, 2)))))          # scale of the tolerance (a sample of the cells)
+    coords = np.ascontiguousarray(mesh.coords, dtype=np.float64)
+    cells = np.ascontiguousarray(mesh.cells, dtype=np.int32)
+    nb32 = np.ascontiguousarray(nb, dtype=np.int32)
+    nj8 = np.ascontiguousarray(nj, dtype=np.int8)
+    limit = int(min(max_classes, max(64, nc // 8)))
+    cls = np.empty(nc, dtype=np.int32)
+    first = np.empty(limit, dtype=np.int64)
+    n = int(lib.knp_host_geometry_classes(nc, _p(coords, _f64p), _p(cells, _i32p), _p(nb32, _i32p), _p(nj8, _i8p), hmed * tol, limit,
+                                          _p(cls, _i32p), _p(first, _i64p), 0))
+    if n == -3 or n == -4:
+        return "unstructured"
+    if n < 0:
+        return None
+    first = first[:n]
+    return np.ascontiguousarray(cls[order].astype(np.uint16)), np.ascontiguousarray(_class_table(mesh, first, nb, nj))
 
 
 class Device:

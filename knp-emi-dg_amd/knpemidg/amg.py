@@ -27,6 +27,18 @@ import scipy.sparse.csgraph as csg
 def _cell_gram(space):
     """(vol [nc], G [nc, nv, nv] = grad lambda_a . grad lambda_b) of every cell, computed once per space."""
     geo = getattr(space, "_gram", None)
+    if geo is None and space.mesh.cells.shape[0] >= 20000:
+        # threaded closed form in the library (csrc/host_sparse.cpp) instead of batched numpy inverses: 0.6 s -> 0.03 s at 10^6 tets
+        from knpemidg import _abi
+        mesh = space.mesh
+        nc, nv = mesh.cells.shape
+        coords = np.ascontiguousarray(mesh.coords, dtype=np.float64)
+        cells = np.ascontiguousarray(mesh.cells, dtype=np.int32)
+        vol, G = np.empty(nc), np.empty((nc, nv, nv))
+        rc = _abi.load().knp_host_cell_gram(nc, mesh.gdim, _abi._p(coords, _abi._f64p), _abi._p(cells, _abi._i32p), _abi._p(vol, _abi._f64p),
+                                            _abi._p(G, _abi._f64p), _setup_threads())
+        if rc == 0:
+            geo = space._gram = (vol, G)
     if geo is None:
         mesh = space.mesh
         d = mesh.gdim
@@ -49,6 +61,22 @@ def _assemble_cached(space, blk, nd):
     lock = space.__dict__.setdefault("_pattern_lock", threading.Lock())
     with lock:
         pat = getattr(space, "_pattern", None)
+        if pat is None and space.dof.size * nd >= 200000:
+            # threaded counting sort in the library instead of numpy's argsort of nc nd^2 int64 keys (same order: stable)
+            from knpemidg import _abi
+            dof32 = np.ascontiguousarray(space.dof, dtype=np.int32)
+            nc_, nent = dof32.shape[0], dof32.shape[0] * nd * nd
+            order = np.empty(nent, dtype=np.int64)
+            starts = np.empty(nent + 1, dtype=np.int64)
+            cols = np.empty(nent, dtype=np.int32)
+            indptr = np.empty(space.n + 1, dtype=np.int32)
+            nseg = np.zeros(1, dtype=np.int64)
+            rc = _abi.load().knp_host_block_pattern(nc_, nd, space.n, _abi._p(dof32, _abi._i32p), _abi._p(order, _abi._i64p),
+                                                    _abi._p(starts, _abi._i64p), _abi._p(cols, _abi._i32p), _abi._p(indptr, _abi._i32p),
+                                                    _abi._p(nseg, _abi._i64p), _setup_threads())
+            if rc == 0:
+                ns = int(nseg[0])
+                pat = space._pattern = (order, starts[:ns].copy(), cols[:ns].copy(), indptr)
         if pat is None:
             dof = space.dof.astype(np.int64)
             key = (np.repeat(dof[:, :, None], nd, axis=2) * space.n + np.repeat(dof[:, None, :], nd, axis=1)).ravel()
@@ -61,7 +89,20 @@ def _assemble_cached(space, blk, nd):
             indptr = np.concatenate([[0], np.cumsum(np.bincount(rows, minlength=space.n))]).astype(np.int32)
             pat = space._pattern = (order, starts, (uk % space.n).astype(np.int32), indptr)
     order, starts, indices, indptr = pat
-    data = np.add.reduceat(blk.ravel()[order], starts)
+    src = np.ascontiguousarray(blk, dtype=np.float64).ravel()
+    if len(order) >= 200000:
+        from knpemidg import _abi
+        st = getattr(space, "_pattern_starts64", None)
+        if st is None:
+            st = space._pattern_starts64 = (np.ascontiguousarray(np.concatenate([starts, [len(order)]]), dtype=np.int64),
+                                            np.ascontiguousarray(order, dtype=np.int64))
+        data = np.empty(len(starts))
+        rc = _abi.load().knp_host_segment_sum(len(starts), _abi._p(st[0], _abi._i64p), _abi._p(st[1], _abi._i64p), _abi._p(src, _abi._f64p),
+                                              _abi._p(data, _abi._f64p), _setup_threads())
+        if rc != 0:
+            data = np.add.reduceat(src[order], starts)
+    else:
+        data = np.add.reduceat(src[order], starts)
     A = sp.csr_matrix((data, indices, indptr), shape=(space.n, space.n))
     A.has_sorted_indices = True
     return A
@@ -79,9 +120,18 @@ class ConformingSpace:
         g = sp.coo_matrix((np.ones(int(ordinary.sum())), (fc[ordinary, 0], fc[ordinary, 1])), shape=(nc, nc))
         ncomp, comp = csg.connected_components(g, directed=False)
         key = mesh.cells.astype(np.int64) * ncomp + comp[:, None]
-        uniq, inv = np.unique(key.ravel(), return_inverse=True)
-        self.n = len(uniq)
-        self.dof = inv.reshape(nc, -1).astype(np.int32)            # [nc, nd] conforming dof of each DG dof
+        nkeys = int(mesh.coords.shape[0]) * int(ncomp)
+        if nkeys <= 8 * key.size:
+            # (vertex, component) pairs in use, numbered in ascending key order = what np.unique returns, without its sort of 4 nc keys
+            used = np.zeros(nkeys, dtype=bool)
+            used[key.ravel()] = True
+            ids = np.cumsum(used, dtype=np.int64) - 1
+            self.n = int(ids[-1]) + 1 if nkeys else 0
+            self.dof = ids[key].astype(np.int32)                   # [nc, nd] conforming dof of each DG dof
+        else:
+            uniq, inv = np.unique(key.ravel(), return_inverse=True)
+            self.n = len(uniq)
+            self.dof = inv.reshape(nc, -1).astype(np.int32)
         self.mesh = mesh
         self.ncomp = ncomp
 
@@ -386,11 +436,38 @@ def mis2_aggregate(S, seed=0):
     return agg, int(agg.max()) + 1
 
 
+def _threaded_matvec(A):
+    """x -> A x through the library's threaded CSR product (csrc/host_sparse.cpp) for the large levels, scipy's for the small ones."""
+    if A.shape[0] < 50000:
+        return lambda x: A @ x
+    from knpemidg import _abi
+    A = A.tocsr()
+    ip, ix, dv = A.indptr.astype(np.int32), A.indices.astype(np.int32), np.ascontiguousarray(A.data, dtype=np.float64)
+    lib = _abi.load()
+    nthreads = _setup_threads()
+
+    def mv(x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        y = np.empty(A.shape[0])
+        lib.knp_host_spmv(A.shape[0], _abi._p(ip, _abi._i32p), _abi._p(ix, _abi._i32p), _abi._p(dv, _abi._f64p), _abi._p(x, _abi._f64p),
+                          _abi._p(y, _abi._f64p), nthreads)
+        return y
+    return mv
+
+
+def _setup_threads():
+    """Threads of the host setup kernels: the cores this process may use, at most 16 (KNP_SETUP_THREADS overrides)."""
+    import os
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    return int(os.environ.get("KNP_SETUP_THREADS", max(1, min(16, avail))))
+
+
 def _spectral_radius_DinvA(A, dinv, iters=15, seed=1):
     x = np.random.default_rng(seed).standard_normal(A.shape[0])
     lam = 1.0
+    mv = _threaded_matvec(A)
     for _ in range(iters):
-        y = dinv * (A @ x)
+        y = dinv * mv(x)
         lam = np.linalg.norm(y) / max(np.linalg.norm(x), 1e-300)
         x = y / max(np.linalg.norm(y), 1e-300)
     return 1.1 * lam
@@ -533,16 +610,36 @@ def _coarse_pseudo_inverse(A, Bnull):
     s = float(np.trace(Ad)) / max(N, 1)
     rayleigh = float(nvec @ (Ad @ nvec))
     Pi = None
+
+    def spd_inverse(M):
+        """LAPACK potrf + potri on the lower triangle (no identity right-hand side, half the flops of a triangular solve with it)."""
+        L, info = sla.lapack.dpotrf(M, lower=1, overwrite_a=1, clean=0)
+        if info != 0:
+            raise np.linalg.LinAlgError("potrf")
+        Mi, info = sla.lapack.dpotri(L, lower=1, overwrite_c=1)
+        if info != 0:
+            raise np.linalg.LinAlgError("potri")
+        Mi = np.tril(Mi)                                           # potri leaves the other triangle untouched: mirror the lower one
+        Mi = Mi + Mi.T
+        Mi[np.diag_indices(N)] *= 0.5
+        return Mi
     try:
-        if rayleigh < 1e-7 * s:                                   # (near-)singular along the candidate
-            M = Ad + s * np.outer(nvec, nvec)
-            Pi = sla.cho_solve(sla.cho_factor(M, lower=True, check_finite=False), np.eye(N), check_finite=False) - np.outer(nvec, nvec) / s
-        else:
-            Pi = sla.cho_solve(sla.cho_factor(Ad, lower=True, check_finite=False), np.eye(N), check_finite=False)
+        singular = rayleigh < 1e-7 * s                             # (near-)singular along the candidate
+        if singular:
+            Ad += s * np.outer(nvec, nvec)
+        keep = Ad.copy() if N <= 6000 else None                    # the eigen-decomposition fallback needs the matrix itself
+        Pi = spd_inverse(Ad)
+        if singular:
+            Pi -= np.outer(nvec, nvec) / s
         if not np.isfinite(Pi).all() or np.abs(Pi).max() * s > 1e10:     # another (near-)null vector is hiding in there
             Pi = None
+        Ad = keep if keep is not None else A.toarray()
+        if singular:
+            Ad = Ad - s * np.outer(nvec, nvec)
     except (np.linalg.LinAlgError, sla.LinAlgError, ValueError):
         Pi = None
+        Ad = A.toarray()
+        Ad = 0.5 * (Ad + Ad.T)
     if Pi is None:
         w, V = np.linalg.eigh(Ad)
         keep = w > 1e-9 * w.max()

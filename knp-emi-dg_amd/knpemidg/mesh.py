@@ -122,6 +122,8 @@ class Mesh:
 
     # -- tables ----------------------------------------------------------------
     def _build_facets(self):
+        if self.cells.shape[0] >= 20000 and self._build_facets_native():
+            return
         cells = self.cells.astype(np.int64)
         nc, nv = cells.shape
         d = nv - 1
@@ -167,6 +169,32 @@ class Mesh:
         assert cnt.max() <= 2, "non-manifold mesh"
         self.facet_cells = fc
         self.facet_local = fl
+
+    def _build_facets_native(self):
+        """The same tables from the library's hash-based builder (csrc/host_sparse.cpp: knp_host_build_facets; identical numbering: facets
+        by first appearance in (cell, local facet) order) -- the numpy version below sorts 4 nc keys three times (0.4 s at 10^6 tets)."""
+        try:
+            from knpemidg import _abi
+            lib = _abi.load()
+        except Exception:
+            return False
+        nc, nv = self.cells.shape
+        cells = np.ascontiguousarray(self.cells, dtype=np.int32)
+        cf = np.empty((nc, nv), dtype=np.int32)
+        facets = np.empty((nc * nv, nv - 1), dtype=np.int32)
+        fc = np.empty((nc * nv, 2), dtype=np.int32)
+        fl = np.empty((nc * nv, 2), dtype=np.int8)
+        nf = int(lib.knp_host_build_facets(nc, nv, _abi._p(cells, _abi._i32p), _abi._p(cf, _abi._i32p), _abi._p(facets, _abi._i32p),
+                                           _abi._p(fc, _abi._i32p), _abi._p(fl, _abi._i8p)))
+        if nf == -2:
+            raise AssertionError("non-manifold mesh")
+        if nf < 0:
+            return False
+        self.cell_facets = cf
+        self.facets = np.ascontiguousarray(facets[:nf])
+        self.facet_cells = np.ascontiguousarray(fc[:nf])
+        self.facet_local = np.ascontiguousarray(fl[:nf])
+        return True
 
     def _midpoints(self, what, conn):
         """Midpoints of the cells / facets, computed once (mesh builders, the Morton order and the partitioner all ask for them);

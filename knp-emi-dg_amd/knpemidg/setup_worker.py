@@ -68,10 +68,12 @@ def start(job):
     for k in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
         env[k] = ""                               # host work only
     # torch.distributed.run pins OMP_NUM_THREADS to 1 for its workers: the helper's LAPACK calls get this rank's share of the cores
+    # Without a cap OpenBLAS starts one thread per LOGICAL core of the host (256 on the GPU boxes, of which a job may use 16): the dense
+    # Cholesky of the coarsest level then spends its time in thread management (0.75 s -> 0.2 s for 3 089 rows with 16 threads).
     world = max(1, int(env.get("WORLD_SIZE", "1") or 1))
-    if world > 1:
-        share = str(max(1, (os.cpu_count() or 1) // world))
-        for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+    share = str(max(1, min(16, (os.cpu_count() or 1) // world)))
+    for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+        if world > 1 or k not in os.environ:
             env[k] = share
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
