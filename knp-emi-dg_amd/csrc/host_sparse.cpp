@@ -259,31 +259,38 @@ int64_t knp_host_build_facets(int64_t nc, int nv, const int32_t* cells, int32_t*
                               int8_t* facet_local) {
     if (!cells || !cell_facets || !facets || !facet_cells || !facet_local || nc < 0 || (nv != 3 && nv != 4)) return -1;
     const int d = nv - 1;
-    struct Key { int32_t v[3]; bool operator==(const Key& o) const { return v[0] == o.v[0] && v[1] == o.v[1] && v[2] == o.v[2]; } };
-    struct Hash { size_t operator()(const Key& k) const {
-        uint64_t h = (uint64_t)(uint32_t)k.v[0] * 0x9E3779B97F4A7C15ull;
-        h ^= ((uint64_t)(uint32_t)k.v[1] + 0x7F4A7C15ull) * 0xC2B2AE3D27D4EB4Full + (h << 6) + (h >> 2);
-        h ^= ((uint64_t)(uint32_t)k.v[2] + 0x165667B1ull) * 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2);
-        return (size_t)h; } };
-    std::unordered_map<Key, int32_t, Hash> ids;
-    ids.reserve((size_t)(nc * nv * 0.6) + 16);
+    // flat open-addressing table on a packed 64-bit key (three 21-bit vertex ids, or two 32-bit ones): 4 nc look-ups, most of them
+    // first insertions -- a node-based std::unordered_map spent 0.5 s on them at 10^6 tets
+    int64_t vmax = 0;
+    for (int64_t i = 0; i < nc * nv; ++i) { if (cells[i] < 0) return -1; vmax = std::max<int64_t>(vmax, cells[i]); }
+    if (nv == 4 && vmax >= (int64_t(1) << 21)) return -1;                      // the caller falls back to its sort-based builder
+    int bits = 4;
+    while ((int64_t(1) << bits) < 3 * nc * nv / 2 + 16) ++bits;
+    const uint64_t mask = (uint64_t(1) << bits) - 1;
+    std::vector<uint64_t> keys((size_t)1 << bits, ~uint64_t(0));
+    std::vector<int32_t> vals((size_t)1 << bits, -1);
     int64_t nf = 0;
     for (int64_t c = 0; c < nc; ++c)
         for (int i = 0; i < nv; ++i) {
-            Key k{{-1, -1, -1}};
+            int32_t v[3] = {-1, -1, -1};
             int q = 0;
             for (int a = 0; a < nv; ++a)
-                if (a != i) k.v[q++] = cells[c * nv + a];
-            auto it = ids.find(k);
+                if (a != i) v[q++] = cells[c * nv + a];
+            const uint64_t key = nv == 4 ? ((uint64_t)v[0] << 42) | ((uint64_t)v[1] << 21) | (uint64_t)v[2] : ((uint64_t)v[0] << 32) | (uint64_t)(uint32_t)v[1];
+            uint64_t h = key * 0x9E3779B97F4A7C15ull;
+            h ^= h >> 29;
+            uint64_t slot = h & mask;
+            while (keys[slot] != key && keys[slot] != ~uint64_t(0)) slot = (slot + 1) & mask;
             int32_t f;
-            if (it == ids.end()) {
+            if (keys[slot] != key) {
                 f = (int32_t)nf++;
-                ids.emplace(k, f);
-                for (int a = 0; a < d; ++a) facets[(int64_t)f * d + a] = k.v[a];
+                keys[slot] = key;
+                vals[slot] = f;
+                for (int a = 0; a < d; ++a) facets[(int64_t)f * d + a] = v[a];
                 facet_cells[2 * (int64_t)f] = (int32_t)c; facet_cells[2 * (int64_t)f + 1] = -1;
                 facet_local[2 * (int64_t)f] = (int8_t)i; facet_local[2 * (int64_t)f + 1] = -1;
             } else {
-                f = it->second;
+                f = vals[slot];
                 if (facet_cells[2 * (int64_t)f + 1] >= 0) return -2;
                 facet_cells[2 * (int64_t)f + 1] = (int32_t)c;
                 facet_local[2 * (int64_t)f + 1] = (int8_t)i;

@@ -27,7 +27,8 @@ import scipy.sparse.csgraph as csg
 def _cell_gram(space):
     """(vol [nc], G [nc, nv, nv] = grad lambda_a . grad lambda_b) of every cell, computed once per space."""
     geo = getattr(space, "_gram", None)
-    if geo is None and space.mesh.cells.shape[0] >= 20000:
+    import os
+    if geo is None and space.mesh.cells.shape[0] >= 20000 and os.environ.get("KNP_SETUP_NATIVE_GRAM", "1") != "0":
         # threaded closed form in the library (csrc/host_sparse.cpp) instead of batched numpy inverses: 0.6 s -> 0.03 s at 10^6 tets
         from knpemidg import _abi
         mesh = space.mesh

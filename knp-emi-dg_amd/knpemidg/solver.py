@@ -317,44 +317,49 @@ class Solver:
         iteration, fewer iterations) unless `emi_dg_chebyshev` in solver_params decides explicitly.  Whether the extra apply pays depends
         on where the run sits between the launch-latency and the bandwidth regime and on the mesh quality (r=2: 4.25 -> 4.7 iterations
         without it for a quarter less work per iteration; EMIx reconstruction: 9.2 -> 13.5 iterations), so it is MEASURED on the first
-        solves of the run itself (_emi_smoother_trial) instead of being read off mesh-size thresholds (round 3)."""
+        EMI system of the run itself (_emi_smoother_trial) instead of being read off mesh-size thresholds (round 3)."""
         sp = getattr(self, "solver_params", None)
         explicit = getattr(sp, "emi_dg_chebyshev", None)
         if explicit is None and os.environ.get("KNP_EMI_CHEB") is not None:
             explicit = int(os.environ["KNP_EMI_CHEB"]) != 0                # the device reads the same variable as an override (csrc/abi.hip)
-        self._emi_trial = None if explicit is not None else {"solve": 0, "cost": {True: [], False: []}}
+        self._emi_trial = None if explicit is not None else True
         return True if explicit is None else bool(explicit)
 
-    def _emi_smoother_trial(self, seconds, res):
-        """Measured choice of the EMI DG-level smoother.  Solve 0 carries one-off work (eigenvalue estimate, graph capture) and is not
-        counted; solves 1 and 4 run with, solves 2 and 3 without the Chebyshev step (the first solves of a run get easier from one to the
-        next: the with / without / without / with order cancels that trend, a plain alternation charged it to the first variant); each is
-        charged its wall time per decade of TRUE-residual reduction (the norm of the residual target, so that steps of different
-        difficulty compare), the times summed over the ranks of a partitioned run (one all-reduce: every rank takes the same decision
-        and keeps ONE symmetric preconditioner).  The step stays unless dropping it is at least 3 % cheaper.  Nothing else has to
-        change with the choice: both variants meet the same stopping test, which does not depend on the preconditioner
-        (csrc/krylov.hip: cg_converged)."""
-        tr = self._emi_trial
-        k = tr["solve"]
-        tr["solve"] += 1
-        if 1 <= k <= 4:
-            decades = max(np.log10(max(float(res[0]), 1e-300) / max(float(res[1]), 1e-300)), 0.25)
-            tr["cost"][k in (1, 4)].append(seconds / decades)
-        if k == 1:
-            self.dev.set_emi_dg_smoother(False)
-        elif k == 3:
-            self.dev.set_emi_dg_smoother(True)
-        elif k == 2:
-            pass
-        elif k == 4:
-            on, off = self.dev.allreduce_sum([sum(tr["cost"][True]), sum(tr["cost"][False])])
-            keep = not (off < 0.97 * on)
-            self.dev.set_emi_dg_smoother(keep)
-            self.emi_dg_chebyshev_measured = {"chebyshev_s_per_decade": float(on), "plain_s_per_decade": float(off), "chosen": bool(keep)}
-            if self.verbose:
-                print(" EMI DG-level smoother: Chebyshev step %.3f ms / decade, plain block-Jacobi %.3f ms / decade -> %s"
-                      % (1e3 * on, 1e3 * off, "Chebyshev" if keep else "plain"))
-            self._emi_trial = None
+    def _emi_smoother_trial(self, solve):
+        """Measured choice of the EMI DG-level smoother, on the FIRST EMI system of the run: the same right-hand side is solved from the
+        same initial guess with the Chebyshev step and with plain block-Jacobi (one untimed solve each first: eigenvalue estimate, graph
+        capture, code-object loads), each charged its wall time per decade of TRUE-residual reduction; the times are summed over the
+        ranks of a partitioned run (one all-reduce: every rank takes the same decision and keeps ONE symmetric preconditioner).  The
+        step stays unless dropping it is at least 3 % cheaper.  The time stepping itself never changes preconditioner: a trial spread
+        over the first steps of the run (tried first) perturbed the extrapolated initial guesses of the steps behind it (r=2: EMI 4.6 ->
+        5.2, KNP 5.1 -> 5.4 iterations per step over the next 20 steps, profiles/r04_smoother_trial.txt).  Both variants meet the same
+        stopping test, which does not depend on the preconditioner (csrc/krylov.hip: cg_converged), so the last solve's result IS the
+        step's solution.  solve() -> (seconds, niter, res) runs one EMI solve on the current device state."""
+        dev = self.dev
+        phi0 = dev.download(_abi.F_PHI)
+        cost = {}
+        out = None
+        for timed in (False, True):
+            for cheb in (True, False):
+                dev.set_emi_dg_smoother(cheb)
+                dev.upload(_abi.F_PHI, phi0)                       # same initial guess; a caller-supplied state is no history point
+                sec, niter, res = solve()
+                if timed:
+                    decades = max(np.log10(max(float(res[0]), 1e-300) / max(float(res[1]), 1e-300)), 0.25)
+                    cost[cheb] = sec / decades
+                out = (sec, niter, res)
+        on, off = self.dev.allreduce_sum([cost[True], cost[False]])
+        keep = not (off < 0.97 * on)
+        self.emi_dg_chebyshev_measured = {"chebyshev_s_per_decade": float(on), "plain_s_per_decade": float(off), "chosen": bool(keep)}
+        if self.verbose:
+            print(" EMI DG-level smoother: Chebyshev step %.3f ms / decade, plain block-Jacobi %.3f ms / decade -> %s"
+                  % (1e3 * on, 1e3 * off, "Chebyshev" if keep else "plain"))
+        self._emi_trial = None
+        if keep:                                                   # the last solve ran without the step: redo with the chosen one
+            dev.set_emi_dg_smoother(True)
+            dev.upload(_abi.F_PHI, phi0)
+            out = solve()
+        return out
 
     def _host_initial_kappa(self):
         """kappa = F psi sum_k z_k^2 D_k c_k of the initial state, nodal [nc, nd] (what k_kappa computes on the device)."""
@@ -698,15 +703,20 @@ class Solver:
             r_abs = self._emi_target * _f(self.F) * self._knp_load_norm()
             self.emi_targets.append(r_abs)            # identical on every rank of a partitioned run (tests/test_gpu_multirank.py)
             dev.emi_residual_target(r_abs)
-        niter, r = dev.emi_solve(self._rtol_emi, self._atol_emi, maxit=self.max_it_emi)
+        if getattr(self, "_emi_trial", None) is not None and self._emi_target and self.use_amg and not self.direct_emi:
+            def one_solve():
+                t0 = time.perf_counter()
+                n_, r_ = dev.emi_solve(self._rtol_emi, self._atol_emi, maxit=self.max_it_emi)
+                return time.perf_counter() - t0, n_, r_
+            _, niter, r = self._emi_smoother_trial(one_solve)
+        else:
+            niter, r = dev.emi_solve(self._rtol_emi, self._atol_emi, maxit=self.max_it_emi)
         te = time.perf_counter()
         res = te - ts
         if self.verbose:
             print(f"{bcolors.OKGREEN} GPU Execution time PDE solve emi: {res:.4f} seconds ({niter} its) {bcolors.ENDC}")
         self.emi_solve_timer += res
         self.emi_niter.append(niter)
-        if getattr(self, "_emi_trial", None) is not None and self._emi_target and self.use_amg and not self.direct_emi:
-            self._emi_smoother_trial(res, r)
         self._maybe_refresh_amg_emi(niter)
         if self.save_solver_stats:
             if not self.direct_emi:

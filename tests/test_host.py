@@ -350,16 +350,16 @@ def test_knp_hierarchy_helper_process_matches_in_process(degree):
 
 def test_emi_dg_smoother_is_chosen_by_measurement():
     """knpemidg/solver.py: Solver._emi_dg_chebyshev / _emi_smoother_trial -- round 3 read the DG-level smoother of the EMI preconditioner
-    off mesh-size thresholds; round 4 measures it: solve 0 is not counted, solves 1 / 4 run with and 2 / 3 without the Chebyshev step,
-    each charged its time per decade of true-residual reduction, the sums all-reduced (every rank of a partitioned run takes the same
-    decision), the step dropped only if that is >= 3 % cheaper; solver_params / KNP_EMI_CHEB decide explicitly when they say so."""
+    off mesh-size thresholds; round 4 measures it on the first EMI system of the run: the same system is solved from the same initial
+    guess with and without the Chebyshev step (one untimed solve each first), each charged its time per decade of true-residual
+    reduction, the costs all-reduced (every rank of a partitioned run takes the same decision), the step dropped only if that is
+    >= 3 % cheaper; the step's solution comes from a solve with the chosen variant; solver_params / KNP_EMI_CHEB decide explicitly."""
     from collections import namedtuple
     from knpemidg.solver import Solver
 
     class Dev:
         def __init__(self):
-            self.calls = []
-            self.reduced = []
+            self.calls, self.reduced, self.uploads = [], [], 0
 
         def set_emi_dg_smoother(self, on):
             self.calls.append(bool(on))
@@ -368,7 +368,13 @@ def test_emi_dg_smoother_is_chosen_by_measurement():
             self.reduced.append(list(v))
             return np.asarray(v, dtype=float) * 3.0          # three ranks with the same timings
 
-    def run(costs_on, costs_off, explicit=None):
+        def download(self, field):
+            return np.zeros(4)
+
+        def upload(self, field, a):
+            self.uploads += 1
+
+    def run(cost_on, cost_off, explicit=None):
         S = Solver.__new__(Solver)
         S.verbose = False
         S.dev = Dev()
@@ -376,24 +382,79 @@ def test_emi_dg_smoother_is_chosen_by_measurement():
             S.solver_params = namedtuple("solver_params", ("emi_dg_chebyshev",))(explicit)
         first = S._emi_dg_chebyshev()
         if S._emi_trial is None:
-            return first, S.dev.calls, None
-        # (seconds, [r0, r1]) of solves 0..4: one decade of reduction each, so seconds = cost per decade
-        seq = [(9.9, [1.0, 0.1]), (costs_on[0], [1.0, 0.1]), (costs_off[0], [1.0, 0.1]), (costs_off[1], [1.0, 0.1]), (costs_on[1], [1.0, 0.1])]
-        for sec, res in seq:
-            assert S._emi_trial is not None
-            S._emi_smoother_trial(sec, res)
-        assert S._emi_trial is None and len(S.dev.reduced) == 1
-        return first, S.dev.calls, S.emi_dg_chebyshev_measured
+            return first, S.dev.calls, None, None
 
-    first, calls, m = run((1.0, 1.0), (0.8, 0.8))            # plain block-Jacobi 20 % cheaper per decade: dropped
-    assert first is True and calls == [False, True, False] and m["chosen"] is False
-    first, calls, m = run((1.0, 1.0), (0.99, 0.99))          # within the 3 % margin: the step stays
-    assert calls[-1] is True and m["chosen"] is True
-    first, calls, m = run((1.0, 1.0), (1.3, 1.2))
-    assert calls[-1] is True and abs(m["plain_s_per_decade"] - 3.0 * 2.5) < 1e-12
+        def solve():                                         # one decade of reduction: seconds = cost per decade
+            on = S.dev.calls[-1]
+            return (cost_on if on else cost_off), (7 if on else 9), [1.0, 0.1, 0.0]
+        out = S._emi_smoother_trial(solve)
+        assert S._emi_trial is None and len(S.dev.reduced) == 1
+        return first, S.dev.calls, S.emi_dg_chebyshev_measured, out
+
+    first, calls, m, out = run(1.0, 0.8)                      # plain block-Jacobi 20 % cheaper per decade: dropped
+    assert first is True and calls == [True, False, True, False] and m["chosen"] is False and out[1] == 9
+    first, calls, m, out = run(1.0, 0.99)                     # within the 3 % margin: the step stays, the step's solve is redone with it
+    assert calls == [True, False, True, False, True] and m["chosen"] is True and out[1] == 7
+    first, calls, m, out = run(1.0, 1.25)
+    assert calls[-1] is True and abs(m["plain_s_per_decade"] - 3.0 * 1.25) < 1e-12
     assert run(None, None, explicit=False)[0] is False and run(None, None, explicit=True)[0] is True      # explicit: no trial
     os.environ["KNP_EMI_CHEB"] = "0"
     try:
         assert run(None, None)[0] is False
     finally:
         del os.environ["KNP_EMI_CHEB"]
+
+
+def test_native_setup_kernels_match_numpy():
+    """Host setup kernels of the library (csrc/host_sparse.cpp, round 4) against the numpy code they replace: facet table (identical
+    numbering), geometry classes (same grouping, same records), cell Gram matrices, the CSR pattern of the conforming operators
+    (identical to a stable argsort of the entry keys) and the scatter-add into it."""
+    import build as _b
+    _b.build()
+    from knpemidg import _abi, amg
+    from knpemidg import mesh as M
+    m, s, f = M.make_mesh_3D(1)                                  # 124 416 tets: above the size from which the native paths are taken
+    ref = M.Mesh.__new__(M.Mesh)
+    ref.coords, ref.cells, ref.gdim = m.coords, m.cells, 3
+    native = M.Mesh._build_facets_native
+    M.Mesh._build_facets_native = lambda self: False
+    try:
+        ref._build_facets()
+    finally:
+        M.Mesh._build_facets_native = native
+    for a in ("cell_facets", "facets", "facet_cells", "facet_local"):
+        assert np.array_equal(getattr(m, a), getattr(ref, a)) and getattr(m, a).dtype == getattr(ref, a).dtype, a
+    order = _abi.morton_order(m.cell_midpoints())
+    g_nat = _abi.geometry_classes(m, order)
+    keep = _abi._geometry_classes_native
+    _abi._geometry_classes_native = lambda *a: None
+    try:
+        g_np = _abi.geometry_classes(m, order)
+    finally:
+        _abi._geometry_classes_native = keep
+    pairs = np.unique(np.stack([g_nat[0].astype(int), g_np[0].astype(int)], axis=1), axis=0)
+    assert len(pairs) == g_nat[1].shape[0] == g_np[1].shape[0] == 24          # same grouping: a bijection between the class ids
+    perm = np.array([dict(pairs.tolist())[i] for i in range(24)])
+    assert np.array_equal(g_nat[1], g_np[1][perm])
+    cs = amg.ConformingSpace(m, f.array(), (1, 2))
+    vol, G = amg._cell_gram(cs)
+    x = m.coords[m.cells]
+    J = (x[:, 1:, :] - x[:, :1, :]).transpose(0, 2, 1)
+    Ji = np.linalg.inv(J)
+    g = np.empty((x.shape[0], 4, 3))
+    g[:, 1:, :] = Ji
+    g[:, 0, :] = -Ji.sum(axis=1)
+    assert np.abs(vol - np.abs(np.linalg.det(J)) / 6.0).max() < 1e-14 * vol.max()
+    assert np.abs(G - np.einsum("cad,cbd->cab", g, g)).max() < 1e-13 * np.abs(G).max()
+    kappa = np.random.default_rng(0).uniform(0.5, 1.5, size=(m.num_cells(), 4))
+    A = cs.stiffness(kappa)
+    dof = cs.dof.astype(np.int64)
+    key = (np.repeat(dof[:, :, None], 4, axis=2) * cs.n + np.repeat(dof[:, None, :], 4, axis=1)).ravel()
+    o = np.argsort(key, kind="stable")
+    ks = key[o]
+    starts = np.nonzero(np.concatenate([[True], ks[1:] != ks[:-1]]))[0]
+    pat = cs._pattern
+    assert np.array_equal(pat[0], o) and np.array_equal(pat[1], starts) and np.array_equal(pat[2], (ks[starts] % cs.n).astype(np.int32))
+    blk = cs.cell_blocks(kappa)
+    want = np.add.reduceat(blk.ravel()[o], starts)
+    assert np.abs(A.data - want).max() < 1e-15 * np.abs(want).max()             # the same sums up to their order
