@@ -103,6 +103,8 @@ def solver_parameters(**extra):
 
 
 def make_solver(dt=0.1, degree=1, verbose=False, mesh_tuple=None, refine=0):
+    from knpemidg import setup_worker
+    setup_worker.prestart(2)           # the hierarchy helpers start importing now, while the mesh is being built
     params, ion_list, stim = physical_setup(dt)
     mesh, subdomains, surfaces = mesh_tuple or load_mesh(refine=refine)
     S = SolverEMIx(params, ion_list, degree_emi=degree, degree_knp=degree)

@@ -73,6 +73,8 @@ def solver_parameters(dim, resolution, **extra):
 
 def make_solver(dim=3, resolution=0, n_axons=4, degree=1, dt=1.0e-4, verbose=False, mesh_tuple=None):
     """Build a ready-to-run solver for the 2D / 3D idealized geometry."""
+    from knpemidg import setup_worker
+    setup_worker.prestart(2)           # the hierarchy helpers start importing now, while the mesh is being built
     params, ion_list, stim_params = physical_setup(dt)
     if mesh_tuple is None:
         mesh_tuple = make_mesh_3D(resolution, n_axons=n_axons) if dim == 3 else make_mesh_2D(resolution)

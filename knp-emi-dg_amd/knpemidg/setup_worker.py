@@ -49,6 +49,14 @@ def main():
     out = sys.stdout.buffer
     sys.stdout = sys.stderr                       # nothing but the result may reach the pipe
     try:
+        # everything the job needs is imported BEFORE the job arrives: a helper started ahead of time (prestart) spends the
+        # interpreter / numpy / scipy / library start-up (0.6 s) while the parent is still building its mesh
+        import numpy, scipy.sparse, scipy.sparse.csgraph, scipy.linalg                    # noqa: F401, E401
+        from knpemidg import amg, _abi                                                     # noqa: F401
+        try:
+            _abi.load()
+        except Exception:
+            pass
         job = pickle.load(sys.stdin.buffer)
         res = {"groups": run(job)}
     except BaseException as e:                    # reported to the parent, which falls back to building in-process
@@ -58,10 +66,11 @@ def main():
     out.flush()
 
 
-def start(job):
-    """Launch the helper and hand it the job from a feeder thread (pipe I/O releases the GIL).  Returns a handle for collect()."""
+_IDLE = []          # helper processes started ahead of time, waiting for a job on stdin
+
+
+def _spawn():
     import subprocess
-    import threading
     env = dict(os.environ)
     pkg_parent = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env["PYTHONPATH"] = pkg_parent + os.pathsep + env.get("PYTHONPATH", "")
@@ -77,7 +86,45 @@ def start(job):
             env[k] = share
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    proc = subprocess.Popen([sys.executable, "-m", "knpemidg.setup_worker"], stdin=subprocess.PIPE, stdout=subprocess.PIPE, env=env)
+    return subprocess.Popen([sys.executable, "-m", "knpemidg.setup_worker"], stdin=subprocess.PIPE, stdout=subprocess.PIPE, env=env)
+
+
+def prestart(n=2):
+    """Start up to n idle helpers now (Solver.__init__): they import their modules while the caller still builds its mesh.  Idle
+    helpers that never get a job are killed at interpreter exit."""
+    import atexit
+    if os.environ.get("KNP_AMG_SERIAL_SETUP", "0") == "1":
+        return
+    if not _IDLE:
+        atexit.register(_reap)
+    while len(_IDLE) < n:
+        try:
+            _IDLE.append(_spawn())
+        except OSError:
+            break
+
+
+def _reap():
+    while _IDLE:
+        p = _IDLE.pop()
+        try:
+            p.kill()
+            p.wait(timeout=5)
+        except Exception:
+            pass
+
+
+def start(job):
+    """Hand the job to a helper (one started ahead of time if there is one, else a new one) from a feeder thread (pipe I/O releases
+    the GIL).  Returns a handle for collect()."""
+    import threading
+    proc = None
+    while _IDLE and proc is None:
+        cand = _IDLE.pop(0)
+        if cand.poll() is None:
+            proc = cand
+    if proc is None:
+        proc = _spawn()
     handle = {"proc": proc, "result": None}
 
     def feed():

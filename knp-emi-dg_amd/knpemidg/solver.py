@@ -72,6 +72,9 @@ class Solver:
         self.mem_models = []
         self.stimulus = None
         self.stimulus_locator = None
+        if mms is None and os.environ.get("KNP_NO_AMG", "0") != "1":
+            from knpemidg import setup_worker
+            setup_worker.prestart(2)       # the two hierarchy helpers import their modules while the caller builds mesh and device context
         self.emi_niter = []
         self.emi_targets = []            # absolute residual targets handed to the EMI solves (error-controlled stop)
         self.knp_niter = []
