@@ -189,7 +189,8 @@ int knp_set_emi_dg_smoother(knp_ctx* ctx, int chebyshev);
 /* ---- auxiliary-space AMG preconditioner (stands in for pc_type hypre, solver.py:433, 688) ---------------
  * M^-1 = cell-block-Jacobi + P Ac^+ P^T with Ac the conforming (membrane-broken) P1 operator; the hierarchy is
  * built on the host (knpemidg/amg.py) and uploaded level by level.  which: 0 = EMI, 1 + k = KNP species k.
- *  knp_amg_begin : DG -> conforming dof map [nc*nd] and its inverse as a CSR list (conforming dof -> DG dofs)
+ *  knp_amg_begin : DG -> conforming dof map [nc*nd] and its inverse as a CSR list (conforming dof -> owned DG dofs, ascending;
+ *                  cg_ptr = cg_idx = NULL: derived here)
  *  knp_amg_level : one level (A csr, inverse diagonal, spectral radius of D^-1 A, Chebyshev degree / lower
  *                  fraction; P [n x ncoarse] and R = P^T as CSR; ncoarse = 0 on the last level)
  *  knp_amg_finish: dense pseudo-inverse [n*n] of the last level; arms the preconditioner

@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstdio>
 #include <algorithm>
+#include <thread>
 
 namespace {
 
@@ -715,6 +716,20 @@ int knp_amg_begin(knp_ctx* c, int which, int64_t ncg, const int32_t* dg2cg, cons
     const int64_t nmap = ndof;                              // dg2cg: conforming dof of every DG dof (injection)
     for (int64_t i = 0; i < nmap; ++i)
         if (dg2cg[i] < 0 || dg2cg[i] >= ncg) { c->err = "amg: dg2cg out of range"; return -1; }
+    // cg_ptr / cg_idx = null: the inverse map (conforming dof -> the OWNED DG dofs that inject into it, ascending) is derived here by a
+    // stable counting sort instead of the caller's argsort of nc nd keys
+    std::vector<int32_t> own_ptr, own_idx;
+    if (!cg_ptr || !cg_idx) {
+        const int64_t nown = c->m.nc_owned * c->nd;
+        own_ptr.assign((size_t)ncg + 1, 0);
+        for (int64_t i = 0; i < nown; ++i) ++own_ptr[(size_t)dg2cg[i] + 1];
+        for (int64_t v = 0; v < ncg; ++v) own_ptr[(size_t)v + 1] += own_ptr[(size_t)v];
+        own_idx.resize((size_t)nown);
+        std::vector<int32_t> fill(own_ptr.begin(), own_ptr.end() - 1);
+        for (int64_t i = 0; i < nown; ++i) own_idx[(size_t)fill[(size_t)dg2cg[i]]++] = (int32_t)i;
+        cg_ptr = own_ptr.data();
+        cg_idx = own_idx.data();
+    }
     if (cg_ptr[ncg] > ndof) { c->err = "amg: cg_ptr inconsistent"; return -1; }
     for (int64_t k = 0; k < cg_ptr[ncg]; ++k)
         if (cg_idx[k] < 0 || cg_idx[k] >= ndof) { c->err = "amg: cg_idx out of range"; return -1; }
@@ -732,12 +747,25 @@ int knp_amg_begin(knp_ctx* c, int which, int64_t ncg, const int32_t* dg2cg, cons
         std::vector<int32_t> tile_off((size_t)ntiles + 1, 0), slot_ptr(1, 0), slot_cg;
         std::vector<uint16_t> slot_idx;
         slot_idx.reserve((size_t)n_own * nd);
-        std::vector<std::pair<int32_t, uint16_t>> tmp;
+        // the per-tile sorts (2 048 keys each, ~2 000 tiles at 10^6 cells) run on a few host threads; the lists are stitched in tile order
+        std::vector<std::vector<std::pair<int32_t, uint16_t>>> sorted((size_t)ntiles);
+        {
+            const int T = (int)std::max<int64_t>(1, std::min<int64_t>(8, ntiles / 64));
+            std::vector<std::thread> pool;
+            for (int w = 0; w < T; ++w)
+                pool.emplace_back([&, w]() {
+                    for (int64_t t = w; t < ntiles; t += T) {
+                        const int64_t c0 = t * tile_cells, c1 = std::min<int64_t>(n_own, c0 + tile_cells);
+                        auto& v = sorted[(size_t)t];
+                        v.reserve((size_t)(c1 - c0) * nd);
+                        for (int64_t i = c0 * nd; i < c1 * nd; ++i) v.emplace_back(dg2cg[i], (uint16_t)(i - c0 * nd));
+                        std::sort(v.begin(), v.end());
+                    }
+                });
+            for (auto& th : pool) th.join();
+        }
         for (int64_t t = 0; t < ntiles; ++t) {
-            const int64_t c0 = t * tile_cells, c1 = std::min<int64_t>(n_own, c0 + tile_cells);
-            tmp.clear();
-            for (int64_t i = c0 * nd; i < c1 * nd; ++i) tmp.emplace_back(dg2cg[i], (uint16_t)(i - c0 * nd));
-            std::sort(tmp.begin(), tmp.end());
+            const auto& tmp = sorted[(size_t)t];
             for (size_t k = 0; k < tmp.size(); ++k) {
                 if (k == 0 || tmp[k].first != tmp[k - 1].first) {
                     if (k) slot_ptr.push_back((int32_t)slot_idx.size());

@@ -690,11 +690,8 @@ class Device:
         d2c = np.ascontiguousarray(np.asarray(dg2cg)[self.cell_order].ravel(), dtype=np.int32)
         assert d2c.shape == (self.nc * nd,)
         ncg = levels[0].A.shape[0]
-        own = d2c[:self.nc_owned * nd]
-        idx = np.argsort(own, kind="stable").astype(np.int32)
-        ptr = np.zeros(ncg + 1, dtype=np.int32)
-        np.cumsum(np.bincount(own, minlength=ncg), out=ptr[1:])
-        self._chk(self.lib.knp_amg_begin(self.ctx, which, ncg, _p(d2c, _i32p), _p(ptr, _i32p), _p(idx, _i32p)), "knp_amg_begin")
+        # (the inverse map conforming dof -> owned DG dofs is derived by the library: null pointers)
+        self._chk(self.lib.knp_amg_begin(self.ctx, which, ncg, _p(d2c, _i32p), None, None), "knp_amg_begin")
         if ncol != 1:
             self._chk(self.lib.knp_amg_columns(self.ctx, which, int(ncol)), "knp_amg_columns")
         if dist0:

@@ -148,7 +148,12 @@ def start(job):
 
 def collect(handle):
     """Groups built by the helper, or None (with the reason on stderr) when it failed."""
+    import time
+    t0 = time.perf_counter()
     handle["thread"].join()
+    handle["waited_s"] = time.perf_counter() - t0          # how long the caller stood still for the helper (0: it was done already)
+    if os.environ.get("KNP_DEBUG"):
+        print("[knpemidg] waited %.2f s for a hierarchy helper" % handle["waited_s"], file=sys.stderr)
     res = handle["result"] or {"error": "no result"}
     if "groups" in res:
         return res["groups"]

@@ -310,6 +310,12 @@ class Solver:
         # the membrane with C_phi = 1e10), which a V-cycle does not
         if self.use_amg and not self.direct_emi:
             self.dev.set_emi_dg_smoother(self._emi_dg_chebyshev())
+            # the KNP helper usually finishes first (no membrane term, one hierarchy for both species): while the EMI helper is still
+            # running, its result is uploaded here instead of in setup_solver_knp (0.2 s of upload hidden behind the wait)
+            eh, kh = getattr(self, "_emi_helper", None), getattr(self, "_knp_helper", None)
+            if (eh is not None and kh is not None and not self.direct_knp and eh[0]["thread"].is_alive() and not kh[0]["thread"].is_alive()):
+                self._setup_amg_knp()
+                self._knp_amg_uploaded_early = True
             self._setup_amg_emi()
         else:
             self._drop_emi_helper()
@@ -483,6 +489,8 @@ class Solver:
 
     def setup_solver_knp(self):
         if self.use_amg and not self.direct_knp:
+            if self.__dict__.pop("_knp_amg_uploaded_early", False):
+                return
             self._setup_amg_knp()
         else:
             self._drop_knp_helper()

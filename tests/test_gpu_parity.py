@@ -552,6 +552,39 @@ def test_unstructured_apply_kernel_variants(hip_lib, monkeypatch, env, variant, 
         dev.close()
 
 
+@pytest.mark.parametrize("names,variant", [(("K", "Cl"), 10), (("K", "Cl", "Na", "Ca"), 0)])
+def test_unstructured_knp_apply_with_one_and_three_solved_species(hip_lib, names, variant):
+    """Species counts other than two on a mesh without geometry classes: ONE solved species runs the NS = 1 instance of the unstructured
+    ring-staged kernel, THREE run the thread-per-cell coordinate kernel (the ring carries at most two); oracle operators at 1e-11."""
+    from knpemidg import _abi as A
+    import emix_sub
+    m, s, f = emix_sub.emix_submesh()
+    P = ko.emix_params()
+    nc = m.num_cells()
+    z = dict(P["z"], Ca=2.0)
+    Dc = dict(P["D"], Ca=0.8e-8)
+    tags = s.array().astype(np.int64)
+    ions = [dict(name=n, z=z[n], D=np.full(nc, Dc[n]) * np.array([1.0, 0.5, 0.25])[tags]) for n in names]
+    pb = ko.Problem(m, tags, f.array(), 1, ions, P, membrane_tags=(1, 2))
+    rng = np.random.default_rng(11)
+    pb.c = rng.uniform(50.0, 150.0, size=pb.c.shape)
+    pb.c_prev_n = pb.c.copy()
+    pb.c_elim = rng.uniform(50.0, 150.0, size=pb.c_elim.shape)
+    x = synthetic_state(pb, volt=1.0e3)
+    dev = device_for(pb)
+    try:
+        push_state(dev, pb)
+        assert dev.n_geometry_classes == 0 and dev.apply_variant(1) == variant
+        dev.update_dnphi()
+        dev.upload(A.F_X, x)
+        dev.knp_apply(A.F_X, A.F_Y)
+        y = dev.download(A.F_Y).reshape(pb.N_ions, -1)
+        for k in range(pb.N_ions):
+            assert relerr(y[k], ko.assemble_knp(pb, k) @ x[k].ravel()) < TOL
+    finally:
+        dev.close()
+
+
 def test_partitioned_emix_mesh_on_one_gpu(hip_lib, monkeypatch):
     """BASELINE configs[4] mesh (121 617 unstructured tets) cut into 4 parts by recursive coordinate bisection: a rank's owned +
     ghost context (ghost values as the halo exchange delivers them) reproduces the owned rows of the single-context applies,
