@@ -75,9 +75,12 @@ def make_solver(dim=3, resolution=0, n_axons=4, degree=1, dt=1.0e-4, verbose=Fal
     """Build a ready-to-run solver for the 2D / 3D idealized geometry."""
     from knpemidg import setup_worker
     setup_worker.prestart(2)           # the hierarchy helpers start importing now, while the mesh is being built
+    from knpemidg import _abi
+    _abi._stamp("make_solver: start")
     params, ion_list, stim_params = physical_setup(dt)
     if mesh_tuple is None:
         mesh_tuple = make_mesh_3D(resolution, n_axons=n_axons) if dim == 3 else make_mesh_2D(resolution)
+    _abi._stamp("make_solver: mesh built")
     mesh, subdomains, surfaces = mesh_tuple
     if dim == 3:
         ode_models = {1: mm_hh, 2: mm_hh_no_stim} if n_axons > 1 else {1: mm_hh}          # run_3D.py:196
@@ -89,4 +92,5 @@ def make_solver(dim=3, resolution=0, n_axons=4, degree=1, dt=1.0e-4, verbose=Fal
     S.setup_parameters()
     S.setup_FEM_spaces()
     S.setup_membrane_model(stim_params, ode_models)
+    _abi._stamp("make_solver: membrane models attached")
     return S

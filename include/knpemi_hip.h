@@ -174,6 +174,10 @@ int knp_knp_rhs(knp_ctx* ctx);             /* B_KNP <- L_knp(C, C_PREV, C_ELIM, 
  * knp_emi_residual_target: r_abs > 0 arms the error-controlled stop above for the following EMI solves; 0 restores PETSc's test.
  *      Every rank of a partitioned run must pass the same number (knp_allreduce_sum). */
 int knp_emi_residual_target(knp_ctx* ctx, double r_abs);
+/* knp_knp_load_measure: out[k] = sum over this context's owned cells of (|b_K| / vol_K)^8 of the KNP right-hand side of species k (field B_KNP
+ * as knp_knp_rhs left it; with KNP_KNP_NORM2=1: |b_K|^2 / vol_K) -- the size of the load the residual target above is scaled with
+ * (knpemidg/solver.py: _knp_load_norm sums over the ranks and takes the root).  Replaces a host pass over the downloaded field. */
+int knp_knp_load_measure(knp_ctx* ctx, double* out);
 int knp_emi_solve(knp_ctx* ctx, double rtol, double atol, int maxit, int check_every, int* niter, double* res);
 int knp_knp_solve(knp_ctx* ctx, double rtol, double atol, int maxit, int min_it, int check_every, int* niter, double* res);
 /* Krylov method of knp_knp_solve: 0 = BiCGStab (default: 4 operator applies and no stored basis per iteration), 1 = right-preconditioned
@@ -205,6 +209,7 @@ int knp_amg_level(knp_ctx* ctx, int which, int64_t n, const int32_t* rowptrA, co
                   const int32_t* rowptrP, const int32_t* colP, const double* valP,
                   const int32_t* rowptrR, const int32_t* colR, const double* valR);
 int knp_amg_finish(knp_ctx* ctx, int which, int64_t n, const double* pinv);
+int knp_amg_finish_f32(knp_ctx* ctx, int which, int64_t n, const float* pinv);   /* the same, inverse already in fp32 */
 int knp_amg_clear(knp_ctx* ctx, int which);
 /* Partitioned runs: ROW-DISTRIBUTED finest conforming level (the reference's BoomerAMG is row-distributed on every level under MPI,
  * src/knpemidg/solver.py:433, 688, with PETSc's VecScatter behind MatMult, :529, :789).  Each rank holds the conforming dofs of its own
@@ -285,6 +290,22 @@ int64_t knp_host_geometry_classes(int64_t nc, const double* coords, const int32_
                                   int64_t max_classes, int32_t* cls, int64_t* first, int nthreads);
 int knp_host_block_pattern(int64_t nc, int nd, int64_t n, const int32_t* dof, int64_t* order, int64_t* starts, int32_t* cols, int32_t* indptr,
                            int64_t* nseg, int nthreads);
+/*  knp_host_sym_to_f32: the dense coarsest-level inverse after LAPACK potri -- `a` [n x n] row-major with valid numbers in its upper triangle
+ *  -> the full symmetric matrix rounded to fp32 (what knp_amg_finish_f32 uploads) and its largest magnitude (NaN if an entry is not finite) */
+int knp_host_sym_to_f32(int64_t n, const double* a, float* out, double* maxabs, int nthreads);
+/*  knp_host_mis2_aggregate: aggregates from a distance-2 maximal independent set of a strength graph (CSR pattern, symmetric, no diagonal),
+ *  Luby rounds on the priorities key[n]; agg[n] receives the aggregate of every node, the return value is their number (< 0: bad arguments) */
+int64_t knp_host_mis2_aggregate(int64_t n, const int32_t* indptr, const int32_t* indices, const double* key, int64_t* agg, int nthreads);
+/*  knp_host_morton_order: stable argsort of points (or, with conn, of the midpoints of the rows of conn) along a Morton curve in units of
+ *  `scale` per axis -- the device numbering of cells and vertices; knp_host_cell_extent_median: that scale, the median cell extent per axis */
+int knp_host_morton_order(int64_t n, int d, const double* pts, const int32_t* conn, int nv, const double* scale, int64_t* order, int nthreads);
+int knp_host_cell_extent_median(int64_t nc, int nv, int d, const double* coords, const int32_t* cells, double* out);
+/*  knp_host_cell_neighbours: nb[nc][nv] = cell behind local facet i (-1: none), nj[nc][nv] = that cell's local index of the facet */
+int knp_host_cell_neighbours(int64_t nc, int nv, const int32_t* cell_facets, const int32_t* facet_cells, const int8_t* facet_local, int32_t* nb,
+                             int8_t* nj, int nthreads);
+/*  knp_host_box_marks: out[i] = 1 where the midpoint of row i of conn lies in the box [a, b] (mode 0) / on its surface within eps (mode 1) */
+int knp_host_box_marks(int64_t n, int d, const double* coords, const int32_t* conn, int nv, const double* a, const double* b, double eps, int mode,
+                       uint8_t* out, int nthreads);
 
 /* ---- timing / sync ------------------------------------------------------------------------------ */
 int knp_sync(knp_ctx* ctx);

@@ -2,6 +2,7 @@
 // interfaces each entry point replaces).
 #include "../../include/knpemi_hip.h"
 #include "knpemi_internal.hpp"
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include "krylov.hpp"
@@ -137,6 +138,15 @@ int knp_ctx_create(knp_ctx** out, int device, int dim, int degree, int n_ions, i
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { g_err = "no HIP device visible"; return -5; }
     if (device < 0 || device >= ndev) { g_err = "device index out of range"; return -5; }
+    // KNP_DEBUG_SETUP=1: wall-clock stamps of the stages below on stderr (next to the host-side stamps of knpemidg/_abi.py)
+    const bool stamps = getenv("KNP_DEBUG_SETUP") && atoi(getenv("KNP_DEBUG_SETUP")) == 1;
+    auto t_last = std::chrono::steady_clock::now();
+    auto stamp = [&](const char* what) {
+        if (!stamps) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[knp setup            +%6.3f] knp_ctx_create: %s\n", std::chrono::duration<double>(now - t_last).count(), what);
+        t_last = now;
+    };
     knp_ctx* c = new knp_ctx();
     c->device = device;
     c->degree = degree;
@@ -150,6 +160,7 @@ int knp_ctx_create(knp_ctx** out, int device, int dim, int degree, int n_ions, i
     if (hipStreamCreate(&c->stream) != hipSuccess) { g_err = "hipStreamCreate failed"; delete c; return -5; }
     hipEventCreate(&c->ev0);
     hipEventCreate(&c->ev1);
+    stamp("HIP runtime, stream");
 
     // ---- host-side validation + derived tables ------------------------------------------------
     for (int64_t i = 0; i < nc * NV; ++i)
@@ -199,6 +210,7 @@ int knp_ctx_create(knp_ctx** out, int device, int dim, int degree, int n_ions, i
         for (int a = 0; a < NV; ++a)
             if (cfacet[k * NV + a] < 0) { g_err = "owned cell with a facet missing from the facet table"; delete c; return -1; }
 
+    stamp("facet flags, neighbours");
     c->h_fflag = fflag;
     MeshDev& m = c->m;
     m.dim = dim; m.nv = nv; m.nc = nc; m.nc_owned = nc_owned; m.nf = nf; m.nmf = (int64_t)mf.size() / 6;
@@ -239,6 +251,7 @@ int knp_ctx_create(knp_ctx** out, int device, int dim, int degree, int n_ions, i
         const double vol = std::fabs(det) / (dim == 2 ? 2.0 : 6.0);
         ivol[(size_t)k] = vol > 0.0 ? (float)(1.0 / vol) : 0.0f;
     }
+    stamp("diameters, volumes");
     int rc = 0;
     rc |= dev_alloc_copy(c, &m.h, hcell.data(), hcell.size());
     rc |= dev_alloc_copy(c, &m.coords, csrc, (size_t)nv * cstride);
@@ -247,6 +260,7 @@ int knp_ctx_create(knp_ctx** out, int device, int dim, int degree, int n_ions, i
     rc |= dev_alloc_copy(c, &m.fflag, fflag.data(), fflag.size());
     rc |= dev_alloc_copy(c, &m.cfacet, cfacet.data(), cfacet.size());
     rc |= dev_alloc_copy(c, &m.mf, mf.data(), mf.size());
+    stamp("mesh tables on the device");
     if (dim == 3 && degree == 1 && nc_owned > 0 && nc < (int64_t(1) << 29)) {
         // halo- / ring-staged applies: per block of 256 consecutive cells, the coupled (SIPG or membrane: a_emi couples both) neighbours outside the block
         const int64_t B = KNP_HALO_BLK, nblk = (nc_owned + B - 1) / B;
@@ -286,6 +300,7 @@ int knp_ctx_create(knp_ctx** out, int device, int dim, int degree, int n_ions, i
         }
     }
     if (rc) { g_err = c->err; delete c; return -2; }
+    stamp("halo lists");
 
     Fields* fl = new Fields();
     const int64_t ndof = nc * ND, ns = c->p.n_sys;
@@ -311,6 +326,7 @@ int knp_ctx_create(knp_ctx** out, int device, int dim, int degree, int n_ions, i
     if (dev_alloc_copy(c, &fl->ivol, ivol.data(), ivol.size())) { g_err = "device allocation failed: " + c->err; delete fl; delete c; return -2; }
     g_fields[c] = fl;
     *out = c;
+    stamp("fields allocated");
     return 0;
 }
 
@@ -686,6 +702,13 @@ int knp_emi_residual_target(knp_ctx* c, double r_abs) {
     if (!c || !(r_abs >= 0.0)) return -1;
     F(c)->emi_r_abs = r_abs;
     return 0;
+}
+
+int knp_knp_load_measure(knp_ctx* c, double* out) {
+    if (!c || !out) return -1;
+    Fields* f = F(c);
+    const bool d8 = !(getenv("KNP_KNP_NORM2") && atoi(getenv("KNP_KNP_NORM2")) == 1);
+    return load_measure(c, f->f[KNP_F_B_KNP], f->ivol, d8, out);
 }
 
 int knp_emi_solve(knp_ctx* c, double rtol, double atol, int maxit, int check_every, int* niter, double* res) {

@@ -823,20 +823,29 @@ int knp_amg_level(knp_ctx* c, int which, int64_t n, const int32_t* rpA, const in
     return rc;
 }
 
-int knp_amg_finish(knp_ctx* c, int which, int64_t n, const double* pinv) {
+static int amg_finish_impl(knp_ctx* c, int which, int64_t n, const double* pinv64, const float* pinv32) {
     if (!c) return -1;
     AmgHierarchy* H = amg_slot(c, which);
     if (!H || H->levels.empty() || H->levels.back().n != n || H->levels.back().ncoarse != 0) {
         c->err = "amg: finish does not match the last level"; return -1;
     }
-    std::vector<float> p32((size_t)n * n);
-    for (size_t i = 0; i < p32.size(); ++i) p32[i] = (float)pinv[i];
-    int rc = up(c, &H->pinv, p32.data(), p32.size());
+    if (!pinv64 && !pinv32) { c->err = "amg: finish without a coarse inverse"; return -1; }
+    int rc;
+    if (pinv32) rc = up(c, &H->pinv, pinv32, (size_t)n * n);
+    else {
+        std::vector<float> p32((size_t)n * n);
+        for (size_t i = 0; i < p32.size(); ++i) p32[i] = (float)pinv64[i];
+        rc = up(c, &H->pinv, p32.data(), p32.size());
+    }
     const bool fuse_env = !(getenv("KNP_FUSE_FIRST0") && atoi(getenv("KNP_FUSE_FIRST0")) == 0);   // read per upload: tests switch it
     H->fuse_first0 = fuse_env && !c->dist && H->ntiles > 0 && H->levels.size() > 1 && H->levels[0].cheb_degree > 0;
     H->ready = (rc == 0);
     return rc;
 }
+
+int knp_amg_finish(knp_ctx* c, int which, int64_t n, const double* pinv) { return amg_finish_impl(c, which, n, pinv, nullptr); }
+// the same with the inverse already rounded to fp32 (the device stores it in fp32 either way)
+int knp_amg_finish_f32(knp_ctx* c, int which, int64_t n, const float* pinv) { return amg_finish_impl(c, which, n, nullptr, pinv); }
 
 // Marks hierarchy `which` as carrying a ROW-DISTRIBUTED level 0 (between knp_amg_begin and the first knp_amg_level): ncg, dg2cg and the
 // level-0 matrices are this rank's rows in local numbering, A sub-assembled from its own cells / facets (knp_amg_interface first).

@@ -22,6 +22,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <map>
+#include <mutex>
 #include <vector>
 
 namespace {
@@ -607,20 +608,31 @@ int build_tables_u(knp_ctx* c, RingUState& S) {
     return 0;
 }
 
-std::map<const knp_ctx*, RingUState>& states_u() {
+// per-context tables.  The map is guarded (contexts may live on different host threads; std::map keeps references to other entries
+// valid across insert / erase), a context's own entry is only touched by the thread that drives that context.
+std::mutex g_states_mu;
+std::map<const knp_ctx*, RingUState>& states_locked() {
     static std::map<const knp_ctx*, RingUState> s;
     return s;
+}
+RingUState& state_u(const knp_ctx* c) {
+    std::lock_guard<std::mutex> lock(g_states_mu);
+    return states_locked()[c];
 }
 
 }  // namespace
 
 void ring_u_free(knp_ctx* c) {
-    auto& st = states_u();
-    auto it = st.find(c);
-    if (it == st.end()) return;
-    RingUTables& T = it->second.T;
+    RingUTables T;
+    {
+        std::lock_guard<std::mutex> lock(g_states_mu);
+        auto& st = states_locked();
+        auto it = st.find(c);
+        if (it == st.end()) return;
+        T = it->second.T;
+        st.erase(it);
+    }
     hipFree(T.hb_src); hipFree(T.hb_loc); hipFree(T.vb_src); hipFree(T.vloc); hipFree(T.hinv4);
-    st.erase(it);
 }
 
 static size_t ring_u_lds(const knp_ctx* c, int which) {
@@ -637,7 +649,7 @@ int64_t ring_u_cells(knp_ctx* c, int which) {
     if (env_int_u("KNP_APPLY_RING_U", 1) == 0 || env_int_u("KNP_APPLY_RING", 1) == 0) return 0;
     if (which == 1 && !(c->nmat > 0 && c->p.n_sys <= 2 && env_int_u("KNP_APPLY_MAT", 1) != 0)) return 0;
     if (ring_u_lds(c, which) > 160 * 1024) return 0;
-    RingUState& S = states_u()[c];
+    RingUState& S = state_u(c);
     if (!S.tried) {
         S.tried = true;
         if (build_tables_u(c, S)) { S.usable = false; return 0; }
@@ -646,7 +658,7 @@ int64_t ring_u_cells(knp_ctx* c, int which) {
 }
 
 int ring_u_emi_apply(knp_ctx* c, const MeshDev& m, const double* x, const double* kappa, double* y, int reserve_cus) {
-    const RingUTables& T = states_u()[c].T;
+    const RingUTables& T = state_u(c).T;
     const size_t lds = ring_u_lds(c, 0);
     if (!grant_lds_u(k_emi_apply_ring_u, lds)) { c->err = "hipFuncSetAttribute(k_emi_apply_ring_u) failed"; return -2; }
     hipLaunchKernelGGL(k_emi_apply_ring_u, grid_u(m, c->device, reserve_cus), dim3(RB + 64 * ULOADERS), lds, c->stream, m, T, x, kappa, y, c->p.C_phi,
@@ -656,7 +668,7 @@ int ring_u_emi_apply(knp_ctx* c, const MeshDev& m, const double* x, const double
 }
 
 int ring_u_knp_apply(knp_ctx* c, const MeshDev& m, const double* x, const double* gphi, double* y, const KnpArgs& ka, int reserve_cus) {
-    const RingUTables& T = states_u()[c].T;
+    const RingUTables& T = state_u(c).T;
     const size_t lds = ring_u_lds(c, 1);
     const dim3 g = grid_u(m, c->device, reserve_cus);
     if (c->p.n_sys == 1) {

@@ -362,4 +362,258 @@ int64_t knp_host_geometry_classes(int64_t nc, const double* coords, const int32_
     }
     return ncls;
 }
+// The dense coarsest-level inverse after LAPACK's potri: `a` [n x n] row-major holds valid numbers in its UPPER triangle only (a Fortran-order
+// lower triangle seen through the C view).  out = the full symmetric matrix rounded to fp32, *maxabs = the largest magnitude (NaN / Inf if
+// any entry is not finite) -- numpy's tril + add + transpose + astype + isfinite + abs().max(), one pass over 64 x 64 tiles, threaded.
+int knp_host_sym_to_f32(int64_t n, const double* a, float* out, double* maxabs, int nthreads) {
+    if (!a || !out || !maxabs || n < 0) return -1;
+    if (nthreads <= 0) nthreads = (int)std::max(1u, std::thread::hardware_concurrency());
+    constexpr int64_t T = 64;
+    const int64_t nt = (n + T - 1) / T;
+    std::vector<double> part((size_t)std::max(1, nthreads), 0.0);
+    auto body = [&](int64_t lo, int64_t hi, int t) {
+        double mx = 0.0;
+        bool bad = false;
+        for (int64_t bi = lo; bi < hi; ++bi)
+            for (int64_t bj = bi; bj < nt; ++bj) {
+                const int64_t i1 = std::min(n, (bi + 1) * T), j1 = std::min(n, (bj + 1) * T);
+                for (int64_t i = bi * T; i < i1; ++i)
+                    for (int64_t j = std::max(i, bj * T); j < j1; ++j) {
+                        const double v = a[i * n + j];
+                        const float f = (float)v;
+                        out[i * n + j] = f;
+                        out[j * n + i] = f;
+                        const double av = std::fabs(v);
+                        if (!(av <= 1.7976931348623157e308)) bad = true;
+                        if (av > mx) mx = av;
+                    }
+            }
+        part[(size_t)t] = bad ? std::nan("") : mx;
+    };
+    // tile rows near the top hold more tiles: deal them round-robin instead of in contiguous chunks
+    if (nthreads == 1 || nt < 4) body(0, nt, 0);
+    else {
+        std::vector<std::thread> pool;
+        for (int t = 0; t < nthreads; ++t)
+            pool.emplace_back([&, t]() {
+                double mx = 0.0;
+                bool bad = false;
+                for (int64_t bi = t; bi < nt; bi += nthreads) {
+                    body(bi, bi + 1, t);
+                    if (part[(size_t)t] != part[(size_t)t]) bad = true; else mx = std::max(mx, part[(size_t)t]);
+                }
+                part[(size_t)t] = bad ? std::nan("") : mx;
+            });
+        for (auto& th : pool) th.join();
+    }
+    double mx = 0.0;
+    for (double v : part) { if (v != v) { mx = v; break; } mx = std::max(mx, v); }
+    *maxabs = mx;
+    return 0;
+}
+// Distance-2 maximal-independent-set aggregation of a strength graph (CSR pattern, symmetric, no diagonal): the vectorised Luby rounds of
+// knpemidg/amg.py (mis2_aggregate) pass for pass -- same keys, same max-reductions, hence the same aggregates -- without numpy's gather +
+// reduceat temporaries (4 of them per round).  key[n]: distinct positive priorities; agg[n]: aggregate of every node; returns their number.
+int64_t knp_host_mis2_aggregate(int64_t n, const int32_t* indptr, const int32_t* indices, const double* key, int64_t* agg, int nthreads) {
+    if (!indptr || !indices || !key || !agg || n < 0) return -1;
+    if (nthreads <= 0) nthreads = (int)std::max(1u, std::thread::hardware_concurrency());
+    const double NINF = -HUGE_VAL;
+    std::vector<int8_t> state((size_t)n, 0);                 // 0 undecided, 1 root, 2 covered
+    std::vector<double> a((size_t)n), b((size_t)n), c((size_t)n);
+    int64_t undecided = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        if (indptr[i + 1] == indptr[i]) state[(size_t)i] = 1;
+        else ++undecided;
+    }
+    // out[i] = max(in[i], max over neighbours in[j])
+    auto spread = [&](const std::vector<double>& in, std::vector<double>& out) {
+        parallel_rows(n, nthreads, [&](int64_t lo, int64_t hi, int) {
+            for (int64_t i = lo; i < hi; ++i) {
+                double m = in[(size_t)i];
+                for (int32_t k = indptr[i]; k < indptr[i + 1]; ++k) m = std::max(m, in[(size_t)indices[k]]);
+                out[(size_t)i] = m;
+            }
+        });
+    };
+    while (undecided > 0) {
+        for (int64_t i = 0; i < n; ++i) a[(size_t)i] = state[(size_t)i] == 0 ? key[i] : NINF;
+        spread(a, b);
+        spread(b, c);
+        for (int64_t i = 0; i < n; ++i)
+            if (state[(size_t)i] == 0 && a[(size_t)i] >= c[(size_t)i]) state[(size_t)i] = 1;
+        for (int64_t i = 0; i < n; ++i) a[(size_t)i] = state[(size_t)i] == 1 ? 1.0 : NINF;
+        spread(a, b);
+        spread(b, c);
+        undecided = 0;
+        for (int64_t i = 0; i < n; ++i) {
+            if (state[(size_t)i] == 0 && c[(size_t)i] > 0.0) state[(size_t)i] = 2;
+            if (state[(size_t)i] == 0) ++undecided;
+        }
+    }
+    int64_t nroot = 0;
+    for (int64_t i = 0; i < n; ++i) agg[i] = state[(size_t)i] == 1 ? nroot++ : -1;
+    // distance-1 members take the neighbouring root with the largest number, distance-2 members follow a neighbour (two synchronous rounds)
+    std::vector<int64_t> next((size_t)n);
+    for (int round = 0; round < 2; ++round) {
+        parallel_rows(n, nthreads, [&](int64_t lo, int64_t hi, int) {
+            for (int64_t i = lo; i < hi; ++i) {
+                int64_t best = agg[i];
+                if (best < 0)
+                    for (int32_t k = indptr[i]; k < indptr[i + 1]; ++k) best = std::max(best, agg[indices[k]]);
+                next[(size_t)i] = best;
+            }
+        });
+        std::memcpy(agg, next.data(), sizeof(int64_t) * (size_t)n);
+    }
+    for (int64_t i = 0; i < n; ++i)
+        if (agg[i] < 0) agg[i] = nroot++;                    // safety: singletons
+    return nroot;
+}
+// median over the cells of the per-axis extent (max - min over the cell's vertices): the length scale of the Morton curve below
+// (numpy: np.median(xc.max(axis=1) - xc.min(axis=1), axis=0) on the gathered [nc][nv][d] coordinates)
+int knp_host_cell_extent_median(int64_t nc, int nv, int d, const double* coords, const int32_t* cells, double* out) {
+    if (!coords || !cells || !out || nc < 1 || nv < 2 || d < 1 || d > 3) return -1;
+    std::vector<double> ext((size_t)nc);
+    for (int k = 0; k < d; ++k) {
+        for (int64_t c = 0; c < nc; ++c) {
+            double lo = coords[(int64_t)cells[c * nv] * d + k], hi = lo;
+            for (int a = 1; a < nv; ++a) {
+                const double v = coords[(int64_t)cells[c * nv + a] * d + k];
+                lo = std::min(lo, v);
+                hi = std::max(hi, v);
+            }
+            ext[(size_t)c] = hi - lo;
+        }
+        const int64_t h = nc / 2;
+        std::nth_element(ext.begin(), ext.begin() + h, ext.end());
+        double med = ext[(size_t)h];
+        if (nc % 2 == 0) med = (*std::max_element(ext.begin(), ext.begin() + h) + med) / 2.0;
+        out[k] = med;
+    }
+    return 0;
+}
+
+// Stable argsort of n points along a Morton (Z-order) curve, bit for bit what knpemidg/_abi.py: morton_order does in ~70 numpy passes:
+// p = x / scale (scale may be NULL), q = trunc((p - min) / largest span * (2^bits - 1)) with bits = 21 (3D) / 31 (otherwise), code = bits of
+// the axes interleaved (axis 0 lowest), order = stable sort by code.  With conn != NULL the points are the midpoints
+// ((x_0 + x_1) + ... + x_{nv-1}) / nv of the rows of conn [n][nv] (cells -> their midpoints) instead of pts itself.
+int knp_host_morton_order(int64_t n, int d, const double* pts, const int32_t* conn, int nv, const double* scale, int64_t* order, int nthreads) {
+    if (!pts || !order || n < 0 || d < 1 || d > 3 || (conn && nv < 1)) return -1;
+    if (n == 0) return 0;
+    if (nthreads <= 0) nthreads = (int)std::max(1u, std::thread::hardware_concurrency());
+    std::vector<double> p((size_t)n * d);
+    parallel_rows(n, nthreads, [&](int64_t lo, int64_t hi, int) {
+        for (int64_t i = lo; i < hi; ++i)
+            for (int k = 0; k < d; ++k) {
+                double v;
+                if (conn) {
+                    v = pts[(int64_t)conn[i * nv] * d + k];
+                    for (int a = 1; a < nv; ++a) v += pts[(int64_t)conn[i * nv + a] * d + k];
+                    v /= (double)nv;
+                } else v = pts[i * d + k];
+                p[(size_t)(i * d + k)] = scale ? v / scale[k] : v;
+            }
+    });
+    double lo[3], hi[3];
+    for (int k = 0; k < d; ++k) { lo[k] = p[(size_t)k]; hi[k] = p[(size_t)k]; }
+    for (int64_t i = 1; i < n; ++i)
+        for (int k = 0; k < d; ++k) {
+            lo[k] = std::min(lo[k], p[(size_t)(i * d + k)]);
+            hi[k] = std::max(hi[k], p[(size_t)(i * d + k)]);
+        }
+    double span = hi[0] - lo[0];
+    for (int k = 1; k < d; ++k) span = std::max(span, hi[k] - lo[k]);
+    const int bits = d == 3 ? 21 : 31;
+    const uint64_t qmax = (uint64_t(1) << bits) - 1;
+    const double M = (double)qmax;
+    std::vector<uint64_t> code((size_t)n, 0), code2((size_t)n);
+    if (span != 0.0)
+        parallel_rows(n, nthreads, [&](int64_t a, int64_t b, int) {
+            for (int64_t i = a; i < b; ++i) {
+                uint64_t cd = 0;
+                for (int k = 0; k < d; ++k) {
+                    const double t = (p[(size_t)(i * d + k)] - lo[k]) / span * M;
+                    uint64_t q = (uint64_t)t;
+                    if (q > qmax) q = qmax;
+                    for (int bb = 0; bb < bits; ++bb) cd |= ((q >> bb) & 1ull) << (bb * d + k);
+                }
+                code[(size_t)i] = cd;
+            }
+        });
+    // LSD radix sort of (code, index), 8 bits per pass; passes whose byte is the same everywhere are skipped
+    std::vector<int64_t> idx2((size_t)n);
+    for (int64_t i = 0; i < n; ++i) order[i] = i;
+    uint64_t* ck = code.data();
+    uint64_t* ck2 = code2.data();
+    int64_t* ix = order;
+    int64_t* ix2 = idx2.data();
+    for (int pass = 0; pass < 8; ++pass) {
+        const int sh = 8 * pass;
+        int64_t cnt[257] = {0};
+        for (int64_t i = 0; i < n; ++i) ++cnt[((ck[i] >> sh) & 0xffu) + 1];
+        bool single = false;
+        for (int v = 0; v < 256; ++v) if (cnt[v + 1] == n) single = true;
+        if (single) continue;
+        for (int v = 0; v < 256; ++v) cnt[v + 1] += cnt[v];
+        for (int64_t i = 0; i < n; ++i) {
+            const int64_t pos = cnt[(ck[i] >> sh) & 0xffu]++;
+            ck2[pos] = ck[i];
+            ix2[pos] = ix[i];
+        }
+        std::swap(ck, ck2);
+        std::swap(ix, ix2);
+    }
+    if (ix != order) std::memcpy(order, ix, sizeof(int64_t) * (size_t)n);
+    return 0;
+}
+// cell -> (neighbour cell behind local facet i or -1, the neighbour's local index of that facet) from the facet tables
+// (numpy: two take_along_axis gathers over [nc][nv][2] temporaries)
+int knp_host_cell_neighbours(int64_t nc, int nv, const int32_t* cell_facets, const int32_t* facet_cells, const int8_t* facet_local, int32_t* nb,
+                             int8_t* nj, int nthreads) {
+    if (!cell_facets || !facet_cells || !facet_local || !nb || !nj || nc < 0 || nv < 2) return -1;
+    if (nthreads <= 0) nthreads = (int)std::max(1u, std::thread::hardware_concurrency());
+    parallel_rows(nc, nthreads, [&](int64_t lo, int64_t hi, int) {
+        for (int64_t c = lo; c < hi; ++c)
+            for (int i = 0; i < nv; ++i) {
+                const int64_t f = cell_facets[c * nv + i];
+                const int other = facet_cells[2 * f] != c ? 0 : 1;          // the side of the facet that is NOT this cell
+                nb[c * nv + i] = facet_cells[2 * f + other];
+                nj[c * nv + i] = facet_local[2 * f + other];
+            }
+    });
+    return 0;
+}
+// Box tests on the midpoints ((x_0 + x_1) + ... ) / nv of the rows of conn (mesh builders: make_mesh_3D.py:15-50 of the reference marks the
+// cells whose midpoint lies in [a, b] and the facets on the box surface).  mode 0: out = 1 where a <= m <= b on every axis; mode 1: out = 1 where
+// the midpoint lies on the surface of the box -- within [a - eps, b + eps] on the other axes and closer than eps to a or b on one axis.
+int knp_host_box_marks(int64_t n, int d, const double* coords, const int32_t* conn, int nv, const double* a, const double* b, double eps, int mode,
+                       uint8_t* out, int nthreads) {
+    if (!coords || !conn || !a || !b || !out || n < 0 || d < 1 || d > 3 || nv < 1 || (mode != 0 && mode != 1)) return -1;
+    if (nthreads <= 0) nthreads = (int)std::max(1u, std::thread::hardware_concurrency());
+    parallel_rows(n, nthreads, [&](int64_t lo, int64_t hi, int) {
+        for (int64_t i = lo; i < hi; ++i) {
+            double m[3];
+            for (int k = 0; k < d; ++k) {
+                double v = coords[(int64_t)conn[i * nv] * d + k];
+                for (int q = 1; q < nv; ++q) v += coords[(int64_t)conn[i * nv + q] * d + k];
+                m[k] = v / (double)nv;
+            }
+            bool r;
+            if (mode == 0) {
+                r = true;
+                for (int k = 0; k < d; ++k) r = r && m[k] >= a[k] && m[k] <= b[k];
+            } else {
+                r = false;
+                for (int ax = 0; ax < d; ++ax) {
+                    bool within = true;
+                    for (int o = 0; o < d; ++o)
+                        if (o != ax) within = within && m[o] >= a[o] - eps && m[o] <= b[o] + eps;
+                    r = r || (within && (std::fabs(m[ax] - a[ax]) < eps || std::fabs(m[ax] - b[ax]) < eps));
+                }
+            }
+            out[i] = r ? 1 : 0;
+        }
+    });
+    return 0;
+}
 }  // extern "C"

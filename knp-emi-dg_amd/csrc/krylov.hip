@@ -1458,6 +1458,48 @@ int gmres_solve(knp_ctx* c, KrylovVecs& kv, double rtol, double atol, int maxit,
     return -1;
 }
 
+// partial sums of the load measure the stopping tests use (residual_measure: (|b_K| / vol_K)^8, or |b_K|^2 / vol_K without d8)
+template <int NV>
+__global__ __launch_bounds__(KNP_BLOCK) void k_load_measure(VecDims d, const double* __restrict__ b, double* __restrict__ partial) {
+    const int s = blockIdx.y;
+    const int64_t c = (int64_t)blockIdx.x * KNP_BLOCK + threadIdx.x;
+    double acc[1] = {0.0};
+    if (c < d.nc_owned) {
+        double bv[NV], bb = 0.0;
+        ldv<NV>(SYS_PTR(b, s), c, bv);
+#pragma unroll
+        for (int a = 0; a < NV; ++a) bb += bv[a] * bv[a];
+        acc[0] = residual_measure(d, c, bb);
+    }
+    write_partials<1>(partial, d.nsys, acc);
+}
+
+// out[s] = sum over this rank's owned cells of the load measure of species s' right-hand side b [nsys][nc][nd] (NOT all-reduced: the caller
+// sums over the ranks and takes the 8th / square root)
+int load_measure(knp_ctx* c, const double* b, const float* ivol, bool d8, double* out) {
+    const int ns = c->p.n_sys;
+    VecDims d{c->m.nc_owned, c->m.nc, ns, nullptr, nullptr, ivol, (d8 && ivol) ? 1 : 0};
+    const dim3 g((unsigned)grid_for(c->m.nc_owned), (unsigned)ns), blk(KNP_BLOCK);
+    switch (c->nd) {
+        case 3: hipLaunchKernelGGL(k_load_measure<3>, g, blk, 0, c->stream, d, b, c->partial); break;
+        case 4: hipLaunchKernelGGL(k_load_measure<4>, g, blk, 0, c->stream, d, b, c->partial); break;
+        case 6: hipLaunchKernelGGL(k_load_measure<6>, g, blk, 0, c->stream, d, b, c->partial); break;
+        case 10: hipLaunchKernelGGL(k_load_measure<10>, g, blk, 0, c->stream, d, b, c->partial); break;
+        default: c->err = "load_measure: unsupported dofs per cell"; return -1;
+    }
+    // second stage without the all-reduce and without a scalar recurrence behind it
+    const int64_t nb = grid_for(c->m.nc_owned);
+    double* red = c->scal + KNP_MAX_SYS * KS_N;
+    hipLaunchKernelGGL((k_reduce<1, 8>), dim3(ns), dim3(KNP_REDUCE_BLOCK), 0, c->stream, c->partial, nb, ns, red, 0, c->scal, c->status, 0.0, 0.0, 0,
+                       0.0, 0, 0);
+    HIPCHK(c, hipGetLastError());
+    double h[KNP_MAX_SYS * KNP_MAX_RED];
+    HIPCHK(c, hipMemcpyAsync(h, red, sizeof(double) * (size_t)ns * KNP_MAX_RED, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int s = 0; s < ns; ++s) out[s] = h[s * KNP_MAX_RED];
+    return 0;
+}
+
 int bicgstab_solve(knp_ctx* c, KrylovVecs& kv, double rtol, double atol, int maxit, int min_it, int check_every, int* niter,
                    double* res) {
     if (check_every < 1) check_every = 1;

@@ -32,6 +32,8 @@ struct KrylovVecs {
     double r_abs = 0.0;                    // PCG: > 0 -> error-controlled stop on the true residual and the energy-norm error estimate (krylov.hip: cg_converged)
 };
 
+// sums over the owned cells of the load measure of the stopping tests, per species (krylov.hip: residual_measure); not all-reduced
+int load_measure(knp_ctx* c, const double* b, const float* ivol, bool d8, double* out);
 int pcg_solve(knp_ctx* c, KrylovVecs& kv, double rtol, double atol, int maxit, int check_every, int* niter, double* res);
 int knp_bj_lambda_max(knp_ctx* c, KrylovVecs& kv, int iters, double* out, bool emi = false);
 int bicgstab_solve(knp_ctx* c, KrylovVecs& kv, double rtol, double atol, int maxit, int min_it, int check_every, int* niter,

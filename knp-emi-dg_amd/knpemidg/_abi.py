@@ -24,6 +24,7 @@ _i32p = C.POINTER(C.c_int32)
 _i64p = C.POINTER(C.c_int64)
 _u32p = C.POINTER(C.c_uint32)
 _i8p = C.POINTER(C.c_int8)
+_f32p = C.POINTER(C.c_float)
 _ctxp = C.c_void_p
 
 # every exported symbol of include/knpemi_hip.h with its signature
@@ -50,6 +51,7 @@ SIGNATURES = {
     "knp_emi_rhs": (C.c_int, [_ctxp]),
     "knp_knp_rhs": (C.c_int, [_ctxp]),
     "knp_emi_residual_target": (C.c_int, [_ctxp, C.c_double]),
+    "knp_knp_load_measure": (C.c_int, [_ctxp, _f64p]),
     "knp_emi_solve": (C.c_int, [_ctxp, C.c_double, C.c_double, C.c_int, C.c_int, C.POINTER(C.c_int), _f64p]),
     "knp_knp_solve": (C.c_int, [_ctxp, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), _f64p]),
     "knp_set_knp_krylov": (C.c_int, [_ctxp, C.c_int, C.c_int]),
@@ -95,6 +97,13 @@ SIGNATURES = {
     "knp_amg_level": (C.c_int, [_ctxp, C.c_int, C.c_int64, _i32p, _i32p, _f64p, _f64p, C.c_double, C.c_int, C.c_double,
                                 C.c_int64, _i32p, _i32p, _f64p, _i32p, _i32p, _f64p]),
     "knp_amg_finish": (C.c_int, [_ctxp, C.c_int, C.c_int64, _f64p]),
+    "knp_amg_finish_f32": (C.c_int, [_ctxp, C.c_int, C.c_int64, _f32p]),
+    "knp_host_sym_to_f32": (C.c_int, [C.c_int64, _f64p, _f32p, _f64p, C.c_int]),
+    "knp_host_morton_order": (C.c_int, [C.c_int64, C.c_int, _f64p, _i32p, C.c_int, _f64p, _i64p, C.c_int]),
+    "knp_host_cell_extent_median": (C.c_int, [C.c_int64, C.c_int, C.c_int, _f64p, _i32p, _f64p]),
+    "knp_host_cell_neighbours": (C.c_int, [C.c_int64, C.c_int, _i32p, _i32p, _i8p, _i32p, _i8p, C.c_int]),
+    "knp_host_box_marks": (C.c_int, [C.c_int64, C.c_int, _f64p, _i32p, C.c_int, _f64p, _f64p, C.c_double, C.c_int, C.POINTER(C.c_uint8), C.c_int]),
+    "knp_host_mis2_aggregate": (C.c_int64, [C.c_int64, _i32p, _i32p, _f64p, _i64p, C.c_int]),
     "knp_amg_clear": (C.c_int, [_ctxp, C.c_int]),
     "knp_amg_interface": (C.c_int, [_ctxp, C.c_int64, C.c_int, _i32p, _i64p, _i32p, C.c_int64, _i32p, _i32p, _i32p]),
     "knp_amg_dist0": (C.c_int, [_ctxp, C.c_int]),
@@ -155,12 +164,51 @@ def host_spgemm(A, B, nthreads=0):
     return out
 
 
+_T_STAMP = [None]
+
+
+def _stamp(label):
+    """KNP_DEBUG_SETUP=1: wall-clock stamps of the host setup stages on stderr (tools/profile_setup.py reads them off a bench run)."""
+    if os.environ.get("KNP_DEBUG_SETUP", "0") != "1":
+        return
+    import sys
+    import time
+    now = time.perf_counter()
+    if _T_STAMP[0] is None:
+        _T_STAMP[0] = (now, now)
+    t0, last = _T_STAMP[0]
+    print("[knp setup %7.3f s  +%6.3f  pid %d  abs %.3f] %s" % (now - t0, now - last, os.getpid(), now, label), file=sys.stderr, flush=True)
+    _T_STAMP[0] = (t0, now)
+
+
+def _morton_native(pts, conn, scale):
+    """morton_order through the library (csrc/host_sparse.cpp: knp_host_morton_order; the same order bit for bit): of the points, or of
+    the midpoints of the rows of conn.  None if the library is not there."""
+    try:
+        lib = load()
+    except OSError:
+        return None
+    pts = np.ascontiguousarray(pts, dtype=np.float64)
+    n = pts.shape[0] if conn is None else conn.shape[0]
+    order = np.empty(n, dtype=np.int64)
+    sc = None if scale is None else np.ascontiguousarray(scale, dtype=np.float64)
+    cn = None if conn is None else np.ascontiguousarray(conn, dtype=np.int32)
+    threads = min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+    rc = lib.knp_host_morton_order(n, pts.shape[1], _p(pts, _f64p), _p(cn, _i32p), 0 if cn is None else cn.shape[1], _p(sc, _f64p),
+                                   _p(order, _i64p), threads)
+    return order if rc == 0 else None
+
+
 def morton_order(points, scale=None):
     """Stable argsort of points along a Morton (Z-order) curve.  `scale` = typical cell extent per axis, so
     that the curve's bricks are cubes in units of CELLS (anisotropic meshes: 1 x 0.1 x 0.1 um boxes).
     Device cell numbering follows this curve: ~85 % of a cell's facet neighbours then sit in the same
     workgroup (served from LDS) and the rest is close enough to still be in the XCD's 4 MiB L2."""
     pts = np.asarray(points, dtype=np.float64)
+    if pts.ndim == 2 and pts.shape[0] >= 50000 and pts.shape[1] <= 3 and os.environ.get("KNP_SETUP_NATIVE_MORTON", "1") != "0":
+        order = _morton_native(pts, None, scale)
+        if order is not None:
+            return order
     if scale is not None:
         pts = pts / np.asarray(scale, dtype=np.float64)
     n, d = pts.shape
@@ -187,12 +235,26 @@ def geometry_classes(mesh, order, max_classes=4096, tol=1.0e-9):
     if d != 3:
         return None
     nc, nv = mesh.cells.shape
-    fc, fl = mesh.facet_cells, mesh.facet_local.astype(np.int64)
-    cf = mesh.cell_facets                                   # [nc, 4] facet ids
-    side = (fc[cf, 0] != np.arange(nc)[:, None]).astype(np.int64)          # which side of the facet this cell is
-    nb = np.take_along_axis(fc[cf], (1 - side)[:, :, None], axis=2)[:, :, 0]     # neighbour cell or -1
-    nj = np.take_along_axis(fl[cf], (1 - side)[:, :, None], axis=2)[:, :, 0]     # neighbour's local facet
+    nb = nj = None
+    if nc >= 20000:
+        try:
+            cf32 = np.ascontiguousarray(mesh.cell_facets, dtype=np.int32)
+            fc32 = np.ascontiguousarray(mesh.facet_cells, dtype=np.int32)
+            fl8 = np.ascontiguousarray(mesh.facet_local, dtype=np.int8)
+            nb, nj = np.empty((nc, nv), dtype=np.int32), np.empty((nc, nv), dtype=np.int8)
+            if load().knp_host_cell_neighbours(nc, nv, _p(cf32, _i32p), _p(fc32, _i32p), _p(fl8, _i8p), _p(nb, _i32p), _p(nj, _i8p), 0) != 0:
+                nb = nj = None
+        except OSError:
+            nb = nj = None
+    if nb is None:
+        fc, fl = mesh.facet_cells, mesh.facet_local.astype(np.int64)
+        cf = mesh.cell_facets                                   # [nc, 4] facet ids
+        side = (fc[cf, 0] != np.arange(nc)[:, None]).astype(np.int64)          # which side of the facet this cell is
+        nb = np.take_along_axis(fc[cf], (1 - side)[:, :, None], axis=2)[:, :, 0]     # neighbour cell or -1
+        nj = np.take_along_axis(fl[cf], (1 - side)[:, :, None], axis=2)[:, :, 0]     # neighbour's local facet
+    _stamp("classes: neighbour table")
     native = _geometry_classes_native(mesh, order, nb, nj, max_classes, tol) if nc >= 20000 else None
+    _stamp("classes: grouped")
     if native is not None:
         return native if native != "unstructured" else None
     X = mesh.coords[mesh.cells]                             # [nc, 4, 3]
@@ -315,6 +377,7 @@ class Device:
                  reorder=None):
         self.lib = load()
         self.ctx = _ctxp()
+        _stamp("device: start")
         nc = mesh.cells.shape[0]
         n_own = nc if nc_owned is None else int(nc_owned)
         if reorder is None:
@@ -324,9 +387,21 @@ class Device:
         scale = None
         self.n_interior = n_own
         if reorder and nc:
-            xc = mesh.coords[mesh.cells]
-            scale = np.maximum(np.median(xc.max(axis=1) - xc.min(axis=1), axis=0), 1e-300)
-            order[:n_own] = morton_order(mesh.cell_midpoints()[:n_own], scale)
+            native = nc >= 50000 and mesh.gdim <= 3 and os.environ.get("KNP_SETUP_NATIVE_MORTON", "1") != "0"
+            co = o = None
+            if native:
+                # median cell extent and the curve over the cell midpoints in the library (same numbers, same order): 0.43 -> 0.05 s at 10^6 tets
+                co = np.ascontiguousarray(mesh.coords, dtype=np.float64)
+                cl = np.ascontiguousarray(mesh.cells, dtype=np.int32)
+                scale = np.empty(mesh.gdim)
+                if self.lib.knp_host_cell_extent_median(nc, cl.shape[1], mesh.gdim, _p(co, _f64p), _p(cl, _i32p), _p(scale, _f64p)) == 0:
+                    scale = np.maximum(scale, 1e-300)
+                    o = _morton_native(co, cl[:n_own], scale)
+            if o is None:
+                xc = mesh.coords[mesh.cells]
+                scale = np.maximum(np.median(xc.max(axis=1) - xc.min(axis=1), axis=0), 1e-300)
+                o = morton_order(mesh.cell_midpoints()[:n_own], scale)
+            order[:n_own] = o
             if n_own < nc:
                 # a partition: owned cells without a ghost neighbour first (their part of an apply runs while the halo
                 # exchange is in flight), the cells on the cut after them; both groups along the Morton curve
@@ -340,6 +415,7 @@ class Device:
         rank = np.empty(nc, dtype=np.int64)
         rank[order] = np.arange(nc)
         self.cell_order, self.cell_rank = order, rank            # device -> caller, caller -> device
+        _stamp("device: cell order (Morton)")
         assert (np.diff(mesh.cells, axis=1) > 0).all(), "cells must hold ascending vertex ids"
         # vertex STORAGE order (ids are only used to fetch coordinates on the device; the local vertex order
         # inside each cell -- which carries the facet matching -- is untouched)
@@ -348,6 +424,7 @@ class Device:
         vrank = np.empty(nv, dtype=np.int64)
         vrank[vorder] = np.arange(nv)
         self.vertex_rank = vrank                                  # caller vertex id -> storage id
+        _stamp("device: vertex order")
         coords = np.ascontiguousarray(mesh.coords[vorder], dtype=np.float64)
         cells = np.ascontiguousarray(vrank[mesh.cells[order]], dtype=np.int32)
         ctags = np.ascontiguousarray(np.asarray(cell_tags)[order], dtype=np.uint32)
@@ -357,6 +434,7 @@ class Device:
         flocal = np.ascontiguousarray(mesh.facet_local, dtype=np.int8)
         mt = np.ascontiguousarray(np.asarray(list(membrane_tags)), dtype=np.uint32)
         assert ctags.shape == (nc,) and ftags.shape == (fcells.shape[0],)
+        _stamp("device: renumbered tables")
         self.dim = mesh.gdim
         self.nd = self.dim + 1 if degree == 1 else (self.dim + 1) * (self.dim + 2) // 2
         self.nc = nc
@@ -374,6 +452,7 @@ class Device:
         if self.n_interior != n_own:
             self._chk(self.lib.knp_set_interior(self.ctx, self.n_interior), "knp_set_interior")
         self.n_geometry_classes = 0
+        _stamp("device: knp_ctx_create")
         self.nranks = 1
         self.degree = int(degree)
         self._pending = []                 # queued PDE<->ODE column copies: (handle, to_facet, what, col, field, offset)
@@ -392,6 +471,7 @@ class Device:
                 self._chk(self.lib.knp_set_geometry_classes(self.ctx, table.shape[0], _p(cls, C.POINTER(C.c_uint16)),
                                                             _p(table, _f64p)), "knp_set_geometry_classes")
                 self.n_geometry_classes = table.shape[0]
+        _stamp("device: geometry classes set")
 
     # -- helpers -------------------------------------------------------------------
     def _chk(self, rc, what):
@@ -716,8 +796,13 @@ class Device:
             self._chk(self.lib.knp_amg_level(self.ctx, which, lv.A.shape[0], _p(rpA, _i32p), _p(ciA, _i32p), _p(vA, _f64p),
                                              _p(dinv, _f64p), float(lv.rho), int(lv.cheb_degree), float(lv.cheb_lower), *args),
                       "knp_amg_level")
-        pinv = np.ascontiguousarray(levels[-1].pinv, dtype=np.float64)
-        self._chk(self.lib.knp_amg_finish(self.ctx, which, pinv.shape[0], _p(pinv, _f64p)), "knp_amg_finish")
+        pinv = levels[-1].pinv
+        if pinv.dtype == np.float32:                               # already rounded by the setup (amg._coarse_pseudo_inverse)
+            pinv = np.ascontiguousarray(pinv)
+            self._chk(self.lib.knp_amg_finish_f32(self.ctx, which, pinv.shape[0], _p(pinv, _f32p)), "knp_amg_finish_f32")
+        else:
+            pinv = np.ascontiguousarray(pinv, dtype=np.float64)
+            self._chk(self.lib.knp_amg_finish(self.ctx, which, pinv.shape[0], _p(pinv, _f64p)), "knp_amg_finish")
 
     def amg_clear(self, which):
         self._chk(self.lib.knp_amg_clear(self.ctx, which), "knp_amg_clear")
@@ -728,6 +813,12 @@ class Device:
         v = np.ascontiguousarray(np.asarray(values, dtype=np.float64).ravel())
         self._chk(self.lib.knp_allreduce_sum(self.ctx, _p(v, _f64p), len(v)), "knp_allreduce_sum")
         return v
+
+    def knp_load_measure(self):
+        """Per solved species: sum over the owned cells of (|b_K| / vol_K)^8 of the current KNP right-hand side (knp_knp_load_measure)."""
+        out = np.zeros(self.n_sys)
+        self._chk(self.lib.knp_knp_load_measure(self.ctx, _p(out, _f64p)), "knp_knp_load_measure")
+        return out
 
     def halo_exchange(self, field):
         self._chk(self.lib.knp_halo_exchange(self.ctx, field), "knp_halo_exchange")
@@ -746,7 +837,7 @@ def _flushing(fn):
 for _name in ("close", "set_params", "set_mms", "upload", "download", "copy_field", "update_kappa", "update_dnphi", "emi_apply",
               "knp_apply", "emi_rhs", "knp_rhs", "emi_solve", "knp_solve", "step_updates", "picard_updates", "max_abs_diff",
               "nernst", "sync", "timer_begin", "timer_end", "bench_apply", "ode_table", "ode_step", "ode_set_stimulus",
-              "amg_upload", "amg_interface", "halo_exchange", "apply_timing_read", "comm_init", "set_interior"):
+              "amg_upload", "amg_interface", "halo_exchange", "knp_load_measure", "apply_timing_read", "comm_init", "set_interior"):
     setattr(Device, _name, _flushing(getattr(Device, _name)))
 
 

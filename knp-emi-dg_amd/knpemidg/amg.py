@@ -409,6 +409,16 @@ def mis2_aggregate(S, seed=0):
     n = S.shape[0]
     rng = np.random.default_rng(seed)
     key = rng.permutation(n).astype(np.float64) + 1.0
+    import os
+    if n >= 20000 and os.environ.get("KNP_SETUP_NATIVE_MIS2", "1") != "0":
+        # the same rounds in the library (csrc/host_sparse.cpp: knp_host_mis2_aggregate), without the gather + reduceat temporaries
+        from knpemidg import _abi
+        ip, ix = np.ascontiguousarray(S.indptr, dtype=np.int32), np.ascontiguousarray(S.indices, dtype=np.int32)
+        agg = np.empty(n, dtype=np.int64)
+        nagg = int(_abi.load().knp_host_mis2_aggregate(n, _abi._p(ip, _abi._i32p), _abi._p(ix, _abi._i32p), _abi._p(key, _abi._f64p),
+                                                        _abi._p(agg, _abi._i64p), _setup_threads()))
+        if nagg >= 0:
+            return agg, nagg
     state = np.zeros(n, dtype=np.int8)                 # 0 undecided, 1 root, 2 covered
     isolated = np.diff(S.indptr) == 0
     state[isolated] = 1
@@ -604,50 +614,63 @@ def _coarse_pseudo_inverse(A, Bnull):
     (mass term) take the plain inverse.  Anything else (several null vectors: subdomains without any coupling) falls back
     to the eigen-decomposition, where everything below 1e-9 of the largest eigenvalue counts as null space."""
     import scipy.linalg as sla
-    Ad = A.toarray()
-    Ad = 0.5 * (Ad + Ad.T)
-    N = Ad.shape[0]
+    A = A.tocsr()
+    N = A.shape[0]
     nvec = np.asarray(Bnull, dtype=np.float64) / max(np.linalg.norm(Bnull), 1e-300)
-    s = float(np.trace(Ad)) / max(N, 1)
-    rayleigh = float(nvec @ (Ad @ nvec))
+    s = float(A.diagonal().sum()) / max(N, 1)
+    rayleigh = float(nvec @ (A @ nvec))
+    singular = rayleigh < 1e-7 * s                                 # (near-)singular along the candidate
     Pi = None
-
-    def spd_inverse(M):
-        """LAPACK potrf + potri on the lower triangle (no identity right-hand side, half the flops of a triangular solve with it)."""
-        L, info = sla.lapack.dpotrf(M, lower=1, overwrite_a=1, clean=0)
+    # Every dense pass over the N x N matrix (76 MB at N = 3 089) costs as much as a tenth of the factorisation: the matrix is built in
+    # Fortran order (no LAPACK copy), only its lower triangle is touched (rank-one updates by BLAS dsyr, potrf / potri in place) and the
+    # mirror + fp32 rounding + sanity checks are one threaded pass in the library.
+    try:
+        M = A.toarray(order="F")
+        if singular:
+            M = sla.blas.dsyr(s, nvec, a=M, lower=1, overwrite_a=1)
+        M, info = sla.lapack.dpotrf(M, lower=1, overwrite_a=1, clean=0)
         if info != 0:
             raise np.linalg.LinAlgError("potrf")
-        Mi, info = sla.lapack.dpotri(L, lower=1, overwrite_c=1)
+        M, info = sla.lapack.dpotri(M, lower=1, overwrite_c=1)     # no identity right-hand side: half the flops of a solve with it
         if info != 0:
             raise np.linalg.LinAlgError("potri")
-        Mi = np.tril(Mi)                                           # potri leaves the other triangle untouched: mirror the lower one
-        Mi = Mi + Mi.T
-        Mi[np.diag_indices(N)] *= 0.5
-        return Mi
-    try:
-        singular = rayleigh < 1e-7 * s                             # (near-)singular along the candidate
         if singular:
-            Ad += s * np.outer(nvec, nvec)
-        keep = Ad.copy() if N <= 6000 else None                    # the eigen-decomposition fallback needs the matrix itself
-        Pi = spd_inverse(Ad)
-        if singular:
-            Pi -= np.outer(nvec, nvec) / s
-        if not np.isfinite(Pi).all() or np.abs(Pi).max() * s > 1e10:     # another (near-)null vector is hiding in there
+            M = sla.blas.dsyr(-1.0 / s, nvec, a=M, lower=1, overwrite_a=1)
+        Pi = _mirror_round(M)
+        if Pi is not None and not (Pi[1] * s <= 1e10):             # NaN / Inf / another (near-)null vector hiding in there
             Pi = None
-        Ad = keep if keep is not None else A.toarray()
-        if singular:
-            Ad = Ad - s * np.outer(nvec, nvec)
+        M = None
     except (np.linalg.LinAlgError, sla.LinAlgError, ValueError):
         Pi = None
-        Ad = A.toarray()
-        Ad = 0.5 * (Ad + Ad.T)
-    if Pi is None:
-        w, V = np.linalg.eigh(Ad)
-        keep = w > 1e-9 * w.max()
-        Pi = (V[:, keep] / w[keep]) @ V[:, keep].T
-    # symmetrise before rounding so that the fp32 operator is still exactly symmetric; keep the rounded values here so that
-    # host and device apply the same operator
-    return (0.5 * (Pi + Pi.T)).astype(np.float32).astype(np.float64)
+    if Pi is not None:
+        return Pi[0]
+    Ad = A.toarray()
+    Ad = 0.5 * (Ad + Ad.T)
+    w, V = np.linalg.eigh(Ad)
+    keep = w > 1e-9 * w.max()
+    Pi = (V[:, keep] / w[keep]) @ V[:, keep].T
+    # symmetrise before rounding so that the fp32 operator is still exactly symmetric
+    return (0.5 * (Pi + Pi.T)).astype(np.float32)
+
+
+def _mirror_round(M):
+    """(full symmetric fp32 matrix, max |entry|) from a Fortran-order matrix whose LOWER triangle is valid (LAPACK potri output)."""
+    N = M.shape[0]
+    Mc = M.T                                                       # C-contiguous view: the valid triangle is its upper one
+    if Mc.flags.c_contiguous and N >= 256:
+        from knpemidg import _abi
+        try:
+            out = np.empty((N, N), dtype=np.float32)
+            mx = np.zeros(1)
+            if _abi.load().knp_host_sym_to_f32(N, _abi._p(Mc, _abi._f64p), _abi._p(out, _abi._f32p), _abi._p(mx, _abi._f64p), _setup_threads()) == 0:
+                return out, float(mx[0])
+        except (OSError, AttributeError):
+            pass
+    L = np.tril(np.asarray(M))
+    full = L + L.T
+    full[np.diag_indices(N)] *= 0.5
+    mx = float(np.abs(full).max()) if N else 0.0
+    return full.astype(np.float32), (mx if np.isfinite(full).all() else float("nan"))
 
 
 def build_emi_levels(cspace, cspace2, facet_tags, membrane_tags, kappa, C_phi):

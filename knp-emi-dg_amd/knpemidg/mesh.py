@@ -86,11 +86,13 @@ class Mesh:
 
     def __init__(self, coords, cells):
         coords = np.ascontiguousarray(coords, dtype=np.float64)
-        cells = np.sort(np.asarray(cells, dtype=np.int64), axis=1)
+        cells = np.asarray(cells)
         assert coords.ndim == 2 and cells.ndim == 2
         assert cells.shape[1] == coords.shape[1] + 1, "simplicial meshes only"
+        if not (cells.dtype == np.int32 and (cells[:, 1:] > cells[:, :-1]).all()):      # generators hand over ascending int32 rows already
+            cells = np.sort(cells.astype(np.int64), axis=1).astype(np.int32)
         self.coords = coords
-        self.cells = np.ascontiguousarray(cells.astype(np.int32))
+        self.cells = np.ascontiguousarray(cells)
         self.gdim = coords.shape[1]
         self._build_facets()
 
@@ -348,20 +350,15 @@ def BoxMesh(p0, p1, nx, ny, nz):
     zs = p0[2] + (p1[2] - p0[2]) * np.arange(nz + 1) / nz
     Z, Y, X = np.meshgrid(zs, ys, xs, indexing="ij")   # x fastest
     coords = np.stack([X.ravel(), Y.ravel(), Z.ravel()], axis=1)
-    iz, iy, ix = np.meshgrid(np.arange(nz), np.arange(ny), np.arange(nx), indexing="ij")
-    ix, iy, iz = ix.ravel(), iy.ravel(), iz.ravel()
+    itype = np.int32 if (nx + 1) * (ny + 1) * (nz + 1) < 2 ** 31 else np.int64
+    iz, iy, ix = np.meshgrid(np.arange(nz, dtype=itype), np.arange(ny, dtype=itype), np.arange(nx, dtype=itype), indexing="ij")
     sx, sy = nx + 1, (nx + 1) * (ny + 1)
-    v0 = iz * sy + iy * sx + ix
-    v1 = v0 + 1
-    v2 = v0 + sx
-    v3 = v1 + sx
-    v4 = v0 + sy
-    v5 = v1 + sy
-    v6 = v2 + sy
-    v7 = v3 + sy
-    tets = np.stack([np.stack([v0, v1, v3, v7], 1), np.stack([v0, v1, v7, v5], 1),
-                     np.stack([v0, v5, v7, v4], 1), np.stack([v0, v3, v2, v7], 1),
-                     np.stack([v0, v6, v4, v7], 1), np.stack([v0, v2, v6, v7], 1)], axis=1)
+    v0 = (iz * sy + iy * sx + ix).ravel()
+    # the six tetrahedra of a brick, (v0, v1, v3, v7) (v0, v1, v7, v5) (v0, v5, v7, v4) (v0, v3, v2, v7) (v0, v6, v4, v7) (v0, v2, v6, v7) with
+    # v1 = v0 + 1, v2 = v0 + sx, v3 = v1 + sx, v4 .. v7 = v0 .. v3 + sy, written with every row already ascending (what Mesh() sorts them to)
+    off = np.array([[0, 1, 1 + sx, 1 + sx + sy], [0, 1, 1 + sy, 1 + sx + sy], [0, sy, 1 + sy, 1 + sx + sy],
+                    [0, sx, 1 + sx, 1 + sx + sy], [0, sy, sx + sy, 1 + sx + sy], [0, sx, sx + sy, 1 + sx + sy]], dtype=itype)
+    tets = v0[:, None, None] + off[None, :, :]
     return Mesh(coords, tets.reshape(-1, 4))
 
 
@@ -370,26 +367,52 @@ def _near(a, b, eps=3.0e-16):
     return np.abs(a - b) < eps
 
 
+def _box_marks_native(mesh, a, b, eps):
+    """(cells inside the box, facets on its surface) through the library (csrc/host_sparse.cpp: knp_host_box_marks; the same tests on the
+    same midpoints, one threaded pass each instead of ~30 numpy passes over the facet midpoints).  (None, None) without the library."""
+    try:
+        from knpemidg import _abi
+        lib = _abi.load()
+    except (OSError, ImportError):
+        return None, None
+    co = np.ascontiguousarray(mesh.coords, dtype=np.float64)
+    u8p = _abi.C.POINTER(_abi.C.c_uint8)
+    out = []
+    for conn, mode in ((mesh.cells, 0), (mesh.facets, 1)):
+        cn = np.ascontiguousarray(conn, dtype=np.int32)
+        m = np.empty(cn.shape[0], dtype=np.uint8)
+        rc = lib.knp_host_box_marks(cn.shape[0], mesh.gdim, _abi._p(co, _abi._f64p), _abi._p(cn, _abi._i32p), cn.shape[1], _abi._p(a, _abi._f64p),
+                                    _abi._p(b, _abi._f64p), float(eps), mode, _abi._p(m, u8p), 0)
+        if rc != 0:
+            return None, None
+        out.append(m.view(np.bool_))
+    return out[0], out[1]
+
+
 def _tag_box(mesh, subdomains, surfaces, a, b, tag_bndr, additive=False, eps=1e-12):
     """Mark cells whose midpoint lies in [a,b] with 1 and the facets on the box
     surface with `tag_bndr` (reference: make_mesh_3D.py:15-50, make_mesh_2D.py:24-47).
     `eps` absorbs the rounding of grid coordinates that dolfin's `near` absorbs."""
     d = mesh.gdim
-    a = np.asarray(a, float)
-    b = np.asarray(b, float)
-    cm = mesh.cell_midpoints()
-    inside = np.all((cm >= a) & (cm <= b), axis=1)
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    b = np.ascontiguousarray(b, dtype=np.float64)
+    inside = on = None
+    if mesh.num_cells() >= 50000:
+        inside, on = _box_marks_native(mesh, a, b, eps)
+    if inside is None:
+        cm = mesh.cell_midpoints()
+        inside = np.all((cm >= a) & (cm <= b), axis=1)
+        fm = mesh.facet_midpoints()
+        on = np.zeros(len(fm), dtype=bool)
+        for ax in range(d):
+            others = [o for o in range(d) if o != ax]
+            within = np.ones(len(fm), dtype=bool)
+            for o in others:
+                within &= (fm[:, o] >= a[o] - eps) & (fm[:, o] <= b[o] + eps)
+            on |= within & (np.abs(fm[:, ax] - a[ax]) < eps)
+            on |= within & (np.abs(fm[:, ax] - b[ax]) < eps)
     subdomains.array()[inside] = 1
     assert inside.any()
-    fm = mesh.facet_midpoints()
-    on = np.zeros(len(fm), dtype=bool)
-    for ax in range(d):
-        others = [o for o in range(d) if o != ax]
-        within = np.ones(len(fm), dtype=bool)
-        for o in others:
-            within &= (fm[:, o] >= a[o] - eps) & (fm[:, o] <= b[o] + eps)
-        on |= within & (np.abs(fm[:, ax] - a[ax]) < eps)
-        on |= within & (np.abs(fm[:, ax] - b[ax]) < eps)
     if additive:
         surfaces.array()[on] += 1
     else:

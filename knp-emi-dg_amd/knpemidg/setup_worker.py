@@ -57,13 +57,20 @@ def main():
             _abi.load()
         except Exception:
             pass
+        _abi._stamp("helper: modules imported, waiting for the job")
         job = pickle.load(sys.stdin.buffer)
+        _abi._stamp("helper: job received (%s)" % job.get("kind", "knp"))
         res = {"groups": run(job)}
+        _abi._stamp("helper: hierarchy built (%s)" % job.get("kind", "knp"))
     except BaseException as e:                    # reported to the parent, which falls back to building in-process
         import traceback
         res = {"error": "%s\n%s" % (e, traceback.format_exc())}
     pickle.dump(res, out, protocol=pickle.HIGHEST_PROTOCOL)
     out.flush()
+    try:
+        _abi._stamp("helper: result sent")
+    except Exception:
+        pass
 
 
 _IDLE = []          # helper processes started ahead of time, waiting for a job on stdin

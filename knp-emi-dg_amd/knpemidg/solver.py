@@ -219,9 +219,11 @@ class Solver:
             membrane_tags = list(self.lm_tags) if self.mms is not None else [m['ode'].tag for m in self.mem_models]
         self.membrane_tags = list(membrane_tags)
         nc = self.mesh.num_cells()
+        _abi._stamp("solver: _ensure_device")
         if self.mms is None:
             self._start_knp_helper()
             self._start_emi_helper()
+            _abi._stamp("solver: helper jobs handed over")
         self.dev = _abi.Device(self.mesh, self.subdomains.array(), self.surfaces.array(), self.membrane_tags,
                                len(self.ion_list), degree=self.degree_knp, device=self.device_index,
                                nc_owned=getattr(self, "nc_owned", None))
@@ -241,6 +243,7 @@ class Solver:
         dev.upload(A.F_PHI_M, self._init_phi_M)
         self._push_params(splitting=True)
         dev.nernst()                                                 # initial E_k (solver.py:299-300)
+        _abi._stamp("solver: initial fields and parameters on the device")
 
     def _push_params(self, splitting):
         z = [float(ion['z']) for ion in self.ion_list]
@@ -414,7 +417,9 @@ class Solver:
             dev.update_kappa()
             kappa = dev.download(_abi.F_KAPPA).reshape(self.mesh.num_cells(), self.nd)
             if np.allclose(kappa, kappa_h, rtol=1e-8, atol=0.0):
+                _abi._stamp("solver: waiting for the EMI helper")
                 res = setup_worker.collect(handle)
+                _abi._stamp("solver: EMI hierarchy collected")
                 if res is not None:
                     levels, dg2cg = res["levels"], res["dof"]
                     self._amg_kappa0 = kappa.ravel().copy()
@@ -449,6 +454,7 @@ class Solver:
                     levels = None
         if levels is not None:
             dev.amg_upload(0, dg2cg, levels)
+            _abi._stamp("solver: EMI hierarchy uploaded")
             nlev = [lv.A.shape[0] for lv in levels]
         else:
             nlev = [lv.A.shape[0] for lv in local]
@@ -742,19 +748,15 @@ class Solver:
         bn = getattr(self, "_knp_bnorm", None)
         if bn is None:
             dev = self.dev
+            _abi._stamp("first step: EMI right-hand side ready")
             dev.update_dnphi(); dev.knp_rhs()
-            b = dev.download(_abi.F_B_KNP).reshape(self.N_ions, self.mesh.num_cells(), self.nd)
-            n_own = getattr(self, "nc_owned", None) or self.mesh.num_cells()
-            x = self.mesh.coords[self.mesh.cells[:n_own]]
-            vol = np.abs(np.linalg.det(x[:, 1:] - x[:, :1])) / (2.0 if self.mesh.gdim == 2 else 6.0)
-            bK2 = (b[:, :n_own] ** 2).sum(axis=2)
-            # a partition sums over its owned cells and all-reduces the sums: every rank must hand the SAME target to the PCG
-            # stopping test (ranks that disagree about convergence leave the loop of collectives at different iterations)
-            if os.environ.get("KNP_KNP_NORM2", "0") == "1":
-                bn = np.sqrt(dev.allreduce_sum((bK2 / vol[None, :]).sum(axis=1)))
-            else:                                                      # order-8 norm of the load density (csrc/krylov.hip)
-                bn = dev.allreduce_sum(((bK2 / vol[None, :] ** 2) ** 4).sum(axis=1)) ** 0.125
+            # summed over the owned cells on the device (a partition all-reduces the sums: every rank must hand the SAME target to the PCG
+            # stopping test -- ranks that disagree about convergence leave the loop of collectives at different iterations); a host
+            # pass over the downloaded field cost 2 s at 8 x 10^6 cells
+            sums = dev.allreduce_sum(dev.knp_load_measure())
+            bn = np.sqrt(sums) if os.environ.get("KNP_KNP_NORM2", "0") == "1" else sums ** 0.125      # order-8 norm of the load density
             self._knp_bnorm = bn
+            _abi._stamp("first step: KNP load norm of the initial state")
         return float(np.min(z * np.asarray(bn)))
 
     # ------------------------------------------------------------------ solve_knp (solver.py:723-791)
@@ -799,9 +801,18 @@ class Solver:
             from knpemidg.mms_terms import extra_rhs       # data terms at the current t (solver.py:845 advances t last)
             self.dev.set_mms(*extra_rhs(self))
         self._t_now = float(t)              # time-dependent sources see the t of this step (solver.py:845 advances t last)
+        first = k == 0 and os.environ.get("KNP_DEBUG_SETUP", "0") == "1"       # what the very first step spends on one-time work
+        if first:
+            self.dev.sync(); _abi._stamp("first step: start")
         self.solve_emi()                    # step I
+        if first:
+            self.dev.sync(); _abi._stamp("first step: EMI solve (block-Jacobi build, smoother trial, graph capture)")
         self.solve_knp()                    # step II
+        if first:
+            self.dev.sync(); _abi._stamp("first step: KNP solve")
         self.dev.step_updates()             # step III: c_prev <- c, phi_M, E_k, c_elim
+        if first:
+            self.dev.sync(); _abi._stamp("first step: step III")
         t.assign(float(t + self.dt))
         return
 

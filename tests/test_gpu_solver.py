@@ -786,3 +786,36 @@ def test_f_source_array_and_callable_vs_oracle(hip_lib, dim, degree):
             if np.abs(d_ref).max() > 0:          # the source is 1e-3 ... 1e-5 of the mass term: 1e-11 of the total = 1e-6 of its own size
                 assert relerr(got[k] - base[k].ravel(), d_ref) < 1e-6
     S.dev.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dim,degree", [(2, 1), (3, 1), (3, 2)])
+def test_knp_load_measure_matches_host_formula(hip_lib, dim, degree, monkeypatch):
+    """knp_knp_load_measure (the device pass that scales the EMI residual target, knpemidg/solver.py: _knp_load_norm): sums of
+    (|b_K| / vol_K)^8 -- or |b_K|^2 / vol_K with KNP_KNP_NORM2=1 -- over the cells of the KNP right-hand side, against numpy on the
+    downloaded field (1 / vol is stored in fp32 on the device: 1e-6)."""
+    from common_examples import make_solver, solver_parameters
+    from knpemidg.mesh import make_mesh_2D
+    from knpemidg import _abi
+    mt = make_mesh_2D(0) if dim == 2 else small_3d((6, 3, 3))
+    S = make_solver(dim=dim, resolution=0, n_axons=1, mesh_tuple=mt, degree=degree)
+    S._unpack_solver_params(solver_parameters(dim, 0))
+    S.splitting_scheme = True
+    S.setup_varform_emi(); S.setup_varform_knp()
+    dev = S.dev
+    dev.update_dnphi(); dev.knp_rhs()
+    b = dev.download(_abi.F_B_KNP).reshape(S.N_ions, S.mesh.num_cells(), S.nd)
+    x = S.mesh.coords[S.mesh.cells]
+    vol = np.abs(np.linalg.det(x[:, 1:] - x[:, :1])) / (2.0 if dim == 2 else 6.0)
+    bK2 = (b ** 2).sum(axis=2)
+    want8 = ((bK2 / vol[None, :] ** 2) ** 4).sum(axis=1)
+    got8 = dev.knp_load_measure()
+    assert got8.shape == (S.N_ions,) and np.all(want8 > 0)
+    assert np.abs(got8 / want8 - 1.0).max() < 1e-5                   # eight powers of the fp32 weight
+    monkeypatch.setenv("KNP_KNP_NORM2", "1")
+    got2 = dev.knp_load_measure()
+    assert np.abs(got2 / (bK2 / vol[None, :]).sum(axis=1) - 1.0).max() < 1e-6
+    monkeypatch.delenv("KNP_KNP_NORM2")
+    # and the solver's target uses it
+    z = np.abs([float(ion['z']) for ion in S.ion_list[:-1]])
+    assert abs(S._knp_load_norm() / float(np.min(z * want8 ** 0.125)) - 1.0) < 1e-6

@@ -458,3 +458,82 @@ def test_native_setup_kernels_match_numpy():
     blk = cs.cell_blocks(kappa)
     want = np.add.reduceat(blk.ravel()[o], starts)
     assert np.abs(A.data - want).max() < 1e-15 * np.abs(want).max()             # the same sums up to their order
+
+
+def test_native_mesh_and_hierarchy_kernels_match_numpy(monkeypatch):
+    """More host kernels of the library (csrc/host_sparse.cpp) against the numpy passes they replace, on the 124 416-tet mesh: the Morton
+    orders of cells and vertices and the median cell extent (identical), the box tags of the mesh generator (identical), the neighbour
+    table behind the geometry classes (identical), the distance-2 MIS aggregation (identical aggregates) and the mirrored fp32 coarse
+    inverse (identical to tril + transpose + astype)."""
+    import build as _b
+    _b.build()
+    from knpemidg import _abi, amg
+    from knpemidg import mesh as M
+    m, s, f = M.make_mesh_3D(1)
+    nc = m.num_cells()
+    lib = _abi.load()
+    # Morton orders
+    xc = m.coords[m.cells]
+    scale = np.maximum(np.median(xc.max(axis=1) - xc.min(axis=1), axis=0), 1e-300)
+    sc = np.empty(3)
+    co, cl = np.ascontiguousarray(m.coords), np.ascontiguousarray(m.cells, dtype=np.int32)
+    assert lib.knp_host_cell_extent_median(nc, 4, 3, _abi._p(co, _abi._f64p), _abi._p(cl, _abi._i32p), _abi._p(sc, _abi._f64p)) == 0
+    assert np.array_equal(sc, scale)
+    monkeypatch.setenv("KNP_SETUP_NATIVE_MORTON", "0")
+    o_np, v_np = _abi.morton_order(m.cell_midpoints(), scale), _abi.morton_order(m.coords, scale)
+    monkeypatch.setenv("KNP_SETUP_NATIVE_MORTON", "1")
+    assert np.array_equal(_abi._morton_native(co, cl, scale), o_np)
+    assert np.array_equal(_abi.morton_order(m.cell_midpoints(), scale), o_np)      # through the public function (points given)
+    assert np.array_equal(_abi._morton_native(co, None, scale), v_np)
+    # box tags of the generator
+    keep = M._box_marks_native
+    M._box_marks_native = lambda *a: (None, None)
+    try:
+        m0, s0, f0 = M.make_mesh_3D(1)
+    finally:
+        M._box_marks_native = keep
+    assert np.array_equal(s0.array(), s.array()) and np.array_equal(f0.array(), f.array()) and np.array_equal(m0.cells, m.cells)
+    # neighbour table
+    fc, fl, cf = m.facet_cells, m.facet_local.astype(np.int64), m.cell_facets
+    side = (fc[cf, 0] != np.arange(nc)[:, None]).astype(np.int64)
+    nb = np.take_along_axis(fc[cf], (1 - side)[:, :, None], axis=2)[:, :, 0]
+    nj = np.take_along_axis(fl[cf], (1 - side)[:, :, None], axis=2)[:, :, 0]
+    nb2, nj2 = np.empty((nc, 4), np.int32), np.empty((nc, 4), np.int8)
+    assert lib.knp_host_cell_neighbours(nc, 4, _abi._p(np.ascontiguousarray(cf, dtype=np.int32), _abi._i32p),
+                                        _abi._p(np.ascontiguousarray(fc, dtype=np.int32), _abi._i32p),
+                                        _abi._p(np.ascontiguousarray(m.facet_local, dtype=np.int8), _abi._i8p), _abi._p(nb2, _abi._i32p),
+                                        _abi._p(nj2, _abi._i8p), 0) == 0
+    assert np.array_equal(nb, nb2) and np.array_equal(nj, nj2)
+    # MIS-2 aggregation on the strength graph of the conforming operator
+    cs = amg.ConformingSpace(m, f.array(), (1, 2))
+    A = cs.stiffness(np.ones((nc, 4))).tocsr()
+    A.setdiag(0.0)
+    A.eliminate_zeros()
+    S = (abs(A) > 0).astype(np.float64).tocsr()
+    S.sort_indices()
+    assert S.shape[0] >= 20000
+    a1, n1 = amg.mis2_aggregate(S, seed=1)
+    monkeypatch.setenv("KNP_SETUP_NATIVE_MIS2", "0")
+    a0, n0 = amg.mis2_aggregate(S, seed=1)
+    assert n0 == n1 and np.array_equal(a0, a1) and a1.min() == 0 and len(np.unique(a1)) == n1
+    # mirrored + rounded coarse inverse
+    rng = np.random.default_rng(2)
+    N = 300
+    Mf = np.asfortranarray(rng.standard_normal((N, N)))
+    L = np.tril(Mf)
+    want = (L + L.T)
+    want[np.diag_indices(N)] *= 0.5
+    got, mx = amg._mirror_round(Mf)
+    assert got.dtype == np.float32 and np.array_equal(got, want.astype(np.float32)) and mx == np.abs(want).max()
+    Mf[7, 3] = np.nan
+    assert not (amg._mirror_round(Mf)[1] <= 1e300)
+    # the deflated coarse inverse itself: pseudo-inverse of a singular graph Laplacian
+    import scipy.sparse as sp
+    n = 400
+    i = np.arange(n - 1)
+    W = sp.coo_matrix((rng.uniform(0.5, 2.0, n - 1), (i, i + 1)), shape=(n, n))
+    W = (W + W.T).tocsr()
+    Lap = (sp.diags(np.asarray(W.sum(axis=1)).ravel()) - W).tocsr()
+    P = amg._coarse_pseudo_inverse(Lap, np.ones(n))
+    ref = np.linalg.pinv(Lap.toarray(), hermitian=True)
+    assert P.dtype == np.float32 and np.array_equal(P, P.T) and np.abs(P - ref).max() < 1e-6 * np.abs(ref).max()
