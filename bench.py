@@ -109,7 +109,12 @@ def cpu_baseline(resolution=1):
         from threadpoolctl import threadpool_limits
         with threadpool_limits(limits=1):                 # BLAS / LAPACK pinned to one thread: `cores` = 1 is what really ran
             return _cpu_baseline_one_core(resolution)
-    return _cpu_baseline_parallel(resolution, cores)
+    # BLAS pinned to one thread: left alone, OpenBLAS starts one thread per LOGICAL core of the host (256 on the GPU boxes) for every small
+    # dense product of the preconditioner and the solves spend their time in thread management (solves of the r=1 step: 4.3 s with 256
+    # BLAS threads, 1.2 s with 16, 0.94 s with 1).  KNP_CPU_BASELINE_BLAS overrides; assembly processes and SpMV threads are `cores` either way.
+    from threadpoolctl import threadpool_limits
+    with threadpool_limits(limits=int(os.environ.get("KNP_CPU_BASELINE_BLAS", 1))):
+        return _cpu_baseline_parallel(resolution, cores)
 
 
 def _cpu_baseline_parallel(resolution, cores):
@@ -206,7 +211,7 @@ def _cpu_baseline_parallel(resolution, cores):
             "assemble_s": t_ass_emi + t_ass_knp, "solve_s": t_sol_emi + t_sol_knp, "ode_s": t_ode, "precond_setup_s": t_setup,
             "emi_iters": it_emi[0], "knp_iters": it_knp,
             "sample": "ONE splitting step on the 4-axon mesh r=%d (%d tets, %d P1-DG DoFs), %.1f s: CSR assembly by %d processes, one x-slab "
-                      "each, %.1f s + scipy CG rtol 1e-5 (%d its) / GMRES(30) rtol 1e-7 (%s its) with %d-thread sparse products %.1f s, "
+                      "each, %.1f s + scipy CG rtol 1e-5 (%d its) / GMRES(30) rtol 1e-7 (%s its) with %d-thread sparse products (BLAS pinned to one thread) %.1f s, "
                       "preconditioned with the product's auxiliary-space AMG hierarchy applied in numpy (its one-off setup, %.1f s, and "
                       "the workers' start-up are not in the step), membrane ODEs by LSODA %.1f s (one process); %d of the host's %d cores; "
                       "CPU restatement, not FEniCS"
@@ -446,8 +451,10 @@ def main():
     # FP64 vector instructions per cell of the two apply kernels (static counts from the gfx950 ISA, loops fully unrolled: DESIGN.md
     # sections 4.0 / 4b) against the chip's FP64 issue peak, 256 CUs x 4 SIMDs x 16 lanes per cycle at 2.4 GHz: the second roofline
     # of these kernels (the P2 applies are bound by it, the P1 ring-staged applies sit between it and the HBM one)
-    fp64_per_cell = {"k_emi_apply_ring": 542, "k_knp_apply_ring<2>": 435, "k_emi_apply_p2<3,256,true>": 2755,
-                     "k_knp_apply_p2<3,256,true>": 2 * 2304}
+    # (tools/count_fp64.py prints them from the current sources; the DG-P2 KNP kernel runs one species per pass: 2 x 2304)
+    fp64_per_cell = {"k_emi_apply_ring": 542, "k_knp_apply_ring<2>": 435, "k_emi_apply_p2<3,256,true>": 2035,
+                     "k_knp_apply_p2<3,256,true>": 2 * 2304, "k_emi_apply_ring_u": 636, "k_knp_apply_ring_u<2>": 684,
+                     "k_emi_apply_p2<3,256,false>": 2264, "k_knp_apply_p2<3,256,false>": 2 * 2533}
     FP64_PEAK_TINST = 256 * 4 * 16 * 2.4e9 / 1e12
 
     def fp64_issue(name, ms):
@@ -492,10 +499,12 @@ def main():
                                    ("3D idealized 4-axon mesh r=%d (%d tets, %d P%d-DG DoFs: phi + K,Cl solved, Na eliminated), "
                                     "HH membranes + stimulus, full splitting step" % (r, nc_global, dofs, args.degree)),
                        "parallelism": ("rcb%d" if emix else "slab%d") % world,
-                       "cpu_baseline_workload": "the same mesh family at r=1 (124 416 tets, 1 492 992 DoFs), ONE step, one thread -- NOT the GPU "
-                                                "line's r=%d mesh: one oracle step at r=2 is ~70 s of assembly + solves, beyond the bounded "
-                                                "sample the default run may spend" % r,
-                       "preconditioner": ("cell-block-Jacobi + conforming-P%d auxiliary space, smoothed-aggregation AMG V-cycle" % args.degree) if S.use_amg
+                       "cpu_baseline_workload": "the same mesh family at r=1 (124 416 tets, 1 492 992 DoFs), ONE step on cpu_baseline.cores host "
+                                                "cores -- NOT the GPU line's r=%d mesh: one oracle step at r=2 is ~70 s of assembly + solves "
+                                                "on one core, beyond the bounded sample the default run may spend" % r,
+                       "preconditioner": ("cell-block-Jacobi + conforming-P%d auxiliary space, smoothed-aggregation AMG V-cycle; block inverses, level "
+                                          "matrices and coarse inverse stored in fp32, vectors / operator applies / stopping tests in fp64"
+                                          % args.degree) if S.use_amg
                        else "cell-block-Jacobi",
                        "emi_iters_per_step": float(np.mean(its_emi)), "knp_iters_per_step": float(np.mean(its_knp)),
                        # host wall time of the phases over the TIMED steps only (each phase ends in a device sync)

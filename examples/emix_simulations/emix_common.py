@@ -105,14 +105,18 @@ def solver_parameters(**extra):
 def make_solver(dt=0.1, degree=1, verbose=False, mesh_tuple=None, refine=0):
     from knpemidg import setup_worker
     setup_worker.prestart(2)           # the hierarchy helpers start importing now, while the mesh is being built
+    from knpemidg import _abi
+    _abi._stamp("make_solver: start")
     params, ion_list, stim = physical_setup(dt)
     mesh, subdomains, surfaces = mesh_tuple or load_mesh(refine=refine)
+    _abi._stamp("make_solver: mesh loaded")
     S = SolverEMIx(params, ion_list, degree_emi=degree, degree_knp=degree)
     S.verbose = verbose
     S.setup_domain(mesh, subdomains, surfaces)
     S.setup_parameters()
     S.setup_FEM_spaces()
     S.setup_membrane_model(stim, {1: mm_glial, 2: mm_hh_emix})                           # run_EMIx_simulation.py:249
+    _abi._stamp("make_solver: membrane models attached")
     return S
 
 

@@ -9,7 +9,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libknpemi_hip.so")
+# KNP_LIB_PATH: another build of the same library (A/B runs of a kernel variant, tools/build_variant.sh); the product is the in-tree one
+LIB_PATH = os.environ.get("KNP_LIB_PATH") or os.path.join(_HERE, "libknpemi_hip.so")
 
 # enum knp_field (include/knpemi_hip.h)
 F_PHI, F_C, F_C_PREV, F_C_ELIM, F_PHI_M, F_I_CH, F_E, F_KAPPA, F_DNPHI, F_B_EMI, F_B_KNP, F_X, F_Y, \
