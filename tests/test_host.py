@@ -537,3 +537,34 @@ def test_native_mesh_and_hierarchy_kernels_match_numpy(monkeypatch):
     P = amg._coarse_pseudo_inverse(Lap, np.ones(n))
     ref = np.linalg.pinv(Lap.toarray(), hermitian=True)
     assert P.dtype == np.float32 and np.array_equal(P, P.T) and np.abs(P - ref).max() < 1e-6 * np.abs(ref).max()
+
+
+def test_native_mesh_kernels_on_a_large_2d_mesh(monkeypatch):
+    """The same host kernels in 2D (63 488 triangles: above the size from which the native paths are taken): facet table, box tags and
+    Morton order identical to the numpy code."""
+    import build as _b
+    _b.build()
+    from knpemidg import _abi
+    from knpemidg import mesh as M
+    m1 = M.make_mesh_2D(4)
+    keep, nat = M._box_marks_native, M.Mesh._build_facets_native
+    M._box_marks_native = lambda *a: (None, None)
+    M.Mesh._build_facets_native = lambda self: False
+    try:
+        m0 = M.make_mesh_2D(4)
+    finally:
+        M._box_marks_native, M.Mesh._build_facets_native = keep, nat
+    assert m1[0].num_cells() == 63488
+    for a in ("cells", "facets", "facet_cells", "facet_local", "cell_facets"):
+        assert np.array_equal(getattr(m0[0], a), getattr(m1[0], a)), a
+    assert np.array_equal(m0[1].array(), m1[1].array()) and np.array_equal(m0[2].array(), m1[2].array())
+    mesh = m1[0]
+    xc = mesh.coords[mesh.cells]
+    scale = np.maximum(np.median(xc.max(axis=1) - xc.min(axis=1), axis=0), 1e-300)
+    monkeypatch.setenv("KNP_SETUP_NATIVE_MORTON", "0")
+    o0 = _abi.morton_order(mesh.cell_midpoints(), scale)
+    monkeypatch.setenv("KNP_SETUP_NATIVE_MORTON", "1")
+    co, cl = np.ascontiguousarray(mesh.coords), np.ascontiguousarray(mesh.cells, dtype=np.int32)
+    sc = np.empty(2)
+    assert _abi.load().knp_host_cell_extent_median(mesh.num_cells(), 3, 2, _abi._p(co, _abi._f64p), _abi._p(cl, _abi._i32p), _abi._p(sc, _abi._f64p)) == 0
+    assert np.array_equal(sc, scale) and np.array_equal(_abi._morton_native(co, cl, scale), o0)
