@@ -174,6 +174,11 @@ int knp_knp_rhs(knp_ctx* ctx);             /* B_KNP <- L_knp(C, C_PREV, C_ELIM, 
  * knp_emi_residual_target: r_abs > 0 arms the error-controlled stop above for the following EMI solves; 0 restores PETSc's test.
  *      Every rank of a partitioned run must pass the same number (knp_allreduce_sum). */
 int knp_emi_residual_target(knp_ctx* ctx, double r_abs);
+/* knp_knp_early_stop: factor in [0, 1); 0 (the state after knp_ctx_create) = a BiCGStab solve never stops before `min_it` iterations.  With
+ * factor > 0 it also stops as soon as its residual is `factor` times UNDER the tolerance -- the floor exists to keep the per-step errors of a
+ * quiet phase (the extrapolated initial guess already passes the test) far below the tolerance, which such a residual does by itself.
+ * (GMRES keeps the plain floor.)  knpemidg.Solver sets 0.01 (`solver_params.knp_early_stop`). */
+int knp_knp_early_stop(knp_ctx* ctx, double factor);
 /* knp_knp_load_measure: out[k] = sum over this context's owned cells of (|b_K| / vol_K)^8 of the KNP right-hand side of species k (field B_KNP
  * as knp_knp_rhs left it; with KNP_KNP_NORM2=1: |b_K|^2 / vol_K) -- the size of the load the residual target above is scaled with
  * (knpemidg/solver.py: _knp_load_norm sums over the ranks and takes the root).  Replaces a host pass over the downloaded field. */

@@ -704,6 +704,12 @@ int knp_emi_residual_target(knp_ctx* c, double r_abs) {
     return 0;
 }
 
+int knp_knp_early_stop(knp_ctx* c, double factor) {
+    if (!c || !(factor >= 0.0) || factor >= 1.0) { if (c) c->err = "knp_knp_early_stop: factor must be in [0, 1)"; return -1; }
+    c->knp_early = factor;
+    return 0;
+}
+
 int knp_knp_load_measure(knp_ctx* c, double* out) {
     if (!c || !out) return -1;
     Fields* f = F(c);

@@ -126,6 +126,7 @@ struct knp_ctx {
     double* gm_V = nullptr;        // GMRES basis, allocated at the first GMRES solve
     int gm_alloc = 0;              // basis vectors allocated
     int last_it_emi = 0, last_it_knp = 0;   // iteration counts of the previous solves (chunking of the status polls)
+    double knp_early = 0.0;                 // knp_knp_early_stop: a residual this factor under the tolerance ends a BiCGStab solve before min_it
     float last_peclet = -1.0f;              // cell Peclet number of the drift seen by the last status poll (< 0: not read yet)
     // auxiliary-space AMG hierarchies: [0] EMI, [1 + k] KNP species k
     std::vector<AmgHierarchy> amg;

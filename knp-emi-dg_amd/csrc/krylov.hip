@@ -369,6 +369,10 @@ __device__ void scalar_op(int op, double* S, const double* R, int* flag, int* it
             S[KS_RES] = norm8 ? pow(R[1], 0.125) : sqrt(R[1]);
             *iter += 1;
             if (S[KS_RES] <= S[KS_TOL] && *iter >= min_it) { *flag = 1; break; }
+            // below the floor of min_it iterations: a residual `rabs` (< 1; knp_knp_early_stop) times under the tolerance ends the solve as well.
+            // The floor keeps the per-step errors of a quiet phase (extrapolated guesses pass the test untouched and their errors pile
+            // up) far below the tolerance; a residual that far below it already does the same.
+            if (rabs > 0.0 && S[KS_RES] <= rabs * S[KS_TOL]) { *flag = 1; break; }
             if (!(S[KS_RES] == S[KS_RES])) { *flag = 3; break; }
             if (R[0] == 0.0 || S[KS_OMEGA] == 0.0) { *flag = (S[KS_RES] <= S[KS_TOL]) ? 1 : 2; break; }
             S[KS_BETA] = (R[0] / S[KS_RHO]) * (S[KS_ALPHA] / S[KS_OMEGA]);
@@ -1216,7 +1220,7 @@ static int bicgstab_impl(knp_ctx* c, KrylovVecs& kv, double rtol, double atol, i
             if ((rc = finalize(c, OP_BI_OMEGA, ns, 2, rtol, atol, min_it))) return rc;
             hipLaunchKernelGGL(k_bi_x<NV>, g, b, 0, c->stream, d, c->scal, c->status, kv.y, kv.z, kv.w, kv.rhat, kv.x, kv.r,
                                c->partial);
-            if ((rc = finalize(c, OP_BI_RHO, ns, 2, rtol, atol, min_it, 0.0, d.d8))) return rc;
+            if ((rc = finalize(c, OP_BI_RHO, ns, 2, rtol, atol, min_it, c->knp_early, d.d8))) return rc;
         }
         it += chunk;
         if ((rc = poll_status(c, ns, hs))) return rc;

@@ -53,6 +53,7 @@ SIGNATURES = {
     "knp_knp_rhs": (C.c_int, [_ctxp]),
     "knp_emi_residual_target": (C.c_int, [_ctxp, C.c_double]),
     "knp_knp_load_measure": (C.c_int, [_ctxp, _f64p]),
+    "knp_knp_early_stop": (C.c_int, [_ctxp, C.c_double]),
     "knp_emi_solve": (C.c_int, [_ctxp, C.c_double, C.c_double, C.c_int, C.c_int, C.POINTER(C.c_int), _f64p]),
     "knp_knp_solve": (C.c_int, [_ctxp, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), _f64p]),
     "knp_set_knp_krylov": (C.c_int, [_ctxp, C.c_int, C.c_int]),
@@ -814,6 +815,9 @@ class Device:
         v = np.ascontiguousarray(np.asarray(values, dtype=np.float64).ravel())
         self._chk(self.lib.knp_allreduce_sum(self.ctx, _p(v, _f64p), len(v)), "knp_allreduce_sum")
         return v
+
+    def knp_early_stop(self, factor):
+        self._chk(self.lib.knp_knp_early_stop(self.ctx, float(factor)), "knp_knp_early_stop")
 
     def knp_load_measure(self):
         """Per solved species: sum over the owned cells of (|b_K| / vol_K)^8 of the current KNP right-hand side (knp_knp_load_measure)."""

@@ -68,6 +68,38 @@ def test_knp_solve(case):
     assert all(n >= 5 for n in niter)          # ksp_min_it 5 (solver.py:686)
 
 
+def test_knp_early_stop_below_the_iteration_floor(case):
+    """knp_knp_early_stop: from a converged state a BiCGStab solve runs its floor of min_it iterations with factor 0 (the reference's
+    ksp_min_it, solver.py:686) and stops after ONE iteration when its residual is already the factor under the tolerance; a solve
+    that is not that far converges as before; factors outside [0, 1) are refused."""
+    pb, dev, A = case
+    ko.solve_emi(pb, direct=True)
+    dev.upload(A.F_PHI, pb.phi)
+    dev.update_dnphi()
+    dev.knp_rhs()
+    dev.knp_solve(1e-13, maxit=5000)
+    c_ref = dev.download(A.F_C)
+    near = c_ref * (1.0 + 1e-10 * np.random.default_rng(7).uniform(-1.0, 1.0, size=c_ref.shape))    # a quiet step's initial guess
+    dev.upload(A.F_C, near)
+    dev.knp_early_stop(0.0)
+    niter, res = dev.knp_solve(1e-6, maxit=100, min_it=5)
+    assert all(n == 5 for n in niter), (niter, res)
+    dev.upload(A.F_C, near)
+    dev.knp_early_stop(0.01)
+    niter, res = dev.knp_solve(1e-6, maxit=100, min_it=5)
+    assert all(n == 1 for n in niter), (niter, res)
+    assert np.all(res[:, 1] <= 0.01 * 20.0 * 1e-6 * res[:, 2])         # 20: the device's factor on the order-8 density test (csrc/abi.hip)
+    assert relerr(dev.download(A.F_C), c_ref) < 1e-9
+    # not yet 100x under the tolerance after the first iteration: the solve goes on as before
+    dev.upload(A.F_C, c_ref * (1.0 + 1e-3 * np.random.default_rng(8).uniform(-1.0, 1.0, size=c_ref.shape)))
+    niter, res = dev.knp_solve(1e-6, maxit=100, min_it=5)
+    assert all(n >= 2 for n in niter) and np.all(res[:, 1] <= 20.0 * 1e-6 * res[:, 2]), (niter, res)
+    with pytest.raises(A.KnpError):
+        dev.knp_early_stop(1.5)
+    dev.knp_early_stop(0.0)
+    dev.upload(A.F_C, pb.c)                               # the fixture's state for the tests behind this one
+
+
 @pytest.mark.parametrize("restart", [30, 8])
 def test_knp_solve_gmres(case, restart):
     """The reference's KNP Krylov method, restarted GMRES (ksp_type gmres, restart 30: solver.py:684-701), on the device: same
