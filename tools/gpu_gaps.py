@@ -12,7 +12,7 @@ t0, t1 = ks[0][0], max(k[1] for k in ks)
 busy, end, gaps = 0, ks[0][0], []
 for s, e, n in ks:
     if s > end:
-        gaps.append((s - end, prev))
+        gaps.append((s - end, prev, n))
         busy += e - s
         end = e
     else:
@@ -22,14 +22,15 @@ for s, e, n in ks:
 wall = t1 - t0
 print("kernels %d  wall %.2f ms  busy %.2f ms = %.1f %%" % (len(ks), wall / 1e6, busy / 1e6, 100.0 * busy / wall))
 for lo, hi in ((0, 2000), (2000, 5000), (5000, 20000), (20000, 100000), (100000, 10 ** 12)):
-    g = [d for d, _ in gaps if lo <= d < hi]
+    g = [d for d, _, _ in gaps if lo <= d < hi]
     print("  gaps %6.0f-%-8.0f us: %6d  total %.2f ms" % (lo / 1e3, hi / 1e3, len(g), sum(g) / 1e6))
 c = collections.Counter()
 tsum = collections.Counter()
-for d, n in gaps:
+short = lambda n: n.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:40]
+for d, n, nxt in gaps:
     if d > 5000:
-        key = n.split("(")[0][-60:]
+        key = short(n) + " -> " + short(nxt)
         c[key] += 1
         tsum[key] += d
 for k, v in tsum.most_common(12):
-    print("  before a gap > 5 us: %-62s %5d x  %.2f ms" % (k, c[k], v / 1e6))
+    print("  gap > 5 us between: %-84s %5d x  %.2f ms" % (k, c[k], v / 1e6))
