@@ -13,6 +13,72 @@ import sys
 import types
 
 
+# ---- transport of jobs and results ------------------------------------------------------------------------------------------------
+# The job of the r=3 mesh is 830 MB of arrays and its result 690 MB: pickled through the pipes that was 0.9 + 0.7 s (two copies in the
+# pickle, two through the 64 KB pipe buffer).  The arrays now travel OUT OF BAND (pickle protocol 5): the sender writes them once into a
+# file under /dev/shm, the pipe carries the small pickle with the file's name, and the receiver maps the file copy-on-write and
+# unlinks it -- its arrays are views of the mapping.  No /dev/shm (or any failure on the way): everything in band, as before.
+_SHM_DIR = "/dev/shm"
+_SHM_MIN = 1 << 20            # payloads below 1 MB stay in band
+_SHM_ALIGN = 64
+_shm_made = []                # files this process wrote and whose receiver may not have unlinked yet (removed at exit)
+_shm_count = [0]
+
+
+def _dump(obj, out):
+    bufs = []
+    try:
+        payload = pickle.dumps(obj, protocol=5, buffer_callback=bufs.append)
+        raws = [b.raw() for b in bufs]
+        total = sum(r.nbytes for r in raws)
+        if total < _SHM_MIN or not os.path.isdir(_SHM_DIR) or os.environ.get("KNP_SETUP_NO_SHM", "0") == "1":
+            raise OSError("in band")
+        if not _shm_made:
+            import atexit
+            atexit.register(_shm_cleanup)
+        name = os.path.join(_SHM_DIR, "knp_setup_%d_%d" % (os.getpid(), _shm_count[0]))
+        _shm_count[0] += 1
+        with open(name, "wb") as f:
+            _shm_made.append(name)
+            for r in raws:
+                f.write(r)
+                f.write(b"\0" * (-r.nbytes % _SHM_ALIGN))                 # every array starts on a 64-byte boundary of the mapping
+        head = {"payload": payload, "file": name, "sizes": [r.nbytes for r in raws]}
+    except (OSError, ValueError, BufferError):
+        head = {"inband": pickle.dumps(obj, protocol=pickle.HIGHEST_PROTOCOL)}
+    pickle.dump(head, out, protocol=pickle.HIGHEST_PROTOCOL)
+    out.flush()
+
+
+def _load(inp):
+    head = pickle.load(inp)
+    if "inband" in head:
+        return pickle.loads(head["inband"])
+    import mmap
+    name, sizes = head["file"], head["sizes"]
+    try:
+        with open(name, "rb") as f:
+            mm = mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_COPY) if sum(sizes) else None     # private, writable: in-place edits stay local
+    finally:
+        try:
+            os.unlink(name)
+        except OSError:
+            pass
+    view, off, bufs = memoryview(mm) if mm is not None else memoryview(b""), 0, []
+    for n in sizes:
+        bufs.append(view[off:off + n])
+        off += n + (-n % _SHM_ALIGN)
+    return pickle.loads(head["payload"], buffers=bufs)
+
+
+def _shm_cleanup():
+    while _shm_made:
+        try:
+            os.unlink(_shm_made.pop())
+        except OSError:
+            pass
+
+
 def mesh_stub(coords, cells, facet_cells, facets=None, facet_local=None):
     """The attributes of a Mesh that the conforming spaces read (facets / facet_local: only the membrane term of the EMI operator)."""
     m = types.SimpleNamespace(coords=coords, cells=cells, facet_cells=facet_cells, facets=facets, facet_local=facet_local,
@@ -58,19 +124,25 @@ def main():
         except Exception:
             pass
         _abi._stamp("helper: modules imported, waiting for the job")
-        job = pickle.load(sys.stdin.buffer)
+        job = _load(sys.stdin.buffer)
         _abi._stamp("helper: job received (%s)" % job.get("kind", "knp"))
         res = {"groups": run(job)}
         _abi._stamp("helper: hierarchy built (%s)" % job.get("kind", "knp"))
     except BaseException as e:                    # reported to the parent, which falls back to building in-process
         import traceback
         res = {"error": "%s\n%s" % (e, traceback.format_exc())}
-    pickle.dump(res, out, protocol=pickle.HIGHEST_PROTOCOL)
-    out.flush()
+    _dump(res, out)
     try:
         _abi._stamp("helper: result sent")
     except Exception:
         pass
+    # the parent unlinks the result file once it has mapped it; should it die first, the file goes when this process is reaped
+    # (kill -> no atexit), so wait for the pipe to close before leaving
+    try:
+        sys.stdin.buffer.read()
+    except Exception:
+        pass
+    _shm_cleanup()
 
 
 _IDLE = []          # helper processes started ahead of time, waiting for a job on stdin
@@ -112,6 +184,7 @@ def prestart(n=2):
 
 
 def _reap():
+    _shm_cleanup()
     while _IDLE:
         p = _IDLE.pop()
         try:
@@ -136,16 +209,17 @@ def start(job):
 
     def feed():
         try:
-            pickle.dump(job, proc.stdin, protocol=pickle.HIGHEST_PROTOCOL)
-            proc.stdin.close()
-            handle["result"] = pickle.load(proc.stdout)
+            _dump(job, proc.stdin)
+            handle["result"] = _load(proc.stdout)
+            proc.stdin.close()                              # the helper waits for this before it removes what it wrote and leaves
         except BaseException as e:
             handle["result"] = {"error": "helper process: %r" % (e,)}
         finally:
-            try:
-                proc.stdout.close()
-            except OSError:
-                pass
+            for pipe in (proc.stdin, proc.stdout):          # stdin first: the helper leaves when it sees it closed
+                try:
+                    pipe.close()
+                except OSError:
+                    pass
             proc.wait()
     th = threading.Thread(target=feed, name="knp-amg-helper-io", daemon=True)
     th.start()

@@ -568,3 +568,50 @@ def test_native_mesh_kernels_on_a_large_2d_mesh(monkeypatch):
     sc = np.empty(2)
     assert _abi.load().knp_host_cell_extent_median(mesh.num_cells(), 3, 2, _abi._p(co, _abi._f64p), _abi._p(cl, _abi._i32p), _abi._p(sc, _abi._f64p)) == 0
     assert np.array_equal(sc, scale) and np.array_equal(_abi._morton_native(co, cl, scale), o0)
+
+
+def test_helper_transport_out_of_band_and_in_band(monkeypatch):
+    """knpemidg/setup_worker.py: jobs and results travel as a small pickle + one file of array bytes under /dev/shm (pickle protocol 5,
+    out-of-band buffers, mapped copy-on-write by the receiver and unlinked at once); in band when /dev/shm is not there, when switched off,
+    or for small payloads.  Same objects either way, 64-byte aligned and writable arrays, nothing left behind."""
+    import glob
+    import io
+    import scipy.sparse as sp
+    from knpemidg import setup_worker as W
+    rng = np.random.default_rng(0)
+    A = sp.random(3000, 3000, density=0.01, random_state=1, format="csr")
+    obj = {"a": rng.standard_normal((70001, 3)), "odd": np.arange(13, dtype=np.int8), "b": rng.integers(0, 9, 250001).astype(np.int32), "A": A,
+           "f32": rng.standard_normal(100003).astype(np.float32), "text": "x", "nested": [np.arange(5), {"k": 1.5}]}
+
+    def same(x, y):
+        assert np.array_equal(x["a"], y["a"]) and np.array_equal(x["odd"], y["odd"]) and np.array_equal(x["b"], y["b"])
+        assert abs(x["A"] - y["A"]).max() == 0 and np.array_equal(x["f32"], y["f32"]) and y["f32"].dtype == np.float32
+        assert y["text"] == "x" and np.array_equal(y["nested"][0], np.arange(5)) and y["nested"][1] == {"k": 1.5}
+    before = set(glob.glob("/dev/shm/knp_setup_*"))
+    buf = io.BytesIO()
+    W._dump(obj, buf)
+    small = buf.tell()
+    buf.seek(0)
+    out = W._load(buf)
+    same(obj, out)
+    if os.path.isdir("/dev/shm"):
+        assert small < 100000                                     # the arrays did not go through the stream
+        for k in ("a", "b", "f32"):
+            assert out[k].ctypes.data % 64 == 0 and out[k].flags.writeable
+        out["a"][0, 0] = 123.0                                     # private mapping: edits stay local
+    assert set(glob.glob("/dev/shm/knp_setup_*")) == before      # the receiver unlinked the file
+    monkeypatch.setenv("KNP_SETUP_NO_SHM", "1")
+    buf = io.BytesIO()
+    W._dump(obj, buf)
+    assert buf.tell() > 1000000
+    buf.seek(0)
+    same(obj, W._load(buf))
+    monkeypatch.delenv("KNP_SETUP_NO_SHM")
+    buf = io.BytesIO()
+    W._dump({"tiny": np.arange(10)}, buf)                        # below 1 MB: in band
+    buf.seek(0)
+    assert np.array_equal(W._load(buf)["tiny"], np.arange(10))
+    # a file nobody picked up is removed by the writer's cleanup
+    W._dump(obj, io.BytesIO())
+    W._shm_cleanup()
+    assert set(glob.glob("/dev/shm/knp_setup_*")) == before
