@@ -311,6 +311,16 @@ int knp_host_cell_neighbours(int64_t nc, int nv, const int32_t* cell_facets, con
 /*  knp_host_box_marks: out[i] = 1 where the midpoint of row i of conn lies in the box [a, b] (mode 0) / on its surface within eps (mode 1) */
 int knp_host_box_marks(int64_t n, int d, const double* coords, const int32_t* conn, int nv, const double* a, const double* b, double eps, int mode,
                        uint8_t* out, int nthreads);
+/*  Smoothed-aggregation passes (knpemidg/amg.py: build_hierarchy), row-parallel, the numbers of the numpy / scipy lines they replace:
+ *  knp_host_strength            : pattern of the strong off-diagonal couplings |a_ij| >= theta sqrt(|a_ii a_jj|)           (*Sj: knp_host_free)
+ *  knp_host_smooth_prolongator  : C = P - diag(v) A P, one damped-Jacobi step on a prolongator, exact zeros dropped         (*Cj, *Cx)
+ *  knp_host_truncate_prolongator: rows cut below trunc * (row maximum) and rescaled to interpolate Bc to the same values    (*Tj, *Tx) */
+int knp_host_strength(int64_t n, const int32_t* Ap, const int32_t* Aj, const double* Ax, const double* diag, double theta, int32_t* Sp, int32_t** Sj,
+                      int nthreads);
+int knp_host_smooth_prolongator(int64_t n, int64_t m, const int32_t* Ap, const int32_t* Aj, const double* Ax, const double* v, const int32_t* Pp,
+                                const int32_t* Pj, const double* Px, int32_t* Cp, int32_t** Cj, double** Cx, int nthreads);
+int knp_host_truncate_prolongator(int64_t n, const int32_t* Pp, const int32_t* Pj, const double* Px, double trunc, const double* Bc, int32_t* Tp,
+                                  int32_t** Tj, double** Tx, int nthreads);
 
 /* ---- timing / sync ------------------------------------------------------------------------------ */
 int knp_sync(knp_ctx* ctx);

@@ -616,4 +616,138 @@ int knp_host_box_marks(int64_t n, int d, const double* coords, const int32_t* co
     });
     return 0;
 }
+// ---- smoothed-aggregation passes of knpemidg/amg.py: build_hierarchy, row-parallel, same arithmetic as the numpy / scipy lines they replace ----
+
+// Strength graph: S keeps the off-diagonal entries of row i with |a_ij| >= theta sqrt(|a_ii a_jj|).  Sp[n + 1] by the caller, *Sj allocated here.
+int knp_host_strength(int64_t n, const int32_t* Ap, const int32_t* Aj, const double* Ax, const double* diag, double theta, int32_t* Sp, int32_t** Sj,
+                      int nthreads) {
+    if (!Ap || !Aj || !Ax || !diag || !Sp || !Sj || n < 0) return -1;
+    if (nthreads <= 0) nthreads = (int)std::max(1u, std::thread::hardware_concurrency());
+    auto strong = [&](int64_t i, int32_t p) {
+        const int32_t j = Aj[p];
+        return j != i && std::fabs(Ax[p]) >= theta * std::sqrt(std::fabs(diag[i] * diag[j]));
+    };
+    std::vector<int32_t> cnt((size_t)n, 0);
+    parallel_rows(n, nthreads, [&](int64_t lo, int64_t hi, int) {
+        for (int64_t i = lo; i < hi; ++i) {
+            int32_t c = 0;
+            for (int32_t p = Ap[i]; p < Ap[i + 1]; ++p) c += strong(i, p) ? 1 : 0;
+            cnt[(size_t)i] = c;
+        }
+    });
+    int64_t nnz = 0;
+    for (int64_t i = 0; i < n; ++i) { Sp[i] = (int32_t)nnz; nnz += cnt[(size_t)i]; if (nnz > 2147483647LL) return -3; }
+    Sp[n] = (int32_t)nnz;
+    *Sj = (int32_t*)std::malloc(sizeof(int32_t) * (size_t)std::max<int64_t>(nnz, 1));
+    if (!*Sj) return -2;
+    int32_t* sj = *Sj;
+    parallel_rows(n, nthreads, [&](int64_t lo, int64_t hi, int) {
+        for (int64_t i = lo; i < hi; ++i) {
+            int32_t o = Sp[i];
+            for (int32_t p = Ap[i]; p < Ap[i + 1]; ++p)
+                if (strong(i, p)) sj[o++] = Aj[p];
+        }
+    });
+    return 0;
+}
+
+// One damped-Jacobi step on a prolongator:  C = P - diag(v) A P  (v = omega / a_ii), entries that come out exactly 0 dropped (scipy's sparse
+// subtraction does), columns sorted.  The products are formed as (v_i a_ik) p_kj and summed in the order of knp_host_spgemm, then subtracted from
+// p_ij -- the numbers of  (P - spgemm(scale_rows(A, v), P)).  A is [n x n], P is [n x m].
+int knp_host_smooth_prolongator(int64_t n, int64_t m, const int32_t* Ap, const int32_t* Aj, const double* Ax, const double* v, const int32_t* Pp,
+                                const int32_t* Pj, const double* Px, int32_t* Cp, int32_t** Cj, double** Cx, int nthreads) {
+    if (!Ap || !Aj || !Ax || !v || !Pp || !Pj || !Px || !Cp || !Cj || !Cx || n < 0 || m < 0) return -1;
+    if (nthreads <= 0) nthreads = (int)std::max(1u, std::thread::hardware_concurrency());
+    // rows are formed once into per-thread buffers (values needed to know which entries vanish), then copied behind a prefix sum
+    std::vector<std::vector<std::pair<int32_t, double>>> rows((size_t)n);
+    parallel_rows(n, nthreads, [&](int64_t lo, int64_t hi, int) {
+        std::vector<int32_t> pos((size_t)m, -1);
+        std::vector<std::pair<int32_t, double>> row;
+        std::vector<uint8_t> inP;
+        for (int64_t i = lo; i < hi; ++i) {
+            row.clear();
+            for (int32_t p = Ap[i]; p < Ap[i + 1]; ++p) {
+                const int32_t k = Aj[p];
+                const double a = Ax[p] * v[i];
+                for (int32_t q = Pp[k]; q < Pp[k + 1]; ++q) {
+                    const int32_t j = Pj[q];
+                    if (pos[j] < 0) { pos[j] = (int32_t)row.size(); row.emplace_back(j, a * Px[q]); }
+                    else row[pos[j]].second += a * Px[q];
+                }
+            }
+            const size_t nprod = row.size();
+            inP.assign(nprod, 0);
+            for (int32_t q = Pp[i]; q < Pp[i + 1]; ++q) {                 // P - (product): entries of P without a product partner stay as they are
+                const int32_t j = Pj[q];
+                if (pos[j] < 0) { pos[j] = (int32_t)row.size(); row.emplace_back(j, Px[q]); }
+                else { row[pos[j]].second = Px[q] - row[pos[j]].second; inP[(size_t)pos[j]] = 1; }
+            }
+            for (size_t e = 0; e < nprod; ++e)
+                if (!inP[e]) row[e].second = -row[e].second;               // 0 - product
+            for (auto& e : row) pos[e.first] = -1;
+            auto& out = rows[(size_t)i];
+            out.reserve(row.size());
+            for (auto& e : row)
+                if (e.second != 0.0) out.push_back(e);
+            std::sort(out.begin(), out.end(), [](const std::pair<int32_t, double>& a_, const std::pair<int32_t, double>& b_) { return a_.first < b_.first; });
+        }
+    });
+    int64_t nnz = 0;
+    for (int64_t i = 0; i < n; ++i) { Cp[i] = (int32_t)nnz; nnz += (int64_t)rows[(size_t)i].size(); if (nnz > 2147483647LL) return -3; }
+    Cp[n] = (int32_t)nnz;
+    *Cj = (int32_t*)std::malloc(sizeof(int32_t) * (size_t)std::max<int64_t>(nnz, 1));
+    *Cx = (double*)std::malloc(sizeof(double) * (size_t)std::max<int64_t>(nnz, 1));
+    if (!*Cj || !*Cx) return -2;
+    int32_t* cj = *Cj;
+    double* cx = *Cx;
+    parallel_rows(n, nthreads, [&](int64_t lo, int64_t hi, int) {
+        for (int64_t i = lo; i < hi; ++i) {
+            int64_t o = Cp[i];
+            for (auto& e : rows[(size_t)i]) { cj[o] = e.first; cx[o] = e.second; ++o; }
+        }
+    });
+    return 0;
+}
+
+// Prolongator truncation: per row keep the entries with |p_ij| >= trunc * max_j |p_ij| and rescale the row so that it still interpolates the
+// coarse vector Bc to the same fine value ((P Bc)_i, sums in storage order as scipy's csr_matvec).  Tp[n + 1] by the caller, *Tj / *Tx allocated here.
+int knp_host_truncate_prolongator(int64_t n, const int32_t* Pp, const int32_t* Pj, const double* Px, double trunc, const double* Bc, int32_t* Tp,
+                                  int32_t** Tj, double** Tx, int nthreads) {
+    if (!Pp || !Pj || !Px || !Bc || !Tp || !Tj || !Tx || n < 0) return -1;
+    if (nthreads <= 0) nthreads = (int)std::max(1u, std::thread::hardware_concurrency());
+    std::vector<double> rowmax((size_t)n, 0.0);
+    std::vector<int32_t> cnt((size_t)n, 0);
+    parallel_rows(n, nthreads, [&](int64_t lo, int64_t hi, int) {
+        for (int64_t i = lo; i < hi; ++i) {
+            double mx = 0.0;
+            for (int32_t p = Pp[i]; p < Pp[i + 1]; ++p) mx = std::max(mx, std::fabs(Px[p]));
+            rowmax[(size_t)i] = mx;
+            int32_t c = 0;
+            for (int32_t p = Pp[i]; p < Pp[i + 1]; ++p) c += std::fabs(Px[p]) >= trunc * mx ? 1 : 0;
+            cnt[(size_t)i] = c;
+        }
+    });
+    int64_t nnz = 0;
+    for (int64_t i = 0; i < n; ++i) { Tp[i] = (int32_t)nnz; nnz += cnt[(size_t)i]; }
+    Tp[n] = (int32_t)nnz;
+    *Tj = (int32_t*)std::malloc(sizeof(int32_t) * (size_t)std::max<int64_t>(nnz, 1));
+    *Tx = (double*)std::malloc(sizeof(double) * (size_t)std::max<int64_t>(nnz, 1));
+    if (!*Tj || !*Tx) return -2;
+    int32_t* tj = *Tj;
+    double* tx = *Tx;
+    parallel_rows(n, nthreads, [&](int64_t lo, int64_t hi, int) {
+        for (int64_t i = lo; i < hi; ++i) {
+            double tgt = 0.0, got = 0.0;
+            int64_t o = Tp[i];
+            const double thr = trunc * rowmax[(size_t)i];
+            for (int32_t p = Pp[i]; p < Pp[i + 1]; ++p) {
+                tgt += Px[p] * Bc[Pj[p]];
+                if (std::fabs(Px[p]) >= thr) { tj[o] = Pj[p]; tx[o] = Px[p]; got += Px[p] * Bc[Pj[p]]; ++o; }
+            }
+            const double scale = std::fabs(got) > 1e-300 ? tgt / (got == 0.0 ? 1.0 : got) : 1.0;
+            for (int64_t q = Tp[i]; q < o; ++q) tx[q] = scale * tx[q];
+        }
+    });
+    return 0;
+}
 }  // extern "C"

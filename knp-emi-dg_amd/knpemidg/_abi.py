@@ -105,6 +105,10 @@ SIGNATURES = {
     "knp_host_cell_extent_median": (C.c_int, [C.c_int64, C.c_int, C.c_int, _f64p, _i32p, _f64p]),
     "knp_host_cell_neighbours": (C.c_int, [C.c_int64, C.c_int, _i32p, _i32p, _i8p, _i32p, _i8p, C.c_int]),
     "knp_host_box_marks": (C.c_int, [C.c_int64, C.c_int, _f64p, _i32p, C.c_int, _f64p, _f64p, C.c_double, C.c_int, C.POINTER(C.c_uint8), C.c_int]),
+    "knp_host_strength": (C.c_int, [C.c_int64, _i32p, _i32p, _f64p, _f64p, C.c_double, _i32p, C.POINTER(_i32p), C.c_int]),
+    "knp_host_smooth_prolongator": (C.c_int, [C.c_int64, C.c_int64, _i32p, _i32p, _f64p, _f64p, _i32p, _i32p, _f64p, _i32p, C.POINTER(_i32p),
+                                            C.POINTER(_f64p), C.c_int]),
+    "knp_host_truncate_prolongator": (C.c_int, [C.c_int64, _i32p, _i32p, _f64p, C.c_double, _f64p, _i32p, C.POINTER(_i32p), C.POINTER(_f64p), C.c_int]),
     "knp_host_mis2_aggregate": (C.c_int64, [C.c_int64, _i32p, _i32p, _f64p, _i64p, C.c_int]),
     "knp_amg_clear": (C.c_int, [_ctxp, C.c_int]),
     "knp_amg_interface": (C.c_int, [_ctxp, C.c_int64, C.c_int, _i32p, _i64p, _i32p, C.c_int64, _i32p, _i32p, _i32p]),

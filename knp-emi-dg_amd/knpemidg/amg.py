@@ -494,6 +494,76 @@ def _spgemm(A, B):
     return _abi.host_spgemm(A, B)
 
 
+def _native_sa(n):
+    """The library's smoothed-aggregation passes for levels of at least 20 000 rows (KNP_SETUP_NATIVE_SA=0: the numpy / scipy lines)."""
+    import os
+    return n >= 20000 and os.environ.get("KNP_SETUP_NATIVE_SA", "1") != "0"
+
+
+def _csr_out(lib, n, m, Cp, cj, cx=None):
+    """scipy CSR from row pointers filled by the library and its malloc'ed column / value arrays (copied, then released)."""
+    from knpemidg import _abi
+    nnz = int(Cp[-1])
+    try:
+        Cj = np.ctypeslib.as_array(cj, shape=(max(nnz, 1),))[:nnz].copy()
+        Cx = np.ones(nnz) if cx is None else np.ctypeslib.as_array(cx, shape=(max(nnz, 1),))[:nnz].copy()
+    finally:
+        lib.knp_host_free(cj)
+        if cx is not None:
+            lib.knp_host_free(cx)
+    out = sp.csr_matrix((Cx, Cj, Cp), shape=(n, m))
+    out.has_sorted_indices = True
+    return out
+
+
+def _csr_in(A):
+    from knpemidg import _abi
+    A = A.tocsr()
+    return (np.ascontiguousarray(A.indptr, dtype=np.int32), np.ascontiguousarray(A.indices, dtype=np.int32),
+            np.ascontiguousarray(A.data, dtype=np.float64))
+
+
+def _strength_native(A, d, theta):
+    from knpemidg import _abi
+    lib = _abi.load()
+    n = A.shape[0]
+    Ap, Aj, Ax = _csr_in(A)
+    dd = np.ascontiguousarray(d, dtype=np.float64)
+    Sp, sj = np.empty(n + 1, dtype=np.int32), _abi._i32p()
+    if lib.knp_host_strength(n, _abi._p(Ap, _abi._i32p), _abi._p(Aj, _abi._i32p), _abi._p(Ax, _abi._f64p), _abi._p(dd, _abi._f64p), float(theta),
+                             _abi._p(Sp, _abi._i32p), _abi.C.byref(sj), _setup_threads()) != 0:
+        return None
+    return _csr_out(lib, n, n, Sp, sj)
+
+
+def _smooth_native(A, v, P):
+    from knpemidg import _abi
+    lib = _abi.load()
+    n, m = P.shape
+    Ap, Aj, Ax = _csr_in(A)
+    Pp, Pj, Px = _csr_in(P)
+    vv = np.ascontiguousarray(v, dtype=np.float64)
+    Cp, cj, cx = np.empty(n + 1, dtype=np.int32), _abi._i32p(), _abi._f64p()
+    if lib.knp_host_smooth_prolongator(n, m, _abi._p(Ap, _abi._i32p), _abi._p(Aj, _abi._i32p), _abi._p(Ax, _abi._f64p), _abi._p(vv, _abi._f64p),
+                                       _abi._p(Pp, _abi._i32p), _abi._p(Pj, _abi._i32p), _abi._p(Px, _abi._f64p), _abi._p(Cp, _abi._i32p),
+                                       _abi.C.byref(cj), _abi.C.byref(cx), _setup_threads()) != 0:
+        return None
+    return _csr_out(lib, n, m, Cp, cj, cx)
+
+
+def _truncate_native(P, trunc, Bc):
+    from knpemidg import _abi
+    lib = _abi.load()
+    n, m = P.shape
+    Pp, Pj, Px = _csr_in(P)
+    bc = np.ascontiguousarray(Bc, dtype=np.float64)
+    Tp, tj, tx = np.empty(n + 1, dtype=np.int32), _abi._i32p(), _abi._f64p()
+    if lib.knp_host_truncate_prolongator(n, _abi._p(Pp, _abi._i32p), _abi._p(Pj, _abi._i32p), _abi._p(Px, _abi._f64p), float(trunc),
+                                         _abi._p(bc, _abi._f64p), _abi._p(Tp, _abi._i32p), _abi.C.byref(tj), _abi.C.byref(tx), _setup_threads()) != 0:
+        return None
+    return _csr_out(lib, n, m, Tp, tj, tx)
+
+
 def _scale_rows(A, v):
     A = A.tocsr()
     return sp.csr_matrix((A.data * np.repeat(v, np.diff(A.indptr)), A.indices, A.indptr), shape=A.shape)
@@ -555,10 +625,13 @@ def build_hierarchy(A, theta=0.08, max_coarse=4000, max_levels=12, cheb_degree=N
             break
         # symmetric strength of connection
         A.sort_indices()
-        rowid = np.repeat(np.arange(n), np.diff(A.indptr))
-        strong = (rowid != A.indices) & (np.abs(A.data) >= theta * np.sqrt(np.abs(d[rowid] * d[A.indices])))
-        S = sp.csr_matrix((np.ones(int(strong.sum())), A.indices[strong],
-                           np.concatenate([[0], np.cumsum(np.bincount(rowid[strong], minlength=n))])), shape=A.shape)
+        native = _native_sa(n)
+        S = _strength_native(A, d, theta) if native else None
+        if S is None:
+            rowid = np.repeat(np.arange(n), np.diff(A.indptr))
+            strong = (rowid != A.indices) & (np.abs(A.data) >= theta * np.sqrt(np.abs(d[rowid] * d[A.indices])))
+            S = sp.csr_matrix((np.ones(int(strong.sum())), A.indices[strong],
+                               np.concatenate([[0], np.cumsum(np.bincount(rowid[strong], minlength=n))])), shape=A.shape)
         agg, nagg = mis2_aggregate(S, seed=len(levels))
         if nagg >= n:
             break
@@ -573,10 +646,18 @@ def build_hierarchy(A, theta=0.08, max_coarse=4000, max_levels=12, cheb_degree=N
         # ~0.25 (CG on Ac: 39 -> 13 iterations at r=1) for 1.8x the operator complexity
         omega = (4.0 / 3.0) / lv.rho
         P = T
-        DA = _scale_rows(A, omega * lv.dinv)                       # omega D^-1 A, once per level
+        DA = None
         for _ in range(psmooth):
-            P = (P - _spgemm(DA, P)).tocsr()
-        if trunc > 0:
+            Pn = _smooth_native(A, omega * lv.dinv, P) if native else None      # P - (omega D^-1 A) P in one pass of the library
+            if Pn is None:
+                if DA is None:
+                    DA = _scale_rows(A, omega * lv.dinv)                   # omega D^-1 A, once per level
+                Pn = (P - _spgemm(DA, P)).tocsr()
+            P = Pn
+        Pt = _truncate_native(P, trunc, nrm) if (trunc > 0 and native) else None
+        if Pt is not None:
+            P = Pt
+        elif trunc > 0:
             # prolongator truncation: drop entries below trunc * (row maximum) and rescale every row so that the
             # coarse near-null-space vector is still interpolated to the same fine values; keeps the convergence of
             # the smoothed prolongator at less than half its operator complexity (3.84 -> 1.57 at r=1)

@@ -615,3 +615,40 @@ def test_helper_transport_out_of_band_and_in_band(monkeypatch):
     W._dump(obj, io.BytesIO())
     W._shm_cleanup()
     assert set(glob.glob("/dev/shm/knp_setup_*")) == before
+
+
+def test_native_smoothed_aggregation_passes_give_the_same_hierarchy(monkeypatch):
+    """knp_host_strength / knp_host_smooth_prolongator / knp_host_truncate_prolongator (csrc/host_sparse.cpp) against the numpy / scipy lines
+    of amg.build_hierarchy they replace: the EMI and KNP hierarchies of the 124 416-tet mesh come out bit for bit the same (matrices,
+    prolongators, coarse inverse)."""
+    import build as _b
+    _b.build()
+    from knpemidg import amg
+    from knpemidg import mesh as M
+    m, s, f = M.make_mesh_3D(1)
+    nc = m.num_cells()
+    kappa = np.random.default_rng(0).uniform(0.5, 1.5, (nc, 4))
+    D = [{0: 1.33e-9, 1: 1.33e-9, 2: 1.33e-9}, {0: 2.03e-9, 1: 2.03e-9, 2: 2.03e-9}]          # 47 % apart: one hierarchy per species
+
+    def build():
+        cs = amg.ConformingSpace(m, f.array(), (1, 2))
+        return amg.build_emi_levels(cs, None, f.array(), (1, 2), kappa, 1.0), amg.build_knp_groups(cs, None, s.array(), D, 1.0e-4, 1)
+    monkeypatch.setenv("KNP_SETUP_NATIVE_SA", "1")
+    emi1, knp1 = build()
+    monkeypatch.setenv("KNP_SETUP_NATIVE_SA", "0")
+    emi0, knp0 = build()
+    assert emi1[0].A.shape[0] >= 20000 and len(emi1) >= 2 and len(knp1) == 2
+
+    def same(la, lb):
+        assert len(la) == len(lb)
+        for x, y in zip(la, lb):
+            for name in ("A", "P", "R"):
+                if hasattr(x, name):
+                    X, Y = getattr(x, name), getattr(y, name)
+                    assert np.array_equal(X.indptr, Y.indptr) and np.array_equal(X.indices, Y.indices) and np.array_equal(X.data, Y.data), name
+            assert np.array_equal(x.dinv, y.dinv) and x.rho == y.rho
+        assert np.array_equal(la[-1].pinv, lb[-1].pinv)
+    same(emi1, emi0)
+    for (ma, la), (mb, lb) in zip(knp1, knp0):
+        assert ma == mb
+        same(la, lb)
