@@ -238,7 +238,7 @@ class Solver:
         for k, ion in enumerate(self.ion_list):
             ion['E'] = DeviceFacetFunction(self.Q, dev, A.F_E, row=k)
         dev.upload(A.F_C, self._init_c)
-        dev.upload(A.F_C_PREV, self._init_c)
+        dev.copy_field(A.F_C_PREV, A.F_C)                            # the same values: one host-to-device transfer instead of two
         dev.upload(A.F_C_ELIM, self._init_c_elim)
         dev.upload(A.F_PHI_M, self._init_phi_M)
         self._push_params(splitting=True)
