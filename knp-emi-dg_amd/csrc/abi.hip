@@ -3,6 +3,7 @@
 #include "../../include/knpemi_hip.h"
 #include "knpemi_internal.hpp"
 #include <chrono>
+#include <thread>
 #include <cstdio>
 #include <cstdlib>
 #include "krylov.hpp"
@@ -121,6 +122,22 @@ AmgHierarchy* amg_slot(knp_ctx* c, int which) {
     return &c->amg[which];
 }
 
+// contiguous chunks of [0, n) on a few host threads (the O(cells) table loops of knp_ctx_create: 0.6 s in one thread at 8 x 10^6 tets)
+template <typename F> static void host_chunks(int64_t n, F f) {
+    int nt = (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    if (const char* ev = getenv("KNP_SETUP_THREADS")) nt = std::max(1, atoi(ev));
+    nt = std::min(nt, 64);                                             // callers keep per-thread results in 64 slots
+    if (n < (int64_t(1) << 16) || nt == 1) { f(0, n, 0); return; }
+    std::vector<std::thread> pool;
+    const int64_t chunk = (n + nt - 1) / nt;
+    for (int t = 0; t < nt; ++t) {
+        const int64_t lo = t * chunk, hi = std::min(n, lo + chunk);
+        if (lo >= hi) break;
+        pool.emplace_back([=]() { f(lo, hi, t); });
+    }
+    for (auto& th : pool) th.join();
+}
+
 extern "C" {
 
 const char* knp_last_error(knp_ctx* ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
@@ -163,8 +180,15 @@ int knp_ctx_create(knp_ctx** out, int device, int dim, int degree, int n_ions, i
     stamp("HIP runtime, stream");
 
     // ---- host-side validation + derived tables ------------------------------------------------
-    for (int64_t i = 0; i < nc * NV; ++i)
-        if (cells[i] < 0 || cells[i] >= nv) { g_err = "cell vertex index out of range"; delete c; return -1; }
+    {
+        int bad[64] = {0};
+        host_chunks(nc * NV, [&](int64_t lo, int64_t hi, int t) {
+            for (int64_t i = lo; i < hi; ++i)
+                if (cells[i] < 0 || cells[i] >= nv) bad[t & 63] = 1;
+        });
+        for (int b : bad)
+            if (b) { g_err = "cell vertex index out of range"; delete c; return -1; }
+    }
     // NOTE: the facet matching relies on both cells of a facet listing the shared vertices in the same
     // relative order (ascending ids in the caller's numbering); the ids themselves may be relabelled for
     // storage locality, so they are not required to be ascending here.
@@ -176,39 +200,53 @@ int knp_ctx_create(knp_ctx** out, int device, int dim, int degree, int n_ions, i
         for (int i = 0; i < n_membrane_tags; ++i) if (membrane_tags[i] == t) return true;
         return false;
     };
-    for (int64_t f = 0; f < nf; ++f) {
-        const int64_t c0 = facet_cells[2 * f], c1 = facet_cells[2 * f + 1];
-        const int l0 = facet_local[2 * f], l1 = facet_local[2 * f + 1];
-        if (c0 < 0 || c0 >= nc || l0 < 0 || l0 >= NV || c1 >= nc || (c1 >= 0 && (l1 < 0 || l1 >= NV))) {
-            g_err = "facet table entry out of range"; delete c; return -1;
-        }
-        cfacet[c0 * NV + l0] = (int32_t)f;
-        if (c1 < 0) continue;
-        cfacet[c1 * NV + l1] = (int32_t)f;
-        const uint32_t t = facet_tags[f];
-        const uint32_t kind = (t == 0) ? FK_SIPG : (is_mem(t) ? FK_MEMBRANE : FK_INACTIVE);
-        // plus (normal-leaving, lower tag) side; on equal tags the reference takes n('-'), i.e. side 1
-        const int e_side = (cell_tags[c0] >= cell_tags[c1]) ? 1 : 0;
-        nbr[c0 * NV + l0] = (int32_t)c1;
-        nbr[c1 * NV + l1] = (int32_t)c0;
-        fb[c0 * NV + l0] = (uint8_t)((l1 & 3) | (kind << 2) | ((e_side == 0 ? 1u : 0u) << 4));
-        fb[c1 * NV + l1] = (uint8_t)((l0 & 3) | (kind << 2) | ((e_side == 1 ? 1u : 0u) << 4));
-        if (kind == FK_MEMBRANE) {
-            const int64_t ce = e_side == 0 ? c0 : c1, ci = e_side == 0 ? c1 : c0;
-            const int le = e_side == 0 ? l0 : l1, li = e_side == 0 ? l1 : l0;
-            const int active = (ce < nc_owned || ci < nc_owned) ? 1 : 0;
-            mf.insert(mf.end(), {(int32_t)ce, (int32_t)ci, le, li, (int32_t)f, active});
-        }
+    {
+        // facets in contiguous chunks: a (cell, local facet) entry belongs to exactly one facet, so the chunks write disjoint entries; the
+        // membrane facets of a chunk are collected per chunk and appended in chunk order = facet order
+        std::vector<std::vector<int32_t>> mf_part(64);
+        int bad[64] = {0};
+        host_chunks(nf, [&](int64_t flo, int64_t fhi, int tid) {
+            auto& mine = mf_part[(size_t)(tid & 63)];
+            for (int64_t f = flo; f < fhi; ++f) {
+                const int64_t c0 = facet_cells[2 * f], c1 = facet_cells[2 * f + 1];
+                const int l0 = facet_local[2 * f], l1 = facet_local[2 * f + 1];
+                if (c0 < 0 || c0 >= nc || l0 < 0 || l0 >= NV || c1 >= nc || (c1 >= 0 && (l1 < 0 || l1 >= NV))) { bad[tid & 63] = 1; continue; }
+                cfacet[c0 * NV + l0] = (int32_t)f;
+                if (c1 < 0) continue;
+                cfacet[c1 * NV + l1] = (int32_t)f;
+                const uint32_t t = facet_tags[f];
+                const uint32_t kind = (t == 0) ? FK_SIPG : (is_mem(t) ? FK_MEMBRANE : FK_INACTIVE);
+                // plus (normal-leaving, lower tag) side; on equal tags the reference takes n('-'), i.e. side 1
+                const int e_side = (cell_tags[c0] >= cell_tags[c1]) ? 1 : 0;
+                nbr[c0 * NV + l0] = (int32_t)c1;
+                nbr[c1 * NV + l1] = (int32_t)c0;
+                fb[c0 * NV + l0] = (uint8_t)((l1 & 3) | (kind << 2) | ((e_side == 0 ? 1u : 0u) << 4));
+                fb[c1 * NV + l1] = (uint8_t)((l0 & 3) | (kind << 2) | ((e_side == 1 ? 1u : 0u) << 4));
+                if (kind == FK_MEMBRANE) {
+                    const int64_t ce = e_side == 0 ? c0 : c1, ci = e_side == 0 ? c1 : c0;
+                    const int le = e_side == 0 ? l0 : l1, li = e_side == 0 ? l1 : l0;
+                    const int active = (ce < nc_owned || ci < nc_owned) ? 1 : 0;
+                    mine.insert(mine.end(), {(int32_t)ce, (int32_t)ci, le, li, (int32_t)f, active});
+                }
+            }
+        });
+        for (int b : bad)
+            if (b) { g_err = "facet table entry out of range"; delete c; return -1; }
+        for (auto& part : mf_part) mf.insert(mf.end(), part.begin(), part.end());
+        int missing[64] = {0};
+        host_chunks(nc, [&](int64_t lo, int64_t hi, int tid) {
+            for (int64_t k = lo; k < hi; ++k) {
+                uint32_t w = 0;
+                for (int a = 0; a < NV; ++a) {
+                    w |= (uint32_t)fb[k * NV + a] << (8 * a);
+                    if (k < nc_owned && cfacet[k * NV + a] < 0) missing[tid & 63] = 1;     // owned cells must have every neighbour present (one ghost layer)
+                }
+                fflag[k] = w;
+            }
+        });
+        for (int b : missing)
+            if (b) { g_err = "owned cell with a facet missing from the facet table"; delete c; return -1; }
     }
-    for (int64_t k = 0; k < nc; ++k) {
-        uint32_t w = 0;
-        for (int a = 0; a < NV; ++a) w |= (uint32_t)fb[k * NV + a] << (8 * a);
-        fflag[k] = w;
-    }
-    // owned cells must have every neighbour present (one ghost layer)
-    for (int64_t k = 0; k < nc_owned; ++k)
-        for (int a = 0; a < NV; ++a)
-            if (cfacet[k * NV + a] < 0) { g_err = "owned cell with a facet missing from the facet table"; delete c; return -1; }
 
     stamp("facet flags, neighbours");
     c->h_fflag = fflag;
@@ -225,7 +263,9 @@ int knp_ctx_create(knp_ctx** out, int device, int dim, int degree, int n_ions, i
         cstride = 4;
     }
     std::vector<double> hcell(nc, 0.0);
-    for (int64_t k = 0; k < nc; ++k) {
+    std::vector<float> ivol((size_t)nc, 1.0f);                             // 1 / cell volume (weights of the residual norms)
+    host_chunks(nc, [&](int64_t klo, int64_t khi, int) {
+    for (int64_t k = klo; k < khi; ++k) {
         double h2 = 0.0;
         for (int a = 0; a < NV; ++a)
             for (int b = a + 1; b < NV; ++b) {
@@ -237,10 +277,6 @@ int knp_ctx_create(knp_ctx** out, int device, int dim, int degree, int n_ions, i
                 h2 = std::max(h2, d2);
             }
         hcell[k] = std::sqrt(h2);
-    }
-    // 1 / cell volume (weights of the residual norms)
-    std::vector<float> ivol((size_t)nc, 1.0f);
-    for (int64_t k = 0; k < nc; ++k) {
         double e[3][3] = {{0.0}};
         for (int a = 0; a < dim; ++a)
             for (int q = 0; q < dim; ++q)
@@ -251,6 +287,7 @@ int knp_ctx_create(knp_ctx** out, int device, int dim, int degree, int n_ions, i
         const double vol = std::fabs(det) / (dim == 2 ? 2.0 : 6.0);
         ivol[(size_t)k] = vol > 0.0 ? (float)(1.0 / vol) : 0.0f;
     }
+    });
     stamp("diameters, volumes");
     int rc = 0;
     rc |= dev_alloc_copy(c, &m.h, hcell.data(), hcell.size());

@@ -652,3 +652,37 @@ def test_native_smoothed_aggregation_passes_give_the_same_hierarchy(monkeypatch)
     for (ma, la), (mb, lb) in zip(knp1, knp0):
         assert ma == mb
         same(la, lb)
+
+
+def test_parallel_facet_builder_equals_the_serial_one(monkeypatch):
+    """knp_host_build_facets above 2^21 (cell, local facet) pairs: the compare-and-swap build on several threads numbers the facets exactly
+    like the serial loop (first appearance in (cell, local facet) order, side 0 = the first cell), in 3D and 2D, and still refuses a facet
+    with three cells."""
+    import build as _b
+    _b.build()
+    from knpemidg import _abi
+    from knpemidg import mesh as M
+    lib = _abi.load()
+
+    def run(cells, threads):
+        monkeypatch.setenv("KNP_SETUP_THREADS", str(threads))
+        nc, nv = cells.shape
+        cf, fa = np.empty((nc, nv), np.int32), np.empty((nc * nv, nv - 1), np.int32)
+        fc, fl = np.empty((nc * nv, 2), np.int32), np.empty((nc * nv, 2), np.int8)
+        nf = int(lib.knp_host_build_facets(nc, nv, _abi._p(cells, _abi._i32p), _abi._p(cf, _abi._i32p), _abi._p(fa, _abi._i32p), _abi._p(fc, _abi._i32p),
+                                           _abi._p(fl, _abi._i8p)))
+        return nf, cf, fa[:max(nf, 0)].copy(), fc[:max(nf, 0)].copy(), fl[:max(nf, 0)].copy()
+    m3 = M.BoxMesh((0, 0, 0), (1, 1, 1), 48, 48, 40)                                                                      # 552 960 tets: 2.2 M pairs
+    c3 = np.ascontiguousarray(m3.cells, dtype=np.int32)
+    assert c3.shape[0] * 4 >= 1 << 21
+    a, b = run(c3, 1), run(c3, 6)
+    assert a[0] == b[0] > 0 and all(np.array_equal(x, y) for x, y in zip(a[1:], b[1:]))
+    f = np.nonzero(m3.facet_cells[:, 1] >= 0)[0][4321]
+    extra = np.sort(np.concatenate([m3.facets[f], [m3.coords.shape[0] - 1]])).astype(np.int32)
+    bad = np.ascontiguousarray(np.vstack([c3, extra[None, :]]))
+    assert run(bad, 1)[0] == -2 and run(bad, 6)[0] == -2
+    m2 = M.RectangleMesh((0, 0), (4, 1), 700, 260, "crossed")                                                             # 728 000 triangles
+    c2 = np.ascontiguousarray(m2.cells, dtype=np.int32)
+    assert c2.shape[0] * 3 >= 1 << 21
+    a, b = run(c2, 1), run(c2, 6)
+    assert a[0] == b[0] > 0 and all(np.array_equal(x, y) for x, y in zip(a[1:], b[1:]))

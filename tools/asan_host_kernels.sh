@@ -26,6 +26,8 @@ o = _abi._morton_native(co, cl, sc); v = _abi._morton_native(co, None, sc)
 g = _abi.geometry_classes(m, o)
 cs = amg.ConformingSpace(m, f.array(), (1, 2))
 lv = amg.build_emi_levels(cs, None, f.array(), (1, 2), np.random.default_rng(0).uniform(0.5, 1.5, (nc, 4)), 1.0)
+big = M.BoxMesh((0, 0, 0), (1, 1, 1), 48, 48, 40)                # 2.2 M (cell, local facet) pairs: the parallel facet builder
+print("parallel facet builder:", big.num_facets(), "facets")
 print("levels", [l.A.shape[0] for l in lv], lv[-1].pinv.dtype, "classes", g[1].shape[0], "| 2D cells", M.make_mesh_2D(4)[0].num_cells())
 PY
 REPO=$PWD LD_PRELOAD=$(gcc -print-file-name=libasan.so):$(gcc -print-file-name=libubsan.so) ASAN_OPTIONS=detect_leaks=0 python /tmp/asan_host.py
