@@ -45,6 +45,12 @@ def _dump(obj, out):
                 f.write(b"\0" * (-r.nbytes % _SHM_ALIGN))                 # every array starts on a 64-byte boundary of the mapping
         head = {"payload": payload, "file": name, "sizes": [r.nbytes for r in raws]}
     except (OSError, ValueError, BufferError):
+        if "name" in locals():                        # a file that could not be written completely (/dev/shm too small): remove it now
+            try:
+                os.unlink(name)
+                _shm_made.remove(name)
+            except (OSError, ValueError):
+                pass
         head = {"inband": pickle.dumps(obj, protocol=pickle.HIGHEST_PROTOCOL)}
     pickle.dump(head, out, protocol=pickle.HIGHEST_PROTOCOL)
     out.flush()
