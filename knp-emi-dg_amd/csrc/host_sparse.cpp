@@ -37,37 +37,19 @@ int knp_host_spgemm(int64_t n, int64_t m, const int32_t* Ap, const int32_t* Aj, 
                     const double* Bx, int32_t* Cp, int32_t** Cj, double** Cx, int nthreads) {
     if (!Ap || !Bp || !Cp || !Cj || !Cx || n < 0 || m < 0) return -1;
     if (nthreads <= 0) nthreads = (int)std::max(1u, std::thread::hardware_concurrency());
-    std::vector<int64_t> cnt((size_t)n, 0);
-    // pass 1: row sizes
-    parallel_rows(n, nthreads, [&](int64_t lo, int64_t hi, int) {
-        std::vector<int32_t> mark((size_t)m, -1);
-        for (int64_t i = lo; i < hi; ++i) {
-            int64_t c = 0;
-            for (int32_t p = Ap[i]; p < Ap[i + 1]; ++p) {
-                const int32_t k = Aj[p];
-                for (int32_t q = Bp[k]; q < Bp[k + 1]; ++q)
-                    if (mark[Bj[q]] != (int32_t)i) { mark[Bj[q]] = (int32_t)i; ++c; }
-            }
-            cnt[i] = c;
-        }
-    });
-    int64_t nnz = 0;
-    for (int64_t i = 0; i < n; ++i) {
-        if (nnz > 2147483647LL) return -3;
-        Cp[i] = (int32_t)nnz;
-        nnz += cnt[i];
-    }
-    if (nnz > 2147483647LL) return -3;
-    Cp[n] = (int32_t)nnz;
-    *Cj = (int32_t*)std::malloc(sizeof(int32_t) * (size_t)std::max<int64_t>(nnz, 1));
-    *Cx = (double*)std::malloc(sizeof(double) * (size_t)std::max<int64_t>(nnz, 1));
-    if (!*Cj || !*Cx) return -2;
-    int32_t* cj = *Cj;
-    double* cx = *Cx;
-    // pass 2: numeric, sorted columns
-    parallel_rows(n, nthreads, [&](int64_t lo, int64_t hi, int) {
+    // one pass: every thread forms its contiguous chunk of rows (sorted columns) into its own buffer, a prefix sum over the row lengths places
+    // the buffers (the symbolic pass of the first version walked every product twice)
+    const int nt = n < 4096 ? 1 : nthreads;
+    const int64_t chunk = (n + nt - 1) / nt;
+    std::vector<std::vector<int32_t>> bj((size_t)nt);
+    std::vector<std::vector<double>> bx((size_t)nt);
+    std::vector<int32_t> len((size_t)n, 0);
+    auto work = [&](int t) {
+        const int64_t lo = t * chunk, hi = std::min(n, lo + chunk);
         std::vector<int32_t> pos((size_t)m, -1);
         std::vector<std::pair<int32_t, double>> row;
+        auto& oj = bj[(size_t)t];
+        auto& ox = bx[(size_t)t];
         for (int64_t i = lo; i < hi; ++i) {
             row.clear();
             for (int32_t p = Ap[i]; p < Ap[i + 1]; ++p) {
@@ -81,10 +63,33 @@ int knp_host_spgemm(int64_t n, int64_t m, const int32_t* Ap, const int32_t* Aj, 
             }
             for (auto& e : row) pos[e.first] = -1;
             std::sort(row.begin(), row.end(), [](const std::pair<int32_t, double>& u, const std::pair<int32_t, double>& v) { return u.first < v.first; });
-            int64_t o = Cp[i];
-            for (auto& e : row) { cj[o] = e.first; cx[o] = e.second; ++o; }
+            for (auto& e : row) { oj.push_back(e.first); ox.push_back(e.second); }
+            len[(size_t)i] = (int32_t)row.size();
         }
-    });
+    };
+    if (nt == 1) work(0);
+    else {
+        std::vector<std::thread> pool;
+        for (int t = 0; t < nt; ++t) pool.emplace_back([&, t]() { work(t); });
+        for (auto& th : pool) th.join();
+    }
+    int64_t nnz = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        if (nnz > 2147483647LL) return -3;
+        Cp[i] = (int32_t)nnz;
+        nnz += len[(size_t)i];
+    }
+    if (nnz > 2147483647LL) return -3;
+    Cp[n] = (int32_t)nnz;
+    *Cj = (int32_t*)std::malloc(sizeof(int32_t) * (size_t)std::max<int64_t>(nnz, 1));
+    *Cx = (double*)std::malloc(sizeof(double) * (size_t)std::max<int64_t>(nnz, 1));
+    if (!*Cj || !*Cx) return -2;
+    for (int t = 0; t < nt; ++t) {
+        const int64_t lo = t * chunk;
+        if (lo >= n) break;
+        std::memcpy(*Cj + Cp[lo], bj[(size_t)t].data(), sizeof(int32_t) * bj[(size_t)t].size());
+        std::memcpy(*Cx + Cp[lo], bx[(size_t)t].data(), sizeof(double) * bx[(size_t)t].size());
+    }
     return 0;
 }
 
@@ -766,12 +771,21 @@ int knp_host_smooth_prolongator(int64_t n, int64_t m, const int32_t* Ap, const i
                                 const int32_t* Pj, const double* Px, int32_t* Cp, int32_t** Cj, double** Cx, int nthreads) {
     if (!Ap || !Aj || !Ax || !v || !Pp || !Pj || !Px || !Cp || !Cj || !Cx || n < 0 || m < 0) return -1;
     if (nthreads <= 0) nthreads = (int)std::max(1u, std::thread::hardware_concurrency());
-    // rows are formed once into per-thread buffers (values needed to know which entries vanish), then copied behind a prefix sum
-    std::vector<std::vector<std::pair<int32_t, double>>> rows((size_t)n);
-    parallel_rows(n, nthreads, [&](int64_t lo, int64_t hi, int) {
+    // rows are formed once (their values decide which entries vanish) into ONE buffer per thread, row after row; a prefix sum over the row
+    // lengths then places the threads' buffers in the result
+    if (nthreads < 1) nthreads = 1;
+    const int nt = n < 4096 ? 1 : nthreads;
+    const int64_t chunk = (n + nt - 1) / nt;
+    std::vector<std::vector<int32_t>> bj((size_t)nt);
+    std::vector<std::vector<double>> bx((size_t)nt);
+    std::vector<int32_t> len((size_t)n, 0);
+    auto work = [&](int t) {
+        const int64_t lo = t * chunk, hi = std::min(n, lo + chunk);
         std::vector<int32_t> pos((size_t)m, -1);
         std::vector<std::pair<int32_t, double>> row;
         std::vector<uint8_t> inP;
+        auto& oj = bj[(size_t)t];
+        auto& ox = bx[(size_t)t];
         for (int64_t i = lo; i < hi; ++i) {
             row.clear();
             for (int32_t p = Ap[i]; p < Ap[i + 1]; ++p) {
@@ -793,27 +807,31 @@ int knp_host_smooth_prolongator(int64_t n, int64_t m, const int32_t* Ap, const i
             for (size_t e = 0; e < nprod; ++e)
                 if (!inP[e]) row[e].second = -row[e].second;               // 0 - product
             for (auto& e : row) pos[e.first] = -1;
-            auto& out = rows[(size_t)i];
-            out.reserve(row.size());
+            std::sort(row.begin(), row.end(), [](const std::pair<int32_t, double>& a_, const std::pair<int32_t, double>& b_) { return a_.first < b_.first; });
+            int32_t kept = 0;
             for (auto& e : row)
-                if (e.second != 0.0) out.push_back(e);
-            std::sort(out.begin(), out.end(), [](const std::pair<int32_t, double>& a_, const std::pair<int32_t, double>& b_) { return a_.first < b_.first; });
+                if (e.second != 0.0) { oj.push_back(e.first); ox.push_back(e.second); ++kept; }
+            len[(size_t)i] = kept;
         }
-    });
+    };
+    if (nt == 1) work(0);
+    else {
+        std::vector<std::thread> pool;
+        for (int t = 0; t < nt; ++t) pool.emplace_back([&, t]() { work(t); });
+        for (auto& th : pool) th.join();
+    }
     int64_t nnz = 0;
-    for (int64_t i = 0; i < n; ++i) { Cp[i] = (int32_t)nnz; nnz += (int64_t)rows[(size_t)i].size(); if (nnz > 2147483647LL) return -3; }
+    for (int64_t i = 0; i < n; ++i) { Cp[i] = (int32_t)nnz; nnz += len[(size_t)i]; if (nnz > 2147483647LL) return -3; }
     Cp[n] = (int32_t)nnz;
     *Cj = (int32_t*)std::malloc(sizeof(int32_t) * (size_t)std::max<int64_t>(nnz, 1));
     *Cx = (double*)std::malloc(sizeof(double) * (size_t)std::max<int64_t>(nnz, 1));
     if (!*Cj || !*Cx) return -2;
-    int32_t* cj = *Cj;
-    double* cx = *Cx;
-    parallel_rows(n, nthreads, [&](int64_t lo, int64_t hi, int) {
-        for (int64_t i = lo; i < hi; ++i) {
-            int64_t o = Cp[i];
-            for (auto& e : rows[(size_t)i]) { cj[o] = e.first; cx[o] = e.second; ++o; }
-        }
-    });
+    for (int t = 0; t < nt; ++t) {
+        const int64_t lo = t * chunk;
+        if (lo >= n) break;
+        std::memcpy(*Cj + Cp[lo], bj[(size_t)t].data(), sizeof(int32_t) * bj[(size_t)t].size());
+        std::memcpy(*Cx + Cp[lo], bx[(size_t)t].data(), sizeof(double) * bx[(size_t)t].size());
+    }
     return 0;
 }
 
