@@ -25,7 +25,8 @@ _shm_made = []                # files this process wrote and whose receiver may 
 _shm_count = [0]
 
 
-def _dump(obj, out):
+def _dump(obj, out, name=None):
+    """name: the file to use (the helper writes its result into a file its PARENT named and will remove whatever happens to the helper)."""
     bufs = []
     try:
         payload = pickle.dumps(obj, protocol=5, buffer_callback=bufs.append)
@@ -36,8 +37,8 @@ def _dump(obj, out):
         if not _shm_made:
             import atexit
             atexit.register(_shm_cleanup)
-        name = os.path.join(_SHM_DIR, "knp_setup_%d_%d" % (os.getpid(), _shm_count[0]))
-        _shm_count[0] += 1
+        if name is None:
+            name = _new_name()
         with open(name, "wb") as f:
             _shm_made.append(name)
             for r in raws:
@@ -45,15 +46,24 @@ def _dump(obj, out):
                 f.write(b"\0" * (-r.nbytes % _SHM_ALIGN))                 # every array starts on a 64-byte boundary of the mapping
         head = {"payload": payload, "file": name, "sizes": [r.nbytes for r in raws]}
     except (OSError, ValueError, BufferError):
-        if "name" in locals():                        # a file that could not be written completely (/dev/shm too small): remove it now
+        if name:                                      # a file that could not be written completely (/dev/shm too small): remove it now
             try:
                 os.unlink(name)
+            except OSError:
+                pass
+            try:
                 _shm_made.remove(name)
-            except (OSError, ValueError):
+            except ValueError:
                 pass
         head = {"inband": pickle.dumps(obj, protocol=pickle.HIGHEST_PROTOCOL)}
     pickle.dump(head, out, protocol=pickle.HIGHEST_PROTOCOL)
     out.flush()
+    return head.get("file")
+
+
+def _new_name():
+    _shm_count[0] += 1
+    return os.path.join(_SHM_DIR, "knp_setup_%d_%d" % (os.getpid(), _shm_count[0]))
 
 
 def _load(inp):
@@ -75,6 +85,18 @@ def _load(inp):
         bufs.append(view[off:off + n])
         off += n + (-n % _SHM_ALIGN)
     return pickle.loads(head["payload"], buffers=bufs)
+
+
+def _remove(name):
+    if name:
+        try:
+            os.unlink(name)
+        except OSError:
+            pass
+        try:
+            _shm_made.remove(name)
+        except ValueError:
+            pass
 
 
 def _shm_cleanup():
@@ -120,6 +142,7 @@ def run(job):
 def main():
     out = sys.stdout.buffer
     sys.stdout = sys.stderr                       # nothing but the result may reach the pipe
+    job = None
     try:
         # everything the job needs is imported BEFORE the job arrives: a helper started ahead of time (prestart) spends the
         # interpreter / numpy / scipy / library start-up (0.6 s) while the parent is still building its mesh
@@ -137,7 +160,7 @@ def main():
     except BaseException as e:                    # reported to the parent, which falls back to building in-process
         import traceback
         res = {"error": "%s\n%s" % (e, traceback.format_exc())}
-    _dump(res, out)
+    _dump(res, out, name=(job or {}).get("_result_file") if isinstance(job, dict) else None)
     try:
         _abi._stamp("helper: result sent")
     except Exception:
@@ -212,10 +235,19 @@ def start(job):
     if proc is None:
         proc = _spawn()
     handle = {"proc": proc, "result": None}
+    if os.path.isdir(_SHM_DIR):
+        # the helper's result file is named (and, on every path, removed) by this process: a helper killed after it wrote the file
+        # cannot clean up after itself
+        job = dict(job, _result_file=_new_name())
+        _shm_made.append(job["_result_file"])
+        handle["result_file"] = job["_result_file"]
+        handle["job_file"] = _new_name()                   # named here, so that it can be removed even if the hand-over itself is cut short
+        import atexit
+        atexit.register(_shm_cleanup)
 
     def feed():
         try:
-            _dump(job, proc.stdin)
+            _dump(job, proc.stdin, name=handle.get("job_file"))
             handle["result"] = _load(proc.stdout)
             proc.stdin.close()                              # the helper waits for this before it removes what it wrote and leaves
         except BaseException as e:
@@ -227,6 +259,8 @@ def start(job):
                 except OSError:
                     pass
             proc.wait()
+            _remove(handle.get("result_file"))              # already gone when the result was loaded; left behind by a helper that was killed
+            _remove(handle.get("job_file"))                 # likewise: the helper unlinks it when it maps it
     th = threading.Thread(target=feed, name="knp-amg-helper-io", daemon=True)
     th.start()
     handle["thread"] = th

@@ -686,3 +686,28 @@ def test_parallel_facet_builder_equals_the_serial_one(monkeypatch):
     assert c2.shape[0] * 3 >= 1 << 21
     a, b = run(c2, 1), run(c2, 6)
     assert a[0] == b[0] > 0 and all(np.array_equal(x, y) for x, y in zip(a[1:], b[1:]))
+
+
+def test_cancelled_helpers_leave_nothing_in_dev_shm():
+    """setup_worker.cancel at any moment of a hand-over (before the helper mapped the job file, while it works, after it wrote its result file):
+    both files are named by the parent and removed by it on every path."""
+    import glob
+    import time
+    from knpemidg import setup_worker as W
+    from knpemidg import mesh as M
+    if not os.path.isdir("/dev/shm"):
+        pytest.skip("no /dev/shm")
+    m, s, f = M.make_mesh_3D(0)
+    kappa = np.random.default_rng(0).uniform(0.5, 1.5, (m.num_cells(), 4))
+    job = W.emi_job(m, f.array(), [1, 2], 1, kappa, 1.0)                    # 1.7 MB of arrays: out of band
+    before = set(glob.glob("/dev/shm/knp_setup_*"))
+    for delay in (0.0, 0.05, 0.4, 1.5):
+        h = W.start(job)
+        time.sleep(delay)
+        W.cancel(h)
+        time.sleep(0.2)
+        assert set(glob.glob("/dev/shm/knp_setup_*")) == before, delay
+    h = W.start(job)
+    res = W.collect(h)
+    assert res is not None and len(res["levels"]) >= 1
+    assert set(glob.glob("/dev/shm/knp_setup_*")) == before
